@@ -1,0 +1,14 @@
+"""MI355X-native (gfx950) implementation of the per-pixel atmosphere / volumetric-cloud raymarch of
+Zylann/godot_atmosphere_shader, behind the reference's `PlanetAtmosphere` / `shader_params` surface.
+
+  csrc/                 hand-written HIP kernels + the C ABI of include/atmo.h (libatmo_hip.so)
+  planet_atmosphere.py  host-side mirror of addons/zylann.atmosphere/planet_atmosphere.gd
+  scene.py              synthetic inputs (camera, depth, jitter, cloud textures) for tests and bench
+  sharding.py           row-band / viewport sharding across the GPUs of a node + RCCL gather
+"""
+from .planet_atmosphere import (  # noqa: F401
+    DefaultShader, PlanetAtmosphere, Shader, SHADERS, Transform2D, atmosphere_vertex, load_shader, make_frame,
+)
+
+__all__ = ["PlanetAtmosphere", "Shader", "SHADERS", "DefaultShader", "Transform2D", "load_shader",
+           "atmosphere_vertex", "make_frame"]

@@ -1,0 +1,92 @@
+"""ctypes binding of the C ABI in include/atmo.h (libatmo_hip.so).
+
+There is no CPU fallback: if the library is missing or no gfx950 device is present, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .build import LIB_PATH
+
+ATMO_OK, ATMO_E_NAME, ATMO_E_ARG, ATMO_E_STATE, ATMO_E_HIP, ATMO_E_NO_DEVICE = range(6)
+VARIANT_NO_CLOUDS, VARIANT_CLOUDS, VARIANT_CLOUDS_HIGH, VARIANT_CLOUDS_HIGH_RM = range(4)
+LIGHT_LUT, LIGHT_DIRECT = 0, 1
+TEX_2D_R32F, TEX_2D_R8, TEX_3D_R8, TEX_CUBE_R8 = range(4)
+MEM_HOST, MEM_DEVICE = 0, 1
+ABI_VERSION = 1
+
+# every symbol include/atmo.h declares
+EXPORTED_SYMBOLS = (
+    "atmo_abi_version", "atmo_device_count", "atmo_create", "atmo_destroy", "atmo_set_param_f32",
+    "atmo_get_param_f32", "atmo_set_texture", "atmo_bake_optical_depth", "atmo_read_optical_depth",
+    "atmo_render", "atmo_set_timing", "atmo_get_timing", "atmo_kernel_name", "atmo_last_error_string",
+)
+
+
+class AtmoFrame(C.Structure):
+    _fields_ = [
+        ("inv_projection_matrix", C.c_float * 16),
+        ("inv_view_matrix", C.c_float * 16),
+        ("viewport_w", C.c_int32),
+        ("viewport_h", C.c_int32),
+        ("planet_center_viewspace", C.c_float * 3),
+        ("sun_center_viewspace", C.c_float * 3),
+        ("time", C.c_float),
+        ("x0", C.c_int32),
+        ("y0", C.c_int32),
+        ("x1", C.c_int32),
+        ("y1", C.c_int32),
+    ]
+
+
+class AtmoError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libatmo_hip error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libatmo_hip.so; raises if it has not been built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the gfx950 HIP extension has not been built "
+            "(python -m godot_atmosphere_shader_amd.build). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, cp, ip, fp = C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_float)
+    sig = {
+        "atmo_abi_version": (ip, []),
+        "atmo_device_count": (ip, []),
+        "atmo_create": (ip, [ip, ip, ip, ip, ip, ip, C.POINTER(vp)]),
+        "atmo_destroy": (ip, [vp]),
+        "atmo_set_param_f32": (ip, [vp, cp, fp, ip]),
+        "atmo_get_param_f32": (ip, [vp, cp, fp, ip]),
+        "atmo_set_texture": (ip, [vp, cp, ip, ip, ip, ip, vp, ip]),
+        "atmo_bake_optical_depth": (ip, [vp, vp]),
+        "atmo_read_optical_depth": (ip, [vp, vp, vp, ip, vp]),
+        "atmo_render": (ip, [vp, C.POINTER(AtmoFrame), vp, vp, vp]),
+        "atmo_set_timing": (ip, [vp, ip]),
+        "atmo_get_timing": (ip, [vp, C.POINTER(ip), C.POINTER(C.c_double)]),
+        "atmo_kernel_name": (cp, [vp]),
+        "atmo_last_error_string": (cp, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.atmo_abi_version() != ABI_VERSION:
+        raise RuntimeError("libatmo_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(ctx, code: int) -> None:
+    if code != ATMO_OK:
+        msg = load().atmo_last_error_string(ctx)
+        raise AtmoError(code, msg.decode() if msg else "")

@@ -1,0 +1,51 @@
+"""Builds libatmo_hip.so (the gfx950 kernels + C ABI) in-tree with hipcc.
+
+hipcc cross-compiles for gfx950 without a GPU.  The .so lands next to this file so that it travels
+with the source tree; it is git-ignored, never pip-installed.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libatmo_hip.so")
+SOURCES = ["atmo_api.hip", "atmo_kernels.hip"]
+HEADERS = ["atmo_device.h", os.path.join("..", "..", "include", "atmo.h")]
+
+# -ffp-contract=off: the kernels and the host-side per-frame constants must round exactly like a scalar
+# fp32 evaluation of the shader wherever control flow or the ill-conditioned cloud chain is involved;
+# hot loops opt back into FMA with `#pragma clang fp contract(fast)`.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the gfx950 extension cannot be built")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP extension if it is missing or stale; returns the library path."""
+    if force or needs_build():
+        cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_native(force=True, verbose=True))

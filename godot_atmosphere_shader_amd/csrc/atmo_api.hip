@@ -1,0 +1,548 @@
+// atmo_api.hip -- host side of the C ABI declared in include/atmo.h.
+//
+// Holds the uniform table (the reference's `shader_params` names), owns the device copies of the four
+// textures, evaluates the per-frame (pixel-independent) expressions of the shader once per launch in
+// fp32 in the reference's operation order (this file is built with -ffp-contract=off, so nothing is
+// fused), and enqueues the gfx950 kernels of atmo_kernels.hip.  There is no CPU fallback: without a
+// HIP device every compute entry point fails with ATMO_E_NO_DEVICE / ATMO_E_HIP.
+#include "../../include/atmo.h"
+#include "atmo_device.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct ParamDesc {
+    const char *name;
+    int count;
+    size_t offset;
+};
+
+// The reference's uniforms with their GDShader defaults.
+struct Params {
+    float u_planet_radius = 1.0f;                            // planet_common.gdshaderinc:4
+    float u_atmosphere_height = 0.1f;                        // :5
+    float u_sun_position[3] = {0, 0, 0};                     // :6 (host-side only: feeds sun_center_viewspace)
+    float u_density = 0.2f;                                  // atmosphere_common.gdshaderinc:10
+    float u_scattering_strength = 20.0f;                     // atmosphere_funcs_v2.gdshaderinc:8
+    float u_scattering_wavelengths[3] = {700, 530, 440};     // :9
+    float u_atmosphere_modulate[3] = {1, 1, 1};              // :10
+    float u_atmosphere_ambient_color[3] = {0, 0, 0.002f};    // :11
+    float u_clip_mode = 0.0f;                                // main:55 (rasteriser only; stored, unused)
+    float u_sphere_depth_factor = 0.0f;                      // main:60
+    float u_cloud_density_scale = 50.0f;                     // cloud_funcs.gdshaderinc:5
+    float u_cloud_bottom = 0.2f;                             // :6
+    float u_cloud_top = 0.5f;                                // :7
+    float u_cloud_blend = 0.5f;                              // :8
+    float u_world_to_model_matrix[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};  // :9
+    float u_cloud_shape_invert = 0.0f;                       // :11
+    float u_cloud_coverage_bias = 0.0f;                      // :12
+    float u_cloud_shape_factor = 0.8f;                       // :13
+    float u_cloud_shape_scale = 1.0f;                        // :14
+    float u_cloud_coverage_rotation[4] = {1, 0, 0, 1};       // :16
+};
+
+#define PD(field, n) {#field, n, offsetof(Params, field)}
+const ParamDesc kParams[] = {
+    PD(u_planet_radius, 1), PD(u_atmosphere_height, 1), PD(u_sun_position, 3), PD(u_density, 1),
+    PD(u_scattering_strength, 1), PD(u_scattering_wavelengths, 3), PD(u_atmosphere_modulate, 3),
+    PD(u_atmosphere_ambient_color, 3), PD(u_clip_mode, 1), PD(u_sphere_depth_factor, 1),
+    PD(u_cloud_density_scale, 1), PD(u_cloud_bottom, 1), PD(u_cloud_top, 1), PD(u_cloud_blend, 1),
+    PD(u_world_to_model_matrix, 16), PD(u_cloud_shape_invert, 1), PD(u_cloud_coverage_bias, 1),
+    PD(u_cloud_shape_factor, 1), PD(u_cloud_shape_scale, 1), PD(u_cloud_coverage_rotation, 4),
+};
+#undef PD
+
+const ParamDesc *find_param(const char *name) {
+    if (!name) return nullptr;
+    for (const ParamDesc &d : kParams)
+        if (std::strcmp(d.name, name) == 0) return &d;
+    return nullptr;
+}
+
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+thread_local std::string g_create_error = "";
+
+}  // namespace
+
+struct AtmoContext {
+    int device = 0;
+    int variant = 0;
+    int flags = 0;
+    int view_steps = 8, cloud_steps = 0, light_steps = 0;
+    Params p;
+    DeviceBuffer lut, blue, shape, cube;
+    int lut_w = 0, lut_h = 0, shape_n = 0, cube_n = 0;
+    bool timing = false;
+    int timed_launches = 0;
+    double timed_ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // events not yet read back
+    std::string err;
+};
+
+namespace {
+
+int fail(AtmoContext *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+int hip_fail(AtmoContext *ctx, hipError_t e, const char *what) {
+    return fail(ctx, ATMO_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(ctx, call)                                   \
+    do {                                                     \
+        hipError_t e_ = (call);                              \
+        if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); \
+    } while (0)
+
+int dev_alloc(AtmoContext *ctx, DeviceBuffer &b, size_t bytes) {
+    if (b.ptr && b.bytes == bytes) return ATMO_OK;
+    if (b.ptr) { (void)hipFree(b.ptr); b.ptr = nullptr; b.bytes = 0; }
+    if (bytes == 0) return ATMO_OK;
+    HIP_TRY(ctx, hipMalloc(&b.ptr, bytes));
+    b.bytes = bytes;
+    return ATMO_OK;
+}
+
+void dev_free(DeviceBuffer &b) {
+    if (b.ptr) (void)hipFree(b.ptr);
+    b.ptr = nullptr;
+    b.bytes = 0;
+}
+
+// ---- cubemap apron -----------------------------------------------------------------------------------
+// The kernel samples each face as an (n+2)^2 image whose border row/column holds the texels that lie
+// across the cube edge (seamless filtering) and whose corners hold the mean of the three faces' corner
+// texels.  Faces +X,-X,+Y,-Y,+Z,-Z; Vulkan face table (same as noise_cubemap.gd:110-128).
+struct FaceBasis { int major[3], s[3], t[3]; };
+const FaceBasis kFaces[6] = {
+    {{1, 0, 0}, {0, 0, -1}, {0, -1, 0}}, {{-1, 0, 0}, {0, 0, 1}, {0, -1, 0}},
+    {{0, 1, 0}, {1, 0, 0}, {0, 0, 1}},   {{0, -1, 0}, {1, 0, 0}, {0, 0, -1}},
+    {{0, 0, 1}, {1, 0, 0}, {0, -1, 0}},  {{0, 0, -1}, {-1, 0, 0}, {0, -1, 0}},
+};
+
+// Integer cube-surface coordinates: texel centre (i,j) of face f sits at 2*i+1-n, 2*j+1-n in the face
+// plane and at n on the major axis (units of half texels).  Stepping one texel off the face keeps the
+// in-plane coordinate at the edge (+-n) and moves the major-axis coordinate in by one texel (n-1 ... in
+// half-texel units: n - 1), which is a texel centre of the neighbouring face.
+uint8_t cube_fold(const uint8_t *faces, int n, int f, int i, int j) {
+    const FaceBasis &fb = kFaces[f];
+    int sc = 2 * i + 1 - n, tc = 2 * j + 1 - n, ma = n;
+    if (i < 0) { sc = -n; ma = n - 1; } else if (i >= n) { sc = n; ma = n - 1; }
+    if (j < 0) { tc = -n; ma = n - 1; } else if (j >= n) { tc = n; ma = n - 1; }
+    int p[3];
+    for (int a = 0; a < 3; ++a) p[a] = fb.major[a] * ma + fb.s[a] * sc + fb.t[a] * tc;
+    // which face is this point on?  exactly one coordinate has magnitude n
+    int f2 = -1;
+    for (int g = 0; g < 6 && f2 < 0; ++g) {
+        const FaceBasis &gb = kFaces[g];
+        int m = gb.major[0] * p[0] + gb.major[1] * p[1] + gb.major[2] * p[2];
+        if (m == n) f2 = g;
+    }
+    const FaceBasis &gb = kFaces[f2];
+    int s2 = gb.s[0] * p[0] + gb.s[1] * p[1] + gb.s[2] * p[2];
+    int t2 = gb.t[0] * p[0] + gb.t[1] * p[1] + gb.t[2] * p[2];
+    int i2 = (s2 + n - 1) / 2, j2 = (t2 + n - 1) / 2;
+    if (i2 < 0) i2 = 0; if (i2 > n - 1) i2 = n - 1;
+    if (j2 < 0) j2 = 0; if (j2 > n - 1) j2 = n - 1;
+    return faces[((size_t)f2 * n + j2) * n + i2];
+}
+
+void build_cube_apron(const uint8_t *faces, int n, std::vector<uint8_t> &out) {
+    const int st = n + 2;
+    out.assign((size_t)6 * st * st, 0);
+    for (int f = 0; f < 6; ++f)
+        for (int j = -1; j <= n; ++j)
+            for (int i = -1; i <= n; ++i) {
+                const bool oi = (i < 0 || i >= n), oj = (j < 0 || j >= n);
+                int v;
+                if (!oi && !oj) {
+                    v = faces[((size_t)f * n + j) * n + i];
+                } else if (oi && oj) {
+                    const int ci = i < 0 ? 0 : n - 1, cj = j < 0 ? 0 : n - 1;
+                    const int a = faces[((size_t)f * n + cj) * n + ci];
+                    const int b = cube_fold(faces, n, f, i, cj);
+                    const int c = cube_fold(faces, n, f, ci, j);
+                    v = (a + b + c + 1) / 3;
+                } else {
+                    v = cube_fold(faces, n, f, i, j);
+                }
+                out[((size_t)f * st + (j + 1)) * st + (i + 1)] = (uint8_t)v;
+            }
+}
+
+// ---- per-frame constants, evaluated like a scalar fp32 run of the shader would ----------------------------
+inline float pow2f(float x) { return x * x; }
+inline float pow4f(float x) { return x * x * x * x; }
+inline float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+inline float clampf(float x, float lo, float hi) { return std::fmin(std::fmax(x, lo), hi); }
+inline float smoothstepf(float e0, float e1, float x) {
+    float t = clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+
+void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth, float *rgba, atmo::RenderConsts &rc) {
+    const Params &p = ctx->p;
+    std::memset(&rc, 0, sizeof(rc));
+    std::memcpy(rc.inv_p, f->inv_projection_matrix, sizeof(rc.inv_p));
+    std::memcpy(rc.inv_v, f->inv_view_matrix, sizeof(rc.inv_v));
+    const float *V = f->inv_view_matrix;
+    // inv_view * (0,0,0,1), summed left to right (main:136)
+    for (int r = 0; r < 3; ++r) rc.cam_pos_world[r] = V[0 + r] * 0.0f + V[4 + r] * 0.0f + V[8 + r] * 0.0f + V[12 + r] * 1.0f;
+    rc.vw = (float)f->viewport_w;
+    rc.vh = (float)f->viewport_h;
+    rc.w = f->viewport_w; rc.h = f->viewport_h;
+    rc.x0 = f->x0; rc.y0 = f->y0; rc.x1 = f->x1; rc.y1 = f->y1;
+    for (int i = 0; i < 3; ++i) rc.center[i] = f->planet_center_viewspace[i];
+    {   // sun_dir = normalize(sun_center_vs - planet_center_vs)  (main:164)
+        float d[3];
+        for (int i = 0; i < 3; ++i) d[i] = f->sun_center_viewspace[i] - f->planet_center_viewspace[i];
+        float inv = 1.0f / std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        for (int i = 0; i < 3; ++i) rc.sun_dir[i] = d[i] * inv;
+    }
+    rc.planet_radius = p.u_planet_radius;
+    rc.atmosphere_height = p.u_atmosphere_height;
+    rc.atmosphere_radius = p.u_planet_radius + p.u_atmosphere_height;
+    rc.density = p.u_density;
+    rc.sphere_depth_factor = p.u_sphere_depth_factor;
+    for (int i = 0; i < 3; ++i) {
+        rc.coeff[i] = pow4f(400.0f / p.u_scattering_wavelengths[i]) * p.u_scattering_strength;  // v2:47-51
+        rc.ambient[i] = p.u_atmosphere_ambient_color[i];
+        rc.modulate[i] = p.u_atmosphere_modulate[i];
+    }
+    rc.view_steps = ctx->view_steps;
+    rc.light_steps = ctx->light_steps;
+
+    // clouds (cloud_funcs.gdshaderinc:260-261, 285-294, 186-206, 108-115)
+    rc.clouds_bottom = p.u_planet_radius + p.u_cloud_bottom * p.u_atmosphere_height;
+    rc.clouds_top = p.u_planet_radius + p.u_cloud_top * p.u_atmosphere_height;
+    rc.cloud_thickness = rc.clouds_top - rc.clouds_bottom;
+    rc.cloud_density_scale = p.u_cloud_density_scale;
+    rc.cloud_blend = p.u_cloud_blend;
+    rc.coverage_bias = p.u_cloud_coverage_bias;
+    rc.shape_factor = p.u_cloud_shape_factor;
+    rc.shape_scale = p.u_cloud_shape_scale;
+    rc.shape_invert = (p.u_cloud_shape_invert == 1.0f) ? 1 : 0;
+    std::memcpy(rc.cov_rot, p.u_cloud_coverage_rotation, sizeof(rc.cov_rot));
+    const float *A = p.u_world_to_model_matrix;
+    for (int col = 0; col < 4; ++col)
+        for (int row = 0; row < 4; ++row)
+            rc.view_to_model[col * 4 + row] = A[0 * 4 + row] * V[col * 4 + 0] + A[1 * 4 + row] * V[col * 4 + 1] +
+                                              A[2 * 4 + row] * V[col * 4 + 2] + A[3 * 4 + row] * V[col * 4 + 3];
+    const float *M = rc.view_to_model;
+    for (int r = 0; r < 3; ++r) {
+        rc.origin_model[r] = M[0 + r] * 0.0f + M[4 + r] * 0.0f + M[8 + r] * 0.0f + M[12 + r] * 1.0f;
+        rc.sun_dir_model[r] = M[0 + r] * rc.sun_dir[0] + M[4 + r] * rc.sun_dir[1] + M[8 + r] * rc.sun_dir[2] + M[12 + r] * 0.0f;
+    }
+    {
+        const float ground = p.u_planet_radius, top = rc.clouds_top, bottom = rc.clouds_bottom;
+        const float space = 0.5f * std::sqrt(1.0f - pow2f(ground / top)) * bottom;
+        const float groundd = 3.0f * space;
+        const float len = std::sqrt(rc.origin_model[0] * rc.origin_model[0] + rc.origin_model[1] * rc.origin_model[1] +
+                                    rc.origin_model[2] * rc.origin_model[2]);
+        rc.max_d = mixf(groundd, space, smoothstepf(bottom, top * 1.05f, len));
+    }
+    rc.cloud_steps = ctx->cloud_steps;
+    rc.inv_cloud_steps = ctx->cloud_steps > 0 ? 1.0f / (float)ctx->cloud_steps : 0.0f;
+    {
+        const float reach = (rc.clouds_top - rc.clouds_bottom) * 0.15f;
+        const float inv_steps = 1.0f / 6.0f;
+        rc.rm_step0 = reach * inv_steps;
+    }
+    rc.lut = (const float *)ctx->lut.ptr; rc.lut_w = ctx->lut_w; rc.lut_h = ctx->lut_h;
+    rc.blue = (const uint8_t *)ctx->blue.ptr;
+    rc.shape = (const uint8_t *)ctx->shape.ptr; rc.shape_n = ctx->shape_n;
+    rc.cube = (const uint8_t *)ctx->cube.ptr; rc.cube_n = ctx->cube_n;
+    rc.depth = depth;
+    rc.out = (float4 *)rgba;
+}
+
+void drain_timing(AtmoContext *ctx) {
+    for (auto &pr : ctx->pending) {
+        if (hipEventSynchronize(pr.second) == hipSuccess) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                ctx->timed_ms += ms;
+                ctx->timed_launches += 1;
+            }
+        }
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    ctx->pending.clear();
+}
+
+}  // namespace
+
+extern "C" {
+
+int atmo_abi_version(void) { return ATMO_ABI_VERSION; }
+
+int atmo_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return -ATMO_E_NO_DEVICE;
+    return n;
+}
+
+int atmo_create(int device, int variant, int view_steps, int cloud_steps, int light_mode, int light_steps,
+                AtmoContext **out) {
+    if (!out) return fail(nullptr, ATMO_E_ARG, "atmo_create: out is null");
+    *out = nullptr;
+    if (variant < ATMO_VARIANT_NO_CLOUDS || variant > ATMO_VARIANT_CLOUDS_HIGH_RM)
+        return fail(nullptr, ATMO_E_ARG, "atmo_create: unknown variant");
+    if (light_mode != ATMO_LIGHT_LUT && light_mode != ATMO_LIGHT_DIRECT)
+        return fail(nullptr, ATMO_E_ARG, "atmo_create: unknown light mode");
+    if (view_steps < 0 || view_steps > 4096 || cloud_steps < 0 || cloud_steps > 4096 || light_steps < 0 || light_steps > 4096)
+        return fail(nullptr, ATMO_E_ARG, "atmo_create: step count out of range");
+    if (light_mode == ATMO_LIGHT_DIRECT && light_steps < 1)
+        return fail(nullptr, ATMO_E_ARG, "atmo_create: direct light mode needs light_steps >= 1");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, ATMO_E_NO_DEVICE, std::string("atmo_create: no HIP device (") + hipGetErrorString(e) + ")");
+    if (device < 0 || device >= n) return fail(nullptr, ATMO_E_NO_DEVICE, "atmo_create: device index out of range");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceProperties");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, ATMO_E_NO_DEVICE, std::string("atmo_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
+
+    AtmoContext *ctx = new (std::nothrow) AtmoContext();
+    if (!ctx) return fail(nullptr, ATMO_E_ARG, "atmo_create: out of host memory");
+    ctx->device = device;
+    ctx->variant = variant;
+    ctx->view_steps = view_steps > 0 ? view_steps : 8;  // shaders/planet_atmosphere_*.gdshader:4-6
+    static const int shipped_cloud_steps[4] = {0, 32, 64, 64};
+    ctx->cloud_steps = (variant == ATMO_VARIANT_NO_CLOUDS) ? 0 : (cloud_steps > 0 ? cloud_steps : shipped_cloud_steps[variant]);
+    ctx->light_steps = (light_mode == ATMO_LIGHT_DIRECT) ? light_steps : 0;
+    ctx->flags = 0;
+    if (variant != ATMO_VARIANT_NO_CLOUDS) ctx->flags |= atmo::KF_CLOUDS;
+    if (variant == ATMO_VARIANT_CLOUDS_HIGH_RM) ctx->flags |= atmo::KF_CLOUD_LIGHT_RM;
+    if (light_mode == ATMO_LIGHT_DIRECT) ctx->flags |= atmo::KF_LIGHT_DIRECT;
+
+    // u_blue_noise_texture starts all-zero (jitter 0), like an unset sampler
+    int rc = dev_alloc(ctx, ctx->blue, 256 * 256);
+    if (rc == ATMO_OK) {
+        e = hipMemset(ctx->blue.ptr, 0, 256 * 256);
+        if (e != hipSuccess) rc = hip_fail(ctx, e, "hipMemset");
+    }
+    if (rc != ATMO_OK) {
+        g_create_error = ctx->err;
+        dev_free(ctx->blue);
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return ATMO_OK;
+}
+
+int atmo_destroy(AtmoContext *ctx) {
+    if (!ctx) return ATMO_OK;
+    (void)hipSetDevice(ctx->device);
+    drain_timing(ctx);
+    dev_free(ctx->lut);
+    dev_free(ctx->blue);
+    dev_free(ctx->shape);
+    dev_free(ctx->cube);
+    delete ctx;
+    return ATMO_OK;
+}
+
+int atmo_set_param_f32(AtmoContext *ctx, const char *name, const float *v, int n) {
+    if (!ctx) return ATMO_E_ARG;
+    if (!v) return fail(ctx, ATMO_E_ARG, "atmo_set_param_f32: value is null");
+    const ParamDesc *d = find_param(name);
+    if (!d) return fail(ctx, ATMO_E_NAME, std::string("atmo_set_param_f32: unknown uniform '") + (name ? name : "(null)") + "'");
+    if (n != d->count)
+        return fail(ctx, ATMO_E_ARG, std::string("atmo_set_param_f32: '") + name + "' takes " + std::to_string(d->count) + " floats");
+    std::memcpy(reinterpret_cast<char *>(&ctx->p) + d->offset, v, sizeof(float) * n);
+    return ATMO_OK;
+}
+
+int atmo_get_param_f32(AtmoContext *ctx, const char *name, float *v, int n) {
+    if (!ctx) return ATMO_E_ARG;
+    if (!v) return fail(ctx, ATMO_E_ARG, "atmo_get_param_f32: value is null");
+    const ParamDesc *d = find_param(name);
+    if (!d) return fail(ctx, ATMO_E_NAME, std::string("atmo_get_param_f32: unknown uniform '") + (name ? name : "(null)") + "'");
+    if (n != d->count)
+        return fail(ctx, ATMO_E_ARG, std::string("atmo_get_param_f32: '") + name + "' holds " + std::to_string(d->count) + " floats");
+    std::memcpy(v, reinterpret_cast<const char *>(&ctx->p) + d->offset, sizeof(float) * n);
+    return ATMO_OK;
+}
+
+int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h, int d, const void *data, int memory) {
+    if (!ctx) return ATMO_E_ARG;
+    if (!name) return fail(ctx, ATMO_E_NAME, "atmo_set_texture: name is null");
+    if (memory != ATMO_MEM_HOST && memory != ATMO_MEM_DEVICE) return fail(ctx, ATMO_E_ARG, "atmo_set_texture: bad memory kind");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const hipMemcpyKind ck = memory == ATMO_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    // Texture updates are rare (bake, scene load): serialise with any in-flight render that reads the old copy.
+    HIP_TRY(ctx, hipDeviceSynchronize());
+
+    if (std::strcmp(name, "u_optical_depth_texture") == 0) {
+        if (!data) { dev_free(ctx->lut); ctx->lut_w = ctx->lut_h = 0; return ATMO_OK; }
+        if (kind != ATMO_TEX_2D_R32F) return fail(ctx, ATMO_E_ARG, "u_optical_depth_texture must be ATMO_TEX_2D_R32F");
+        if (w < 1 || h < 1 || w > 8192 || h > 8192) return fail(ctx, ATMO_E_ARG, "u_optical_depth_texture: bad size");
+        int rc = dev_alloc(ctx, ctx->lut, (size_t)w * h * sizeof(float));
+        if (rc != ATMO_OK) return rc;
+        HIP_TRY(ctx, hipMemcpy(ctx->lut.ptr, data, ctx->lut.bytes, ck));
+        ctx->lut_w = w; ctx->lut_h = h;
+        return ATMO_OK;
+    }
+    if (std::strcmp(name, "u_blue_noise_texture") == 0) {
+        if (!data) { HIP_TRY(ctx, hipMemset(ctx->blue.ptr, 0, 256 * 256)); return ATMO_OK; }
+        if (kind != ATMO_TEX_2D_R8) return fail(ctx, ATMO_E_ARG, "u_blue_noise_texture must be ATMO_TEX_2D_R8");
+        if (w != 256 || h != 256) return fail(ctx, ATMO_E_ARG, "u_blue_noise_texture must be 256x256 (indexed & 0xff, main:169)");
+        HIP_TRY(ctx, hipMemcpy(ctx->blue.ptr, data, 256 * 256, ck));
+        return ATMO_OK;
+    }
+    if (std::strcmp(name, "u_cloud_shape_texture") == 0) {
+        if (!data) { dev_free(ctx->shape); ctx->shape_n = 0; return ATMO_OK; }
+        if (kind != ATMO_TEX_3D_R8) return fail(ctx, ATMO_E_ARG, "u_cloud_shape_texture must be ATMO_TEX_3D_R8");
+        if (w < 1 || w > 512 || h != w || d != w) return fail(ctx, ATMO_E_ARG, "u_cloud_shape_texture must be n x n x n, n <= 512");
+        int rc = dev_alloc(ctx, ctx->shape, (size_t)w * w * w);
+        if (rc != ATMO_OK) return rc;
+        HIP_TRY(ctx, hipMemcpy(ctx->shape.ptr, data, ctx->shape.bytes, ck));
+        ctx->shape_n = w;
+        return ATMO_OK;
+    }
+    if (std::strcmp(name, "u_cloud_coverage_cubemap") == 0) {
+        if (!data) { dev_free(ctx->cube); ctx->cube_n = 0; return ATMO_OK; }
+        if (kind != ATMO_TEX_CUBE_R8) return fail(ctx, ATMO_E_ARG, "u_cloud_coverage_cubemap must be ATMO_TEX_CUBE_R8");
+        if (w < 1 || w > 4096 || h != w || d != 6) return fail(ctx, ATMO_E_ARG, "u_cloud_coverage_cubemap must be n x n x 6 faces");
+        const size_t face_bytes = (size_t)w * w;
+        std::vector<uint8_t> host(6 * face_bytes);
+        if (memory == ATMO_MEM_HOST) std::memcpy(host.data(), data, host.size());
+        else HIP_TRY(ctx, hipMemcpy(host.data(), data, host.size(), hipMemcpyDeviceToHost));
+        std::vector<uint8_t> padded;
+        build_cube_apron(host.data(), w, padded);
+        int rc = dev_alloc(ctx, ctx->cube, padded.size());
+        if (rc != ATMO_OK) return rc;
+        HIP_TRY(ctx, hipMemcpy(ctx->cube.ptr, padded.data(), padded.size(), hipMemcpyHostToDevice));
+        ctx->cube_n = w;
+        return ATMO_OK;
+    }
+    return fail(ctx, ATMO_E_NAME, std::string("atmo_set_texture: unknown texture uniform '") + name + "'");
+}
+
+int atmo_bake_optical_depth(AtmoContext *ctx, void *stream) {
+    if (!ctx) return ATMO_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int w = 256, h = 256;  // optical_depth_baker.gd:24
+    if (ctx->lut_w != w || ctx->lut_h != h) {
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        int rc = dev_alloc(ctx, ctx->lut, (size_t)w * h * sizeof(float));
+        if (rc != ATMO_OK) return rc;
+        ctx->lut_w = w; ctx->lut_h = h;
+    }
+    atmo::BakeConsts bc;
+    bc.planet_radius = ctx->p.u_planet_radius;
+    bc.atmosphere_height = ctx->p.u_atmosphere_height;
+    bc.density = ctx->p.u_density;
+    bc.w = w; bc.h = h;
+    bc.steps = 64;  // optical_depth.gdshader:18
+    bc.out = (float *)ctx->lut.ptr;
+    HIP_TRY(ctx, atmo::launch_bake(bc, (hipStream_t)stream));
+    return ATMO_OK;
+}
+
+int atmo_read_optical_depth(AtmoContext *ctx, float *lut_host, uint8_t *rgba8_host, int capacity_texels, void *stream) {
+    if (!ctx) return ATMO_E_ARG;
+    if (!ctx->lut.ptr) return fail(ctx, ATMO_E_STATE, "atmo_read_optical_depth: no LUT bound");
+    const int n = ctx->lut_w * ctx->lut_h;
+    if (capacity_texels < n) return fail(ctx, ATMO_E_ARG, "atmo_read_optical_depth: buffer too small");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    std::vector<float> tmp;
+    float *dst = lut_host;
+    if (!dst) { tmp.resize(n); dst = tmp.data(); }
+    HIP_TRY(ctx, hipMemcpy(dst, ctx->lut.ptr, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    if (rgba8_host) {
+        // encode_float_to_viewport (optical_depth.gdshader:33-43): byte k of the bit pattern, little-endian;
+        // value/255 stored to UNORM8 gives the byte back, so the packing is the raw IEEE bytes.
+        for (int i = 0; i < n; ++i) {
+            uint32_t u;
+            std::memcpy(&u, &dst[i], 4);
+            for (int k = 0; k < 4; ++k) rgba8_host[4 * i + k] = (uint8_t)((u >> (8 * k)) & 255u);
+        }
+    }
+    return ATMO_OK;
+}
+
+int atmo_render(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, void *stream) {
+    if (!ctx) return ATMO_E_ARG;
+    if (!frame || !depth_dev || !rgba_dev) return fail(ctx, ATMO_E_ARG, "atmo_render: null argument");
+    if (frame->viewport_w < 1 || frame->viewport_h < 1 || frame->viewport_w > 65536 || frame->viewport_h > 65536)
+        return fail(ctx, ATMO_E_ARG, "atmo_render: bad viewport size");
+    if (frame->x0 < 0 || frame->y0 < 0 || frame->x1 > frame->viewport_w || frame->y1 > frame->viewport_h ||
+        frame->x0 > frame->x1 || frame->y0 > frame->y1)
+        return fail(ctx, ATMO_E_ARG, "atmo_render: rect outside the viewport");
+    if ((reinterpret_cast<uintptr_t>(rgba_dev) & 15u) != 0) return fail(ctx, ATMO_E_ARG, "atmo_render: rgba_dev must be 16-byte aligned");
+    if (!(ctx->flags & atmo::KF_LIGHT_DIRECT) && !ctx->lut.ptr)
+        return fail(ctx, ATMO_E_STATE, "atmo_render: u_optical_depth_texture not set (call atmo_bake_optical_depth or atmo_set_texture)");
+    if ((ctx->flags & atmo::KF_CLOUDS) && !ctx->shape.ptr)
+        return fail(ctx, ATMO_E_STATE, "atmo_render: u_cloud_shape_texture not set");
+    if (frame->x0 == frame->x1 || frame->y0 == frame->y1) return ATMO_OK;  // empty rect: nothing to shade
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    atmo::RenderConsts rc;
+    fill_consts(ctx, frame, depth_dev, rgba_dev, rc);
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->timing) {
+        HIP_TRY(ctx, hipEventCreate(&e0));
+        HIP_TRY(ctx, hipEventCreate(&e1));
+        HIP_TRY(ctx, hipEventRecord(e0, s));
+    }
+    HIP_TRY(ctx, atmo::launch_render(ctx->flags, rc, s));
+    if (ctx->timing) {
+        HIP_TRY(ctx, hipEventRecord(e1, s));
+        ctx->pending.emplace_back(e0, e1);
+    }
+    return ATMO_OK;
+}
+
+int atmo_set_timing(AtmoContext *ctx, int enable) {
+    if (!ctx) return ATMO_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    drain_timing(ctx);
+    ctx->timing = enable != 0;
+    ctx->timed_launches = 0;
+    ctx->timed_ms = 0.0;
+    return ATMO_OK;
+}
+
+int atmo_get_timing(AtmoContext *ctx, int *launches, double *total_ms) {
+    if (!ctx) return ATMO_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    drain_timing(ctx);
+    if (launches) *launches = ctx->timed_launches;
+    if (total_ms) *total_ms = ctx->timed_ms;
+    return ATMO_OK;
+}
+
+const char *atmo_kernel_name(AtmoContext *ctx) {
+    if (!ctx) return "";
+    return atmo::render_kernel_name(ctx->flags);
+}
+
+const char *atmo_last_error_string(AtmoContext *ctx) {
+    if (!ctx) return g_create_error.c_str();
+    return ctx->err.c_str();
+}
+
+}  // extern "C"

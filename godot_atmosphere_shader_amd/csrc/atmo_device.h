@@ -1,0 +1,72 @@
+// atmo_device.h -- structures shared by the host API (atmo_api.hip) and the gfx950 kernels
+// (atmo_kernels.hip).  Not part of the public C ABI (that is include/atmo.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace atmo {
+
+// Everything a render launch needs that is constant over the draw.  Passed BY VALUE as the kernel
+// argument, so every field lands in SGPRs through scalar loads of the kernarg segment.
+// Values marked [host] are per-frame expressions of the reference shader that do not depend on the
+// pixel; the API evaluates them once in fp32, in the reference's operation order.
+struct RenderConsts {
+    // --- atmosphere_fragment prologue (shaders/include/planet_atmosphere_main.gdshaderinc:128-169)
+    float inv_p[16];
+    float inv_v[16];
+    float cam_pos_world[3];  // [host] inv_v * (0,0,0,1)                      main:136
+    float vw, vh;            // VIEWPORT_SIZE as floats
+    int32_t w, h;            // VIEWPORT_SIZE
+    int32_t x0, y0, x1, y1;  // rect shaded by this launch
+    float center[3];         // v_planet_center_viewspace
+    float sun_dir[3];        // [host] normalize(sun_center_vs - planet_center_vs)   main:164
+    float planet_radius, atmosphere_height;
+    float atmosphere_radius; // [host] R + H                                   main:144
+    float density;           // u_density
+    float sphere_depth_factor;
+    // --- compute_atmosphere_v2 (shaders/include/atmosphere_funcs_v2.gdshaderinc:32-101)
+    float coeff[3];          // [host] pow4(400/lambda) * strength             v2:47-51
+    float ambient[3], modulate[3];
+    int32_t view_steps;
+    int32_t light_steps;     // direct light mode only
+    // --- render_clouds / raymarch_cloud (shaders/include/cloud_funcs.gdshaderinc:175-324)
+    float clouds_bottom, clouds_top;  // [host] R + u_cloud_{bottom,top} * H   clouds:260-261
+    float cloud_thickness;            // [host] top - bottom
+    float cloud_density_scale, cloud_blend, coverage_bias, shape_factor, shape_scale;
+    int32_t shape_invert;             // u_cloud_shape_invert == 1.0           clouds:57
+    float cov_rot[4];                 // mat2 column-major
+    float view_to_model[16];          // [host] u_world_to_model_matrix * inv_view   clouds:285
+    float origin_model[3];            // [host] (view_to_model * (0,0,0,1)).xyz      clouds:286
+    float sun_dir_model[3];           // [host] (view_to_model * (sun_dir,0)).xyz    clouds:288
+    float max_d;                      // [host] march-distance cap             clouds:186-202
+    float inv_cloud_steps;            // [host] 1/float(steps)                 clouds:206
+    int32_t cloud_steps;
+    float rm_step0;                   // [host] reach * (1/6)                  clouds:108,114-115
+    // --- textures (device memory owned by the context)
+    const float *lut;        // u_optical_depth_texture, lut_h rows of lut_w
+    int32_t lut_w, lut_h;
+    const uint8_t *blue;     // u_blue_noise_texture 256x256
+    const uint8_t *shape;    // u_cloud_shape_texture n^3
+    int32_t shape_n;
+    const uint8_t *cube;     // u_cloud_coverage_cubemap, 6 faces of (n+2)^2 with seamless apron; null => 1.0
+    int32_t cube_n;
+    // --- per-pixel streams
+    const float *depth;      // h rows of w
+    float4 *out;             // (y1-y0) rows of (x1-x0)
+};
+
+struct BakeConsts {
+    float planet_radius, atmosphere_height, density;
+    int32_t w, h, steps;
+    float *out;
+};
+
+// kernel launchers (atmo_kernels.hip)
+enum KernelFlags : int { KF_CLOUDS = 1, KF_CLOUD_LIGHT_RM = 2, KF_LIGHT_DIRECT = 4 };
+
+hipError_t launch_render(int flags, const RenderConsts &rc, hipStream_t stream);
+hipError_t launch_bake(const BakeConsts &bc, hipStream_t stream);
+const char *render_kernel_name(int flags);
+
+}  // namespace atmo

@@ -1,0 +1,153 @@
+/*
+ * atmo.h -- C ABI of libatmo_hip.so: the MI355X (gfx950) implementation of the per-pixel
+ * atmosphere / volumetric-cloud raymarch of Zylann/godot_atmosphere_shader.
+ *
+ * The reference has no FFI: the path sits behind Godot's shader-uniform interface.  Each entry
+ * point below names the reference interface it replaces (paths relative to
+ * /root/reference/addons/zylann.atmosphere/).  A GDExtension (or any other host) binds exactly
+ * these symbols; see INTEGRATION.md for the binding a maintainer would add.
+ *
+ * Conventions: opaque handle, int error codes (0 = ATMO_OK), no exceptions or aborts across the
+ * boundary, caller owns every buffer it passes, one context per GPU, a context is not thread-safe
+ * but distinct contexts are independent.  All matrices are 16 floats, column-major (GLSL/Godot
+ * memory order); mat2 is 4 floats column-major.  Colours are linear (the host applies Godot's
+ * `source_color` sRGB->linear conversion).  Device pointers are plain HIP device addresses.
+ */
+#ifndef ATMO_H
+#define ATMO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ATMO_ABI_VERSION 1
+
+typedef struct AtmoContext AtmoContext;
+
+enum AtmoError {
+    ATMO_OK = 0,
+    ATMO_E_NAME = 1,     /* unknown uniform / texture name (Godot ignores these silently; the ABI reports them) */
+    ATMO_E_ARG = 2,      /* bad count, size, null pointer, unsupported step count */
+    ATMO_E_STATE = 3,    /* render without a LUT / required texture */
+    ATMO_E_HIP = 4,      /* HIP runtime error; see atmo_last_error_string */
+    ATMO_E_NO_DEVICE = 5 /* no gfx950 device / device index out of range */
+};
+
+/* Shader variants: shaders/planet_atmosphere_{no_clouds,clouds,clouds_high,clouds_high_rm}.gdshader:4-7 */
+enum AtmoVariant {
+    ATMO_VARIANT_NO_CLOUDS = 0,      /* ATMOSPHERE_RAYMARCH_STEPS 8 */
+    ATMO_VARIANT_CLOUDS = 1,         /* + CLOUDS_ENABLED, CLOUDS_MAX_RAYMARCH_STEPS 32 */
+    ATMO_VARIANT_CLOUDS_HIGH = 2,    /* + CLOUDS_MAX_RAYMARCH_STEPS 64 */
+    ATMO_VARIANT_CLOUDS_HIGH_RM = 3  /* + CLOUDS_RAYMARCHED_LIGHTING (README's "clouds_high_m") */
+};
+
+/* How the sun-ray optical depth of compute_atmosphere_v2 is obtained. */
+enum AtmoLightMode {
+    ATMO_LIGHT_LUT = 0,    /* reference: get_baked_optical_depth, shaders/include/atmosphere_funcs_v2.gdshaderinc:14-29 */
+    ATMO_LIGHT_DIRECT = 1  /* inline light march of `light_steps` samples (BASELINE "N view x M light steps");
+                              the integrand of shaders/optical_depth.gdshader:17-31 from the sample position */
+};
+
+/* Texture formats accepted by atmo_set_texture. */
+enum AtmoTextureKind {
+    ATMO_TEX_2D_R32F = 0,  /* u_optical_depth_texture (what optical_depth_baker.gd:75-80 uploads) */
+    ATMO_TEX_2D_R8 = 1,    /* u_blue_noise_texture, 256x256 */
+    ATMO_TEX_3D_R8 = 2,    /* u_cloud_shape_texture, n^3, x fastest */
+    ATMO_TEX_CUBE_R8 = 3   /* u_cloud_coverage_cubemap, 6 faces +X,-X,+Y,-Y,+Z,-Z of n^2, level 0 */
+};
+
+enum AtmoMemory { ATMO_MEM_HOST = 0, ATMO_MEM_DEVICE = 1 };
+
+/*
+ * Per-frame arguments: the parameters of atmosphere_fragment
+ * (shaders/include/planet_atmosphere_main.gdshaderinc:106-117) that are constant over a draw, plus
+ * the rect of the viewport this call shades (row-band / tile sharding; the whole viewport when
+ * x0=y0=0, x1=viewport_w, y1=viewport_h).
+ */
+typedef struct AtmoFrame {
+    float inv_projection_matrix[16]; /* INV_PROJECTION_MATRIX: (SCREEN_UV*2-1, depth, 1) -> view space */
+    float inv_view_matrix[16];       /* INV_VIEW_MATRIX */
+    int32_t viewport_w, viewport_h;  /* VIEWPORT_SIZE */
+    float planet_center_viewspace[3];/* varying v_planet_center_viewspace (atmosphere_vertex, main:101-102) */
+    float sun_center_viewspace[3];   /* varying v_sun_center_viewspace (main:103) */
+    float time;                      /* TIME (cloud_funcs.gdshaderinc:298; dead in the shipped shaders) */
+    int32_t x0, y0, x1, y1;          /* rect to shade, in pixels */
+} AtmoFrame;
+
+/* ABI version of the loaded library (== ATMO_ABI_VERSION of the header it was built from). */
+int atmo_abi_version(void);
+
+/* Number of usable gfx950 devices, or a negative AtmoError. Does not create a context. */
+int atmo_device_count(void);
+
+/*
+ * Replaces: assigning a shader variant to the node (`custom_shader`, planet_atmosphere.gd:118-141) and
+ * its compile-time #defines (shaders/planet_atmosphere_*.gdshader:4-7).
+ * view_steps = ATMOSPHERE_RAYMARCH_STEPS (0 => the variant's shipped value, 8); cloud_steps =
+ * CLOUDS_MAX_RAYMARCH_STEPS (0 => shipped 32/64); light_mode/light_steps: see AtmoLightMode
+ * (light_steps ignored for ATMO_LIGHT_LUT).  Uniforms start at the shader defaults
+ * (SURVEY.md 8b); u_blue_noise_texture starts all-zero, u_cloud_coverage_cubemap unset (= 1.0).
+ */
+int atmo_create(int device, int variant, int view_steps, int cloud_steps, int light_mode, int light_steps,
+                AtmoContext **out);
+
+int atmo_destroy(AtmoContext *ctx);
+
+/*
+ * Replaces: ShaderMaterial.set_shader_parameter(name, value) for float / vecN / matN uniforms
+ * (planet_atmosphere.gd:106-108,114-115,175-176,216,235,250,331,336,340).  n = number of floats
+ * (1, 2, 3, 4 or 16) and must match the uniform's type.  Names are the reference's uniform names.
+ */
+int atmo_set_param_f32(AtmoContext *ctx, const char *name, const float *v, int n);
+int atmo_get_param_f32(AtmoContext *ctx, const char *name, float *v, int n);
+
+/*
+ * Replaces: ShaderMaterial.set_shader_parameter(name, Texture) for u_optical_depth_texture
+ * (planet_atmosphere.gd:156), u_blue_noise_texture (:107), u_cloud_shape_texture and
+ * u_cloud_coverage_cubemap (user-set).  The data is copied; `memory` says where `data` lives.
+ * data == NULL unsets the texture (cubemap => constant 1.0).  2-D: w x h; 3-D: w=h=d=n; cube: w=h=n, d=6.
+ */
+int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h, int d,
+                     const void *data, int memory);
+
+/*
+ * Replaces: OpticalDepthBaker (optical_depth_baker.gd:37-85) + shaders/optical_depth.gdshader:45-68:
+ * bakes the 256x256, 64-sample optical-depth LUT on the device from the current u_planet_radius,
+ * u_atmosphere_height, u_density and binds it as u_optical_depth_texture (no viewport, no readback).
+ */
+int atmo_bake_optical_depth(AtmoContext *ctx, void *stream);
+
+/* Copy the currently bound LUT (w*h floats) to host memory; also writes the RGBA8 packing of
+ * shaders/optical_depth.gdshader:33-43 when rgba8 != NULL (w*h*4 bytes). For hosts that want to hand the
+ * LUT back to a Godot ImageTexture. Synchronises the stream. */
+int atmo_read_optical_depth(AtmoContext *ctx, float *lut_host, uint8_t *rgba8_host, int capacity_texels, void *stream);
+
+/*
+ * Replaces: one draw of the atmosphere mesh, i.e. fragment() of shaders/planet_atmosphere_*.gdshader:20-27
+ * calling atmosphere_fragment for every pixel of the rect.
+ *   depth_dev: device pointer, viewport_h rows of viewport_w floats (u_depth_texture, reversed-Z).
+ *   rgba_dev:  device pointer, (y1-y0) rows of (x1-x0) RGBA float4: ALBEDO.rgb, ALPHA; discarded
+ *              fragments are written as (0,0,0,0).  Must be 16-byte aligned.
+ *   stream:    hipStream_t (NULL = default stream).  The call only enqueues work.
+ */
+int atmo_render(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, void *stream);
+
+/* Average device time of the last `atmo_render` kernels measured with HIP events on their own stream:
+ * enable with atmo_set_timing(ctx, 1); atmo_get_timing returns count and total milliseconds since enabling. */
+int atmo_set_timing(AtmoContext *ctx, int enable);
+int atmo_get_timing(AtmoContext *ctx, int *launches, double *total_ms);
+
+/* Name of the kernel the current configuration launches (for matching rocprofv3 kernel traces). */
+const char *atmo_kernel_name(AtmoContext *ctx);
+
+/* Last error message of this context (or of the failed atmo_create when ctx == NULL). Never NULL. */
+const char *atmo_last_error_string(AtmoContext *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* ATMO_H */

@@ -1,0 +1,303 @@
+"""ctypes loader for the CPU oracle (oracle/atmo_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg -- never by anything under godot_atmosphere_shader_amd/.  PARITY UNPINNED (see atmo_oracle.h).
+
+The wrapper is deliberately free of any import from the product package: scenes are handed over as
+plain dicts / numpy arrays (see `render`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class OracleParams(C.Structure):
+    _fields_ = [
+        ("u_planet_radius", C.c_float),
+        ("u_atmosphere_height", C.c_float),
+        ("u_density", C.c_float),
+        ("u_scattering_strength", C.c_float),
+        ("u_scattering_wavelengths", C.c_float * 3),
+        ("u_atmosphere_modulate", C.c_float * 3),
+        ("u_atmosphere_ambient_color", C.c_float * 3),
+        ("u_sphere_depth_factor", C.c_float),
+        ("u_cloud_density_scale", C.c_float),
+        ("u_cloud_bottom", C.c_float),
+        ("u_cloud_top", C.c_float),
+        ("u_cloud_blend", C.c_float),
+        ("u_world_to_model_matrix", C.c_float * 16),
+        ("u_cloud_shape_invert", C.c_float),
+        ("u_cloud_coverage_bias", C.c_float),
+        ("u_cloud_shape_factor", C.c_float),
+        ("u_cloud_shape_scale", C.c_float),
+        ("u_cloud_coverage_rotation", C.c_float * 4),
+    ]
+
+
+class OracleTextures(C.Structure):
+    _fields_ = [
+        ("optical_depth", C.c_void_p),
+        ("lut_w", C.c_int32),
+        ("lut_h", C.c_int32),
+        ("blue_noise", C.c_void_p),
+        ("shape", C.c_void_p),
+        ("shape_n", C.c_int32),
+        ("cubemap", C.c_void_p),
+        ("cube_n", C.c_int32),
+    ]
+
+
+class OracleFrame(C.Structure):
+    _fields_ = [
+        ("inv_projection_matrix", C.c_float * 16),
+        ("inv_view_matrix", C.c_float * 16),
+        ("viewport_w", C.c_int32),
+        ("viewport_h", C.c_int32),
+        ("planet_center_viewspace", C.c_float * 3),
+        ("sun_center_viewspace", C.c_float * 3),
+        ("time", C.c_float),
+    ]
+
+
+class OracleConfig(C.Structure):
+    _fields_ = [
+        ("view_steps", C.c_int32),
+        ("cloud_steps", C.c_int32),
+        ("cloud_light_rm", C.c_int32),
+        ("light_steps", C.c_int32),
+    ]
+
+
+# Shader defaults (declared at the cited reference lines).
+PARAM_DEFAULTS = {
+    "u_planet_radius": 1.0,
+    "u_atmosphere_height": 0.1,
+    "u_density": 0.2,
+    "u_scattering_strength": 20.0,
+    "u_scattering_wavelengths": (700.0, 530.0, 440.0),
+    "u_atmosphere_modulate": (1.0, 1.0, 1.0),
+    "u_atmosphere_ambient_color": (0.0, 0.0, 0.002),
+    "u_sphere_depth_factor": 0.0,
+    "u_cloud_density_scale": 50.0,
+    "u_cloud_bottom": 0.2,
+    "u_cloud_top": 0.5,
+    "u_cloud_blend": 0.5,
+    "u_world_to_model_matrix": (1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1),
+    "u_cloud_shape_invert": 0.0,
+    "u_cloud_coverage_bias": 0.0,
+    "u_cloud_shape_factor": 0.8,
+    "u_cloud_shape_scale": 1.0,
+    "u_cloud_coverage_rotation": (1, 0, 0, 1),
+}
+
+
+def build(force: bool = False) -> None:
+    """Compile the oracle shared objects with the committed Makefile."""
+    need = force or not all(
+        os.path.exists(os.path.join(_HERE, n)) for n in ("liboracle_f32.so", "liboracle_f64.so", "liboracle_f32_fast.so")
+    )
+    if need:
+        subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
+
+
+def _host_has_avx2_fma() -> bool:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    fl = line.split()
+                    return "avx2" in fl and "fma" in fl
+    except OSError:
+        pass
+    return False
+
+
+class Oracle:
+    """One precision build of the oracle. precision: 'f32' (parity), 'f64' (twin), 'f32_fast' (timing only)."""
+
+    def __init__(self, precision: str = "f32"):
+        build()
+        if precision == "f32_fast" and not _host_has_avx2_fma():
+            precision = "f32"
+        self.precision = precision
+        self.sfx = "_f64" if precision == "f64" else "_f32"
+        self.real = C.c_double if precision == "f64" else C.c_float
+        self.np_real = np.float64 if precision == "f64" else np.float32
+        self.lib = C.CDLL(os.path.join(_HERE, f"liboracle_{precision}.so"))
+        R = self.real
+        RP = C.POINTER(R)
+        f = self._fn
+        f("oracle_render", C.c_long, [C.POINTER(OracleParams), C.POINTER(OracleTextures), C.POINTER(OracleConfig),
+                                      C.POINTER(OracleFrame), C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int])
+        f("oracle_bake_optical_depth", None, [C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p])
+        f("oracle_ray_sphere", None, [RP, R, RP, RP, RP])
+        f("oracle_get_atmosphere_density", R, [C.c_float, C.c_float, C.c_float, R])
+        f("oracle_blend_colors", None, [RP, RP, RP])
+        f("oracle_sample_lut", R, [C.POINTER(OracleTextures), R, R])
+        f("oracle_sample_shape", R, [C.POINTER(OracleTextures), RP])
+        f("oracle_sample_cube", R, [C.POINTER(OracleTextures), RP])
+        f("oracle_cube_texel", C.c_int, [C.POINTER(OracleTextures), C.c_int, C.c_int, C.c_int])
+        f("oracle_get_cloud_density", R, [C.POINTER(OracleParams), C.POINTER(OracleTextures), RP])
+        if precision != "f64":
+            self.lib.oracle_encode_float_to_viewport.argtypes = [C.c_float, C.POINTER(C.c_uint8)]
+            self.lib.oracle_encode_float_to_viewport.restype = None
+            self.lib.oracle_decode_viewport_to_float.argtypes = [C.POINTER(C.c_uint8)]
+            self.lib.oracle_decode_viewport_to_float.restype = C.c_float
+
+    def _fn(self, name, restype, argtypes):
+        fn = getattr(self.lib, name + self.sfx)
+        fn.restype = restype
+        fn.argtypes = argtypes
+        setattr(self, "_" + name, fn)
+
+    # ---- marshalling ---------------------------------------------------------------------
+    @staticmethod
+    def make_params(params: dict) -> OracleParams:
+        p = OracleParams()
+        merged = dict(PARAM_DEFAULTS)
+        for k, v in params.items():
+            if k in merged:
+                merged[k] = v
+        for k, v in merged.items():
+            if isinstance(v, (int, float)):
+                setattr(p, k, float(v))
+            else:
+                arr = np.asarray(v, dtype=np.float32).reshape(-1)
+                field = getattr(p, k)
+                for i in range(len(field)):
+                    field[i] = float(arr[i])
+        return p
+
+    @staticmethod
+    def make_textures(textures: dict):
+        """textures: optical_depth (h,w f32), blue_noise (256,256 u8), shape (n,n,n u8, [z,y,x]),
+        cubemap (6,n,n u8) or None.  Returns (struct, keepalive list)."""
+        t = OracleTextures()
+        keep = []
+
+        def ptr(a):
+            keep.append(a)
+            return a.ctypes.data_as(C.c_void_p)
+
+        lut = textures.get("optical_depth")
+        if lut is not None:
+            lut = np.ascontiguousarray(lut, dtype=np.float32)
+            t.optical_depth = ptr(lut)
+            t.lut_h, t.lut_w = lut.shape
+        bn = textures.get("blue_noise")
+        if bn is not None:
+            bn = np.ascontiguousarray(bn, dtype=np.uint8)
+            assert bn.shape == (256, 256)
+            t.blue_noise = ptr(bn)
+        sh = textures.get("shape")
+        if sh is not None:
+            sh = np.ascontiguousarray(sh, dtype=np.uint8)
+            assert sh.ndim == 3 and sh.shape[0] == sh.shape[1] == sh.shape[2]
+            t.shape = ptr(sh)
+            t.shape_n = sh.shape[0]
+        cm = textures.get("cubemap")
+        if cm is not None:
+            cm = np.ascontiguousarray(cm, dtype=np.uint8)
+            assert cm.ndim == 3 and cm.shape[0] == 6 and cm.shape[1] == cm.shape[2]
+            t.cubemap = ptr(cm)
+            t.cube_n = cm.shape[1]
+        return t, keep
+
+    @staticmethod
+    def make_frame(frame: dict) -> OracleFrame:
+        f = OracleFrame()
+        for i, v in enumerate(np.asarray(frame["inv_projection_matrix"], dtype=np.float32).reshape(-1)):
+            f.inv_projection_matrix[i] = float(v)
+        for i, v in enumerate(np.asarray(frame["inv_view_matrix"], dtype=np.float32).reshape(-1)):
+            f.inv_view_matrix[i] = float(v)
+        f.viewport_w, f.viewport_h = int(frame["viewport_w"]), int(frame["viewport_h"])
+        for i in range(3):
+            f.planet_center_viewspace[i] = float(np.float32(frame["planet_center_viewspace"][i]))
+            f.sun_center_viewspace[i] = float(np.float32(frame["sun_center_viewspace"][i]))
+        f.time = float(frame.get("time", 0.0))
+        return f
+
+    @staticmethod
+    def make_config(config: dict) -> OracleConfig:
+        return OracleConfig(int(config["view_steps"]), int(config.get("cloud_steps", 0)),
+                            int(config.get("cloud_light_rm", 0)), int(config.get("light_steps", 0)))
+
+    # ---- entry points --------------------------------------------------------------------
+    def render(self, params: dict, textures: dict, config: dict, frame: dict, depth: np.ndarray,
+               rect=None, nthreads: int = 1):
+        """Returns (rgba[(y1-y0),(x1-x0),4] in this build's precision, hit_count).
+
+        Matrices in `frame` are flat 16-element column-major sequences (GLSL/Godot order)."""
+        p = self.make_params(params)
+        t, keep = self.make_textures(textures)
+        cfg = self.make_config(config)
+        f = self.make_frame(frame)
+        w, h = f.viewport_w, f.viewport_h
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        assert depth.shape == (h, w)
+        x0, y0, x1, y1 = rect if rect is not None else (0, 0, w, h)
+        out = np.empty((y1 - y0, x1 - x0, 4), dtype=self.np_real)
+        hits = self._oracle_render(C.byref(p), C.byref(t), C.byref(cfg), C.byref(f),
+                                   depth.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                   x0, y0, x1, y1, nthreads)
+        del keep
+        return out, int(hits)
+
+    def bake_optical_depth(self, planet_radius, atmosphere_height, density, w=256, h=256, steps=64):
+        out = np.empty((h, w), dtype=np.float32)
+        self._oracle_bake_optical_depth(planet_radius, atmosphere_height, density, w, h, steps,
+                                        out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def _vec(self, v):
+        return (self.real * len(v))(*[float(x) for x in v])
+
+    def ray_sphere(self, center, radius, origin, direction):
+        out = (self.real * 2)()
+        self._oracle_ray_sphere(self._vec(center), radius, self._vec(origin), self._vec(direction), out)
+        return float(out[0]), float(out[1])
+
+    def get_atmosphere_density(self, planet_radius, atmosphere_height, density, height):
+        return float(self._oracle_get_atmosphere_density(planet_radius, atmosphere_height, density, height))
+
+    def blend_colors(self, self4, over4):
+        out = (self.real * 4)()
+        self._oracle_blend_colors(self._vec(self4), self._vec(over4), out)
+        return [float(x) for x in out]
+
+    def sample_lut(self, lut, u, v):
+        t, keep = self.make_textures({"optical_depth": lut})
+        return float(self._oracle_sample_lut(C.byref(t), u, v))
+
+    def sample_shape(self, shape, p):
+        t, keep = self.make_textures({"shape": shape})
+        return float(self._oracle_sample_shape(C.byref(t), self._vec(p)))
+
+    def sample_cube(self, cubemap, d):
+        t, keep = self.make_textures({"cubemap": cubemap})
+        return float(self._oracle_sample_cube(C.byref(t), self._vec(d)))
+
+    def cube_texel(self, cubemap, face, i, j):
+        t, keep = self.make_textures({"cubemap": cubemap})
+        return int(self._oracle_cube_texel(C.byref(t), face, i, j))
+
+    def get_cloud_density(self, params, textures, pos_model):
+        p = self.make_params(params)
+        t, keep = self.make_textures(textures)
+        return float(self._oracle_get_cloud_density(C.byref(p), C.byref(t), self._vec(pos_model)))
+
+    def encode_float_to_viewport(self, h):
+        out = (C.c_uint8 * 4)()
+        self.lib.oracle_encode_float_to_viewport(h, out)
+        return bytes(out)
+
+    def decode_viewport_to_float(self, b):
+        arr = (C.c_uint8 * 4)(*b)
+        return float(self.lib.oracle_decode_viewport_to_float(arr))

@@ -1,0 +1,259 @@
+"""Parity of the gfx950 kernels (through the C ABI) against the fp32 CPU oracle.  Needs an MI355X.
+
+Tolerance: BASELINE.json north_star, <= 1e-4 max per-channel deviation on RGBA32F (TOL in common.py).
+The LUT bake is held to bit-exactness (it is evaluated with IEEE sqrt/divide, unfused).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from common import CONFIGS, TOL, demo_frame, demo_params, demo_textures, make_node
+from godot_atmosphere_shader_amd import scene as S
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _gpu_render(node, cam, depth_np, rect=None):
+    depth = torch.from_numpy(depth_np).cuda()
+    out = node.render(cam, depth, rect=rect)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _oracle_render(oracle, config_name, params, textures, cam, depth_np, lut, rect=None):
+    tex = dict(textures, optical_depth=lut)
+    img, hits = oracle.render(params, tex, CONFIGS[config_name][1], demo_frame(cam), depth_np, rect=rect, nthreads=8)
+    return img, hits
+
+
+@pytest.mark.parametrize("rhd", [(100.0, 8.0, 0.5), (1.0, 0.2, 10.0), (1.0, 0.1, 0.2)], ids=["demo", "prefab", "defaults"])
+def test_bake_bit_exact(oracle32, rhd):
+    """configs[0]: 256x256 LUT, 64 samples per ray -- device bake == oracle bake, bit for bit, plus the
+    RGBA8 packing of optical_depth.gdshader:33-43."""
+    r, h, d = rhd
+    tex = demo_textures(cube_n=16, shape_n=8)
+    node = make_node("no_clouds_8", tex, demo_params(u_planet_radius=r, u_atmosphere_height=h, u_density=d))
+    lut, rgba8 = node.read_optical_depth(with_rgba8=True)
+    ref = oracle32.bake_optical_depth(r, h, d)
+    assert lut.shape == (256, 256)
+    assert np.array_equal(lut.view(np.uint32), ref.view(np.uint32)), f"max diff {np.abs(lut - ref).max()}"
+    assert np.array_equal(rgba8.reshape(-1, 4), ref.reshape(-1).view(np.uint8).reshape(-1, 4))
+    for idx in (0, 255, 256 * 128 + 17, 65535):
+        assert bytes(rgba8.reshape(-1, 4)[idx]) == oracle32.encode_float_to_viewport(float(ref.reshape(-1)[idx]))
+    node.close()
+
+
+@pytest.mark.parametrize("pose", ["P_space", "P_ground", "P_limb", "P_clouds", "P_night"])
+@pytest.mark.parametrize("config_name", list(CONFIGS))
+def test_parity_demo_scene(oracle32, config_name, pose):
+    w, h = 256, 144
+    tex = demo_textures()
+    params = demo_params()
+    cam = S.Camera.from_pose(w, h, pose)
+    depth = S.depth_ground_sphere(cam)
+    node = make_node(config_name, tex, params)
+    got = _gpu_render(node, cam, depth)
+    lut = node.read_optical_depth()
+    want, hits = _oracle_render(oracle32, config_name, params, tex, cam, depth, lut)
+    node.close()
+    # discard decisions must agree exactly (they are taken in the bit-exact prologue)
+    assert np.array_equal(np.all(got == 0.0, axis=-1), np.all(want == 0.0, axis=-1))
+    err = np.abs(got - want).max()
+    assert err <= TOL, f"{config_name}/{pose}: max abs err {err:.3e}"
+    assert hits > 0
+
+
+@pytest.mark.parametrize("config_name", ["no_clouds_32_lut", "clouds_high"])
+def test_parity_far_depth_and_sphere_depth(oracle32, config_name):
+    """Empty depth buffer (reversed-Z 0) with u_sphere_depth_factor = 1 (SURVEY.md 8d depth variant i)."""
+    w, h = 200, 120  # not multiples of the 16x16 tile
+    tex = demo_textures()
+    params = demo_params(u_sphere_depth_factor=1.0)
+    cam = S.Camera.from_pose(w, h, "P_limb")
+    depth = S.depth_far(cam)
+    node = make_node(config_name, tex, params)
+    got = _gpu_render(node, cam, depth)
+    lut = node.read_optical_depth()
+    want, _ = _oracle_render(oracle32, config_name, params, tex, cam, depth, lut)
+    node.close()
+    assert np.abs(got - want).max() <= TOL
+
+
+def test_parity_unset_cubemap_and_no_invert(oracle32):
+    """Unset coverage cubemap => uniform coverage 1.0 (README.md:46); u_cloud_shape_invert = 0 branch."""
+    w, h = 160, 96
+    tex = demo_textures()
+    tex["cubemap"] = None
+    params = demo_params(u_cloud_shape_invert=0.0, u_cloud_coverage_bias=-0.35)
+    cam = S.Camera.from_pose(w, h, "P_space")
+    depth = S.depth_ground_sphere(cam)
+    node = make_node("clouds_high", tex, params)
+    got = _gpu_render(node, cam, depth)
+    lut = node.read_optical_depth()
+    want, _ = _oracle_render(oracle32, "clouds_high", params, tex, cam, depth, lut)
+    node.close()
+    assert np.abs(got - want).max() <= TOL
+
+
+def test_parity_rotated_planet_transform(oracle32):
+    """Non-identity u_world_to_model_matrix (planet node rotated and moved): view->model transform path."""
+    w, h = 160, 96
+    tex = demo_textures()
+    a = 0.7
+    rot = np.array([[np.cos(a), 0, np.sin(a), 0], [0, 1, 0, 0], [-np.sin(a), 0, np.cos(a), 0], [0, 0, 0, 1]])
+    model = rot.copy()
+    model[:3, 3] = (3.0, -2.0, 1.0)
+    w2m = np.linalg.inv(model)
+    params = demo_params(u_world_to_model_matrix=S.col_major(w2m))
+    cam = S.Camera.from_pose(w, h, "P_space")
+    depth = S.depth_ground_sphere(cam, center_world=(3.0, -2.0, 1.0))
+    from godot_atmosphere_shader_amd.planet_atmosphere import make_frame
+
+    node = make_node("clouds_high", tex, params)
+    node.global_transform = model
+    node._process(0.0, cam, time=0.0)
+    node.set_shader_parameter("u_cloud_coverage_rotation", np.asarray(params["u_cloud_coverage_rotation"], dtype=np.float32))
+    got = _gpu_render(node, cam, depth)
+    lut = node.read_optical_depth()
+    frame = make_frame(cam, model, S.DEMO_SUN_POSITION)
+    want, _ = oracle32.render(params, dict(tex, optical_depth=lut), CONFIGS["clouds_high"][1], frame, depth, nthreads=8)
+    node.close()
+    assert np.abs(got - want).max() <= TOL
+
+
+def test_rect_and_tiles_equal_full_frame():
+    """Tile sharding is exact: any rect of the viewport reproduces the same bits as the full-frame launch."""
+    w, h = 320, 180
+    tex = demo_textures()
+    cam = S.Camera.from_pose(w, h, "P_space")
+    depth = S.depth_ground_sphere(cam)
+    node = make_node("clouds_high", tex)
+    full = _gpu_render(node, cam, depth)
+    for rect in [(0, 0, w, h), (0, 45, w, 90), (17, 3, 203, 101), (319, 179, 320, 180), (0, 0, 1, 1)]:
+        part = _gpu_render(node, cam, depth, rect=rect)
+        x0, y0, x1, y1 = rect
+        assert part.shape == (y1 - y0, x1 - x0, 4)
+        assert np.array_equal(part, full[y0:y1, x0:x1])
+    # empty rect: nothing written, no error
+    d = torch.from_numpy(depth).cuda()
+    out = node.render(cam, d, rect=(5, 5, 5, 9))
+    assert out.shape == (4, 0, 4)
+    node.close()
+
+
+def test_tiny_viewports(oracle32):
+    tex = demo_textures()
+    params = demo_params()
+    for (w, h) in [(1, 1), (3, 2), (17, 1)]:
+        cam = S.Camera.from_pose(w, h, "P_ground")
+        depth = S.depth_ground_sphere(cam)
+        node = make_node("clouds", tex, params)
+        got = _gpu_render(node, cam, depth)
+        lut = node.read_optical_depth()
+        want, _ = _oracle_render(oracle32, "clouds", params, tex, cam, depth, lut)
+        node.close()
+        assert np.abs(got - want).max() <= TOL
+
+
+def test_full_size_properties():
+    """BASELINE sizes (1920x1080 and 3840x2160): size-independent properties instead of a CPU comparison.
+    - determinism (two launches, same bits); - row-band sharding == full frame (bit-exact);
+    - alpha in [0, 0.99] for the atmosphere-only variant, all values finite;
+    - discarded pixel set == analytic shell-miss set from a float64 ray/sphere test (up to limb pixels);
+    - every 8th pixel of every 8th row of the full-res frame is exactly the rect render of that pixel."""
+    tex = demo_textures()
+    for (w, h) in [(1920, 1080), (3840, 2160)]:
+        cam = S.Camera.from_pose(w, h, "P_space")
+        depth_np = S.depth_ground_sphere(cam)
+        depth = torch.from_numpy(depth_np).cuda()
+        node = make_node("no_clouds_32x8_direct", tex)
+        a = node.render(cam, depth)
+        b = node.render(cam, depth)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        assert torch.isfinite(a).all()
+        assert float(a[..., 3].min()) >= 0.0 and float(a[..., 3].max()) <= 0.99
+        # row bands as 8 ranks would shard them
+        bands = [node.render(cam, depth, rect=(0, h * k // 8, w, h * (k + 1) // 8)) for k in range(8)]
+        torch.cuda.synchronize()
+        assert torch.equal(torch.cat(bands, dim=0), a)
+        # analytic discard mask
+        d = cam.pixel_view_dirs()
+        d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        c = (cam.view @ np.array([0, 0, 0, 1.0]))[:3]
+        bq = d @ c
+        hh = (S.DEMO_PLANET_RADIUS + S.DEMO_ATMOSPHERE_HEIGHT) ** 2 - (c @ c - bq * bq)
+        miss = hh < 0
+        got_miss = (a == 0).all(dim=-1).cpu().numpy()
+        sure = np.abs(hh) > 1e-2  # pixels not within rounding distance of the limb
+        assert np.array_equal(got_miss[sure], miss[sure])
+        assert abs(int(got_miss.sum()) - int(miss.sum())) <= 64
+        node.close()
+
+
+def test_c_abi_error_codes():
+    """The C ABI reports what Godot ignores: unknown names, wrong counts, missing LUT, bad rects."""
+    from godot_atmosphere_shader_amd import _native as N
+
+    lib = N.load()
+    ctx = C.c_void_p()
+    assert lib.atmo_create(0, N.VARIANT_NO_CLOUDS, 0, 0, N.LIGHT_LUT, 0, C.byref(ctx)) == N.ATMO_OK
+    one = (C.c_float * 1)(1.0)
+    assert lib.atmo_set_param_f32(ctx, b"u_no_such_uniform", one, 1) == N.ATMO_E_NAME
+    assert b"u_no_such_uniform" in lib.atmo_last_error_string(ctx)
+    assert lib.atmo_set_param_f32(ctx, b"u_sun_position", one, 1) == N.ATMO_E_ARG
+    assert lib.atmo_set_param_f32(ctx, b"u_density", one, 1) == N.ATMO_OK
+    back = (C.c_float * 1)(0.0)
+    assert lib.atmo_get_param_f32(ctx, b"u_density", back, 1) == N.ATMO_OK and back[0] == 1.0
+    assert lib.atmo_set_texture(ctx, b"u_bogus_texture", N.TEX_2D_R8, 1, 1, 1, None, N.MEM_HOST) == N.ATMO_E_NAME
+    bn = np.zeros((128, 128), dtype=np.uint8)
+    assert lib.atmo_set_texture(ctx, b"u_blue_noise_texture", N.TEX_2D_R8, 128, 128, 1, bn.ctypes.data_as(C.c_void_p), N.MEM_HOST) == N.ATMO_E_ARG
+    f = N.AtmoFrame()
+    f.viewport_w, f.viewport_h, f.x1, f.y1 = 16, 16, 16, 16
+    depth = torch.zeros((16, 16), device="cuda")
+    out = torch.zeros((16, 16, 4), device="cuda")
+    # no LUT yet
+    assert lib.atmo_render(ctx, C.byref(f), C.c_void_p(depth.data_ptr()), C.c_void_p(out.data_ptr()), None) == N.ATMO_E_STATE
+    assert lib.atmo_bake_optical_depth(ctx, None) == N.ATMO_OK
+    f.x1 = 17
+    assert lib.atmo_render(ctx, C.byref(f), C.c_void_p(depth.data_ptr()), C.c_void_p(out.data_ptr()), None) == N.ATMO_E_ARG
+    f.x1 = 16
+    assert lib.atmo_render(ctx, C.byref(f), None, C.c_void_p(out.data_ptr()), None) == N.ATMO_E_ARG
+    assert lib.atmo_destroy(ctx) == N.ATMO_OK
+    bad = C.c_void_p()
+    assert lib.atmo_create(0, 9, 0, 0, 0, 0, C.byref(bad)) == N.ATMO_E_ARG
+    assert lib.atmo_create(99, 0, 0, 0, 0, 0, C.byref(bad)) == N.ATMO_E_NO_DEVICE
+
+
+def test_host_mirror_behaviour():
+    """PlanetAtmosphere mirrors planet_atmosphere.gd: silent unknown names, shader_params/ get/set with
+    defaults, deprecated aliases warn, u_density re-bakes the LUT, shader switch keeps parameters."""
+    from godot_atmosphere_shader_amd import PlanetAtmosphere, load_shader
+
+    tex = demo_textures(cube_n=16, shape_n=8)
+    node = PlanetAtmosphere(blue_noise=tex["blue_noise"])
+    node.set_shader_parameter("u_not_a_uniform", 3.0)  # Godot stores and ignores it
+    assert node.get_shader_parameter("u_not_a_uniform") == 3.0
+    assert node.get("shader_params/u_scattering_strength") == 20.0  # default via shader_get_parameter_default
+    with pytest.warns(DeprecationWarning):
+        node.set_shader_param("u_density", 0.3)
+    with pytest.warns(DeprecationWarning):
+        assert node.get_shader_param("u_density") == 0.3
+    names = [p["name"] for p in node.get_property_list()]
+    assert "shader_params/u_density" in names and "shader_params/u_planet_radius" not in names
+    node.planet_radius = 100.0
+    node.atmosphere_height = 8.0
+    lut_a = node.read_optical_depth()
+    node.set("shader_params/u_density", 0.5)  # planet_atmosphere.gd:217-218 -> re-bake
+    lut_b = node.read_optical_depth()
+    assert not np.array_equal(lut_a, lut_b)
+    node.custom_shader = load_shader("res://addons/zylann.atmosphere/shaders/planet_atmosphere_clouds_high_m.gdshader")
+    assert node.kernel_name == "atmo_render_kernel<3>"
+    assert "shader_params/u_cloud_blend" in [p["name"] for p in node.get_property_list()]
+    assert np.array_equal(node.read_optical_depth(), lut_b)  # parameters survived the shader switch
+    with pytest.raises(NotImplementedError):
+        load_shader("planet_atmosphere_v1_clouds.gdshader")
+    node.close()
