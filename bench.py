@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Benchmark of the atmosphere raymarch hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one synthetic frame: BASELINE.json configs[1],
+`planet_atmosphere_no_clouds` at 1920x1080 with 32 view steps x 8 light steps (direct light mode), demo
+scene, pose P_space, analytic ground-sphere depth buffer, all inputs resident in HBM before the timed
+region.  With N > 1 every rank shades its own viewport (weak scaling, BASELINE configs[4] shape: one
+viewport per GPU on an orbit of camera poses) and the frames are gathered to rank 0 over RCCL, pipelined
+two deep so that the gather of frame k overlaps the render of frame k+1; all K gathers are complete
+before the clock stops.  Rank 0 prints ONE JSON line.
+
+Other workloads (--workload): lut32 (reference-exact LUT light, 32 view steps), shipped8 (the shipped
+no_clouds shader), clouds_high, clouds_high_rm; --width/--height select the framebuffer (3840x2160 for 4K).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+BYTES_PER_RAY = 20          # 16 B RGBA32F store + 4 B depth load
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_VALU_PEAK_TFLOPS = 157.3
+
+WORKLOADS = {
+    # name: (tests/common.py CONFIGS key, description)
+    "direct32x8": ("no_clouds_32x8_direct", "planet_atmosphere_no_clouds, 32 view x 8 light steps (direct light march)"),
+    "lut32": ("no_clouds_32_lut", "planet_atmosphere_no_clouds, 32 view steps, baked-LUT light (reference algorithm)"),
+    "shipped8": ("no_clouds_8", "planet_atmosphere_no_clouds as shipped: 8 view steps, baked-LUT light"),
+    "clouds": ("clouds", "planet_atmosphere_clouds: 8 view, 32 cloud steps"),
+    "clouds_high": ("clouds_high", "planet_atmosphere_clouds_high: 8 view, 64 cloud steps, NoiseCubemap coverage"),
+    "clouds_high_rm": ("clouds_high_rm", "planet_atmosphere_clouds_high_rm: 8 view, 64 cloud x 6 light steps"),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="direct32x8", choices=sorted(WORKLOADS))
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--pose", default="P_space")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather (reported separately)")
+    ap.add_argument("--also", default="", help="comma-separated extra workloads to time at N=1 (reported under 'extra')")
+    return ap.parse_args()
+
+
+def cpu_baseline(config_name, params, textures, cam, depth_np, lut):
+    """The oracle (a port of the GDShader, not the reference itself: Godot is a GPU-only path) timed on this
+    host's cores over one full frame of the same workload."""
+    from common import CONFIGS, demo_frame
+    from oracle.oracle import Oracle
+
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    o = Oracle("f32_fast")
+    tex = dict(textures, optical_depth=lut)
+    frame = demo_frame(cam)
+    w, h = cam.width, cam.height
+    # bounded sample: every 4th 8-row band of the frame when the full frame would take too long
+    t0 = time.perf_counter()
+    _, _ = o.render(params, tex, CONFIGS[config_name][1], frame, depth_np, rect=(0, h // 2 - 4, w, h // 2 + 4), nthreads=cores)
+    probe = time.perf_counter() - t0
+    est_full = probe * h / 8.0
+    if est_full <= 30.0:
+        rect = (0, 0, w, h)
+        sample = f"1 full {w}x{h} frame"
+    else:
+        rows = max(8, int(h * 20.0 / est_full) // 8 * 8)
+        y0 = (h - rows) // 2
+        rect = (0, y0, w, y0 + rows)
+        sample = f"rows {y0}..{y0 + rows} of one {w}x{h} frame"
+    t0 = time.perf_counter()
+    _, hits = o.render(params, tex, CONFIGS[config_name][1], frame, depth_np, rect=rect, nthreads=cores)
+    dt = time.perf_counter() - t0
+    rays = (rect[2] - rect[0]) * (rect[3] - rect[1])
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": sample + f", {o.precision} build of oracle/atmo_oracle.c, {dt:.2f} s",
+            "hit_fraction": hits / rays}
+
+
+def time_workload(torch, node, cam, depth, steps, warmup, out=None):
+    """Single-GPU timed loop; returns (seconds, kernel launches, kernel ms from HIP events)."""
+    for _ in range(warmup):
+        out = node.render(cam, depth, out=out)
+    torch.cuda.synchronize()
+    node.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = node.render(cam, depth, out=out)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n, ms = node.get_timing()
+    node.set_timing(False)
+    return dt, n, ms, out
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+
+    from common import demo_params, demo_textures, make_node
+    from godot_atmosphere_shader_amd import scene as S
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    w, h = args.width, args.height
+    config_name, desc = WORKLOADS[args.workload]
+    textures = demo_textures()
+    params = demo_params()
+    pose = args.pose if (world == 1 or rank == 0) else S.orbit_pose(rank, world)
+    cam = S.Camera.from_pose(w, h, pose)
+    depth_np = S.depth_ground_sphere(cam)
+    depth = torch.from_numpy(depth_np).cuda()
+    node = make_node(config_name, textures, params, device=local_rank)
+    rays = w * h
+
+    # ---- timed region ---------------------------------------------------------------------------------
+    if world == 1:
+        dt, launches, kernel_ms, out = time_workload(torch, node, cam, depth, args.steps, args.warmup)
+        dt_max = dt
+        gather_mode = "none (single GPU)"
+    else:
+        from godot_atmosphere_shader_amd.sharding import FrameGather
+
+        gather = None if args.no_gather else FrameGather(h, w, torch.device("cuda", local_rank), dst=0, depth=2)
+        scratch = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+
+        def step():
+            if gather is None:
+                node.render(cam, depth, out=scratch)
+            else:
+                buf, slot = gather.next_send_buffer()
+                node.render(cam, depth, out=buf)
+                gather.submit(slot)
+
+        for _ in range(args.warmup):
+            step()
+        if gather is not None:
+            gather.finish()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        node.set_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        if gather is not None:
+            gather.finish()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        launches, kernel_ms = node.get_timing()
+        node.set_timing(False)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt_max = float(tmax.item())
+        gather_mode = "skipped" if gather is None else "RCCL gather to rank 0, 2 frames in flight"
+
+    if rank == 0:
+        value = world * rays * args.steps / dt_max / 1e6
+        kernel_avg_ms = kernel_ms / max(launches, 1)
+        achieved_gbs = BYTES_PER_RAY * rays / (kernel_avg_ms * 1e-3) / 1e9
+        frame = node.render(cam, depth)
+        torch.cuda.synchronize()
+        hit_fraction = float((frame.abs().sum(dim=-1) > 0).float().mean().item())
+        result = {
+            "metric": "Mrays/s at 1920x1080, 32 view x 8 light steps; % HBM roofline",
+            "value": value,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{desc}; {w}x{h}; demo scene, pose {args.pose}"
+                            + ("" if world == 1 else f" on rank 0, orbit poses on ranks 1..{world - 1}; one viewport per GPU"),
+                "width": w, "height": h, "rays_per_step_per_gpu": rays,
+                "hit_fraction": hit_fraction,
+                "mrays_per_s_hit_only": value * hit_fraction,
+                "gather": gather_mode,
+                "kernel": node.kernel_name,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved_gbs,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel_avg_ms": kernel_avg_ms,
+                "kernel_launches_timed": launches,
+                "algorithmic_bytes_per_launch": BYTES_PER_RAY * rays,
+                "note": "path is VALU/transcendental-bound, not HBM-bound (20 B/ray); see DESIGN.md",
+            },
+        }
+        if world == 1 and args.also:
+            extra = {}
+            for name in [x for x in args.also.split(",") if x]:
+                cfg2, desc2 = WORKLOADS[name]
+                node2 = make_node(cfg2, textures, params, device=local_rank)
+                dt2, n2, ms2, _ = time_workload(torch, node2, cam, depth, max(10, args.steps // 4), max(3, args.warmup // 4))
+                extra[name] = {"workload": desc2, "Mrays/s": rays * max(10, args.steps // 4) / dt2 / 1e6,
+                               "kernel_avg_ms": ms2 / max(n2, 1), "kernel": node2.kernel_name}
+                node2.close()
+            result["extra"] = extra
+        if world == 1 and not args.no_cpu_baseline:
+            lut = None if "direct" in config_name else node.read_optical_depth()
+            result["cpu_baseline"] = cpu_baseline(config_name, params, textures, cam, depth_np, lut)
+        print(json.dumps(result), flush=True)
+    node.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -485,18 +485,19 @@ int atmo_read_optical_depth(AtmoContext *ctx, float *lut_host, uint8_t *rgba8_ho
 
 int atmo_render(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, void *stream) {
     if (!ctx) return ATMO_E_ARG;
-    if (!frame || !depth_dev || !rgba_dev) return fail(ctx, ATMO_E_ARG, "atmo_render: null argument");
+    if (!frame) return fail(ctx, ATMO_E_ARG, "atmo_render: null frame");
     if (frame->viewport_w < 1 || frame->viewport_h < 1 || frame->viewport_w > 65536 || frame->viewport_h > 65536)
         return fail(ctx, ATMO_E_ARG, "atmo_render: bad viewport size");
     if (frame->x0 < 0 || frame->y0 < 0 || frame->x1 > frame->viewport_w || frame->y1 > frame->viewport_h ||
         frame->x0 > frame->x1 || frame->y0 > frame->y1)
         return fail(ctx, ATMO_E_ARG, "atmo_render: rect outside the viewport");
+    if (frame->x0 == frame->x1 || frame->y0 == frame->y1) return ATMO_OK;  // empty rect: nothing to shade
+    if (!depth_dev || !rgba_dev) return fail(ctx, ATMO_E_ARG, "atmo_render: null device pointer");
     if ((reinterpret_cast<uintptr_t>(rgba_dev) & 15u) != 0) return fail(ctx, ATMO_E_ARG, "atmo_render: rgba_dev must be 16-byte aligned");
     if (!(ctx->flags & atmo::KF_LIGHT_DIRECT) && !ctx->lut.ptr)
         return fail(ctx, ATMO_E_STATE, "atmo_render: u_optical_depth_texture not set (call atmo_bake_optical_depth or atmo_set_texture)");
     if ((ctx->flags & atmo::KF_CLOUDS) && !ctx->shape.ptr)
         return fail(ctx, ATMO_E_STATE, "atmo_render: u_cloud_shape_texture not set");
-    if (frame->x0 == frame->x1 || frame->y0 == frame->y1) return ATMO_OK;  // empty rect: nothing to shade
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     atmo::RenderConsts rc;

@@ -301,6 +301,9 @@ class PlanetAtmosphere:
             self.close()
             self._create_context()
             for k, v in list(self._params.items()):  # the material keeps its parameters across shader changes
+                if k == "u_optical_depth_texture" and isinstance(v, str):
+                    self._bake_pending = True  # device-baked LUT: re-bake into the new context
+                    continue
                 self._forward(k, v)
         self._sync_bake_flag()
 

@@ -56,7 +56,7 @@ def test_parity_demo_scene(oracle32, config_name, pose):
     depth = S.depth_ground_sphere(cam)
     node = make_node(config_name, tex, params)
     got = _gpu_render(node, cam, depth)
-    lut = node.read_optical_depth()
+    lut = None if "direct" in config_name else node.read_optical_depth()
     want, hits = _oracle_render(oracle32, config_name, params, tex, cam, depth, lut)
     node.close()
     # discard decisions must agree exactly (they are taken in the bit-exact prologue)
@@ -175,7 +175,7 @@ def test_full_size_properties():
         torch.cuda.synchronize()
         assert torch.equal(a, b)
         assert torch.isfinite(a).all()
-        assert float(a[..., 3].min()) >= 0.0 and float(a[..., 3].max()) <= 0.99
+        assert float(a[..., 3].min()) >= 0.0 and float(a[..., 3].max()) <= float(np.float32(0.99))
         # row bands as 8 ranks would shard them
         bands = [node.render(cam, depth, rect=(0, h * k // 8, w, h * (k + 1) // 8)) for k in range(8)]
         torch.cuda.synchronize()
