@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz: small frames rendered by the fp32 CPU oracle at the reference's demo-scene
+parameters (addons/zylann.atmosphere/demo/planet_atmosphere_test.tscn:96-114).
+
+The reference ships no golden vectors and cannot be executed here (GDShader; no Godot), so these fixtures
+pin the oracle against itself over time (regression) and give the GPU tests committed expected outputs.
+They are data: inputs are regenerated from seeds (texture CRCs are stored to detect generator drift),
+expected outputs are the stored RGBA arrays.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from common import CONFIGS, demo_frame, demo_params, demo_textures  # noqa: E402
+from godot_atmosphere_shader_amd import scene as S  # noqa: E402
+from oracle.oracle import Oracle  # noqa: E402
+
+W, H = 64, 36
+GOLDEN_POSES = ["P_space", "P_ground", "P_limb"]
+
+
+def main():
+    o = Oracle("f32")
+    tex = demo_textures()
+    params = demo_params()
+    lut = o.bake_optical_depth(S.DEMO_PLANET_RADIUS, S.DEMO_ATMOSPHERE_HEIGHT, params["u_density"])
+    out = {
+        "crc_blue_noise": np.uint32(S.checksum(tex["blue_noise"])),
+        "crc_shape": np.uint32(S.checksum(tex["shape"])),
+        "crc_cubemap": np.uint32(S.checksum(tex["cubemap"])),
+        "crc_lut": np.uint32(S.checksum(lut)),
+        "lut_probe_idx": np.array([0, 255, 256 * 128 + 17, 256 * 200 + 250, 65535], dtype=np.int64),
+    }
+    out["lut_probe_val"] = lut.reshape(-1)[out["lut_probe_idx"]]
+    for pose in GOLDEN_POSES:
+        cam = S.Camera.from_pose(W, H, pose)
+        depth = S.depth_ground_sphere(cam)
+        out[f"depth_{pose}"] = depth
+        for name, (_, cfg, _) in CONFIGS.items():
+            img, hits = o.render(params, dict(tex, optical_depth=lut), cfg, demo_frame(cam), depth, nthreads=4)
+            out[f"rgba_{name}_{pose}"] = img
+            out[f"hits_{name}_{pose}"] = np.int64(hits)
+    path = os.path.join(HERE, "demo_scene_64x36.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -257,3 +257,21 @@ def test_host_mirror_behaviour():
     with pytest.raises(NotImplementedError):
         load_shader("planet_atmosphere_v1_clouds.gdshader")
     node.close()
+
+
+@pytest.mark.parametrize("pose", ["P_space", "P_ground", "P_limb"])
+def test_gpu_matches_committed_golden(pose):
+    """HIP path vs the committed golden frames (tests/golden/demo_scene_64x36.npz, made by the fp32 oracle)."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "demo_scene_64x36.npz"))
+    tex = demo_textures()
+    assert S.checksum(tex["cubemap"]) == int(g["crc_cubemap"]) and S.checksum(tex["shape"]) == int(g["crc_shape"])
+    cam = S.Camera.from_pose(64, 36, pose)
+    for config_name in CONFIGS:
+        node = make_node(config_name, tex)
+        got = _gpu_render(node, cam, g[f"depth_{pose}"])
+        node.close()
+        want = g[f"rgba_{config_name}_{pose}"]
+        assert int((np.abs(got).sum(axis=-1) > 0).sum()) == int(g[f"hits_{config_name}_{pose}"])
+        assert np.abs(got - want).max() <= TOL, config_name

@@ -1,0 +1,166 @@
+"""CPU-only tests of the host side: the C ABI library loads and exports every symbol include/atmo.h declares
+(no compute without a GPU), it fails loudly without a device, sharding index math, scene generators, and the
+pieces of the PlanetAtmosphere mirror that need no GPU."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from godot_atmosphere_shader_amd import scene as S
+from godot_atmosphere_shader_amd import sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    from godot_atmosphere_shader_amd import _native as N
+    return N.load().atmo_device_count() > 0
+
+
+def test_library_exports_every_declared_symbol():
+    from godot_atmosphere_shader_amd import _native as N
+    from godot_atmosphere_shader_amd.build import build_native
+
+    build_native()
+    lib = N.load()
+    header = open(os.path.join(ROOT, "include", "atmo.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(atmo_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(N.EXPORTED_SYMBOLS)
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+    assert lib.atmo_abi_version() == N.ABI_VERSION
+
+
+def test_struct_layout_matches_header():
+    from godot_atmosphere_shader_amd import _native as N
+    # 16+16 floats, 2 ints, 3+3+1 floats, 4 ints
+    assert C.sizeof(N.AtmoFrame) == (32 + 2 + 7 + 4) * 4
+
+
+def test_no_gpu_fails_loudly():
+    """Without an MI355X there is no fallback: create fails with ATMO_E_NO_DEVICE and says why."""
+    from godot_atmosphere_shader_amd import _native as N
+    if _has_gpu():
+        pytest.skip("GPU present")
+    lib = N.load()
+    assert lib.atmo_device_count() < 0
+    ctx = C.c_void_p()
+    rc = lib.atmo_create(0, N.VARIANT_NO_CLOUDS, 0, 0, N.LIGHT_LUT, 0, C.byref(ctx))
+    assert rc == N.ATMO_E_NO_DEVICE and not ctx.value
+    assert b"no HIP device" in lib.atmo_last_error_string(None)
+    from godot_atmosphere_shader_amd import PlanetAtmosphere
+    with pytest.raises(N.AtmoError):
+        PlanetAtmosphere()
+
+
+def test_argument_validation_needs_no_gpu():
+    from godot_atmosphere_shader_amd import _native as N
+    lib = N.load()
+    ctx = C.c_void_p()
+    assert lib.atmo_create(0, 17, 0, 0, 0, 0, C.byref(ctx)) == N.ATMO_E_ARG
+    assert lib.atmo_create(0, 0, 0, 0, N.LIGHT_DIRECT, 0, C.byref(ctx)) == N.ATMO_E_ARG  # direct needs light_steps
+    assert lib.atmo_create(0, 0, -1, 0, 0, 0, C.byref(ctx)) == N.ATMO_E_ARG
+    assert lib.atmo_create(0, 0, 0, 0, 0, 0, None) == N.ATMO_E_ARG
+    assert lib.atmo_destroy(None) == N.ATMO_OK
+    assert lib.atmo_set_param_f32(None, b"u_density", (C.c_float * 1)(1.0), 1) == N.ATMO_E_ARG
+
+
+def test_row_bands_cover_and_partition():
+    for h in (1, 7, 1080, 2160, 1081):
+        for n in (1, 2, 3, 4, 8):
+            bands = sharding.row_bands(h, n)
+            assert len(bands) == n and bands[0][0] == 0 and bands[-1][1] == h
+            assert all(a[1] == b[0] for a, b in zip(bands, bands[1:]))
+            sizes = [b[1] - b[0] for b in bands]
+            assert max(sizes) - min(sizes) <= 1
+    assert sharding.row_bands(2, 4) == [(0, 0), (0, 1), (1, 1), (1, 2)]
+    assert sharding.band_rect(1920, (135, 270)) == (0, 135, 1920, 270)
+    with pytest.raises(ValueError):
+        sharding.row_bands(10, 0)
+
+
+def test_balanced_row_bands_equalise_hits():
+    # P_space-like profile: empty rows top and bottom, a disc in the middle
+    h = 1080
+    y = np.arange(h) - h / 2
+    cost = np.sqrt(np.maximum(430.0 ** 2 - y ** 2, 0.0))
+    bands = sharding.balanced_row_bands(cost, 8)
+    assert bands[0][0] == 0 and bands[-1][1] == h and all(a[1] == b[0] for a, b in zip(bands, bands[1:]))
+    sums = [cost[a:b].sum() for a, b in bands]
+    assert max(sums) / (sum(sums) / 8) < 1.02
+    equal = [cost[a:b].sum() for a, b in sharding.row_bands(h, 8)]
+    assert max(equal) / (sum(equal) / 8) > 1.5  # what balancing fixes
+    assert sharding.balanced_row_bands(np.zeros(16), 4) == sharding.row_bands(16, 4)
+
+
+def test_scene_generators_are_deterministic_and_well_formed():
+    bn = S.make_blue_noise()
+    assert bn.shape == (256, 256) and bn.dtype == np.uint8
+    assert np.array_equal(np.bincount(bn.ravel(), minlength=256), np.full(256, 256))  # flat histogram, mean 127.5
+    assert S.checksum(bn) == S.checksum(S.make_blue_noise())
+    sh = S.make_shape_texture(16, cells=4)
+    assert sh.shape == (16, 16, 16) and sh.std() > 10
+    cm = S.make_coverage_cubemap(16)
+    assert cm.shape == (6, 16, 16)
+    d = S.cube_texel_directions(4)
+    assert np.allclose(np.linalg.norm(d, axis=-1), 1.0)
+    # Vulkan table: +X face has x as the major axis, s grows with -z, t grows with -y
+    assert np.all(d[0, ..., 0] > 0.5) and d[0, 0, 0, 2] > d[0, 0, 3, 2] and d[0, 0, 0, 1] > d[0, 3, 0, 1]
+    assert np.all(d[3, ..., 1] < -0.5) and np.all(d[4, ..., 2] > 0.5)
+
+
+def test_camera_conventions():
+    cam = S.Camera.from_pose(64, 36, "P_space")
+    # centre pixel looks down -Z in view space; reversed-Z: depth 1 at near, 0 at far
+    v = cam.inv_projection @ np.array([0.0, 0.0, 1.0, 1.0])
+    assert (v[:3] / v[3])[2] == pytest.approx(-cam.near)
+    v = cam.inv_projection @ np.array([0.0, 0.0, 0.0, 1.0])
+    assert (v[:3] / v[3])[2] == pytest.approx(-cam.far, rel=1e-6)
+    # SCREEN_UV origin top-left: ndc y = -1 is the top of the view (+Y up)
+    top = cam.inv_projection @ np.array([0.0, -1.0, 1.0, 1.0])
+    assert top[1] / top[3] > 0
+    depth = S.depth_ground_sphere(cam)
+    assert depth.dtype == np.float32 and depth.max() < 1.0 and depth.min() == 0.0
+    hit = depth > 0
+    assert 0.3 < hit.mean() < 0.6  # the ground sphere covers about half of the 16:9 frame from the demo camera
+
+
+def test_srgb_to_linear_and_demo_params():
+    assert S.srgb_to_linear(1.0) == pytest.approx(1.0)
+    assert S.srgb_to_linear(0.0196078) == pytest.approx(0.0196078 / 12.92)
+    assert S.srgb_to_linear(0.980392) == pytest.approx(((0.980392 + 0.055) / 1.055) ** 2.4)
+    assert S.DEMO_SHADER_PARAMS["u_atmosphere_ambient_color"][2] == pytest.approx(((0.0431373 + 0.055) / 1.055) ** 2.4)
+
+
+def test_shader_resources_and_transform2d():
+    from godot_atmosphere_shader_amd import SHADERS, Transform2D, atmosphere_vertex, load_shader
+    assert load_shader("res://addons/zylann.atmosphere/shaders/planet_atmosphere_clouds_high_m.gdshader") is SHADERS["planet_atmosphere_clouds_high_rm"]
+    assert load_shader("planet_atmosphere_clouds").cloud_steps == 32
+    assert load_shader("planet_atmosphere_clouds_high.gdshader").cloud_steps == 64
+    assert all(s.view_steps == 8 for s in SHADERS.values())
+    with pytest.raises(FileNotFoundError):
+        load_shader("nope.gdshader")
+    names = [u["name"] for u in SHADERS["planet_atmosphere_no_clouds"].get_shader_uniform_list()]
+    assert "u_optical_depth_texture" in names and "u_cloud_blend" not in names
+    t = Transform2D().rotated(0.3).as_mat2_col_major()
+    assert np.allclose(t, [math.cos(0.3), math.sin(0.3), -math.sin(0.3), math.cos(0.3)])
+    cam = S.Camera.from_pose(16, 9, "P_space")
+    planet, sun = atmosphere_vertex(cam.view, np.eye(4), S.DEMO_SUN_POSITION)
+    assert planet.dtype == np.float32
+    assert np.allclose(planet, [-0.357289, -0.105603, -157.92054], atol=1e-4)
+    assert np.allclose(sun, [-0.357289, -0.105603, 478.677 - 157.92054], atol=1e-3)
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under the package may reference it."""
+    pkg = os.path.join(ROOT, "godot_atmosphere_shader_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "liboracle" not in text, f
+                assert "atmo_oracle" not in text, f
