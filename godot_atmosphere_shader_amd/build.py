@@ -11,15 +11,20 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "libatmo_hip.so")
+# ATMO_HIP_LIB: load a differently-built library instead (A/B experiments on compiler flags; see tools/ab_build.sh)
+LIB_PATH = os.environ.get("ATMO_HIP_LIB") or os.path.join(_HERE, "libatmo_hip.so")
 SOURCES = ["atmo_api.hip", "atmo_kernels.hip"]
 HEADERS = ["atmo_device.h", os.path.join("..", "..", "include", "atmo.h")]
 
 # -ffp-contract=off: the kernels and the host-side per-frame constants must round exactly like a scalar
 # fp32 evaluation of the shader wherever control flow or the ill-conditioned cloud chain is involved;
 # hot loops opt back into FMA with `#pragma clang fp contract(fast)`.
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: hipcc's SLP pass packs neighbouring scalar f32 ops into v_pk_*_f32 plus the v_mov
+# shuffles that feed them; on gfx950 a v_pk_fma_f32 issues in ~5 cycles against 2.8 for v_fma_f32
+# (profiles/round1/valu_peak_mi355x.jsonl), so the packing loses: measured +8..19 % Mrays/s on every workload
+# with it off (profiles/round1/ab_slp_vectorize.txt).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
+               "-shared", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc() -> str:

@@ -182,6 +182,49 @@ void build_cube_apron(const uint8_t *faces, int n, std::vector<uint8_t> &out) {
             }
 }
 
+// ---- device texture layouts (see atmo_kernels.hip "samplers") ---------------------------------------------
+
+// 6 x (n+1)^2 words: word (i,j) of a face = padded texels (i,j), (i+1,j), (i,j+1), (i+1,j+1) in bytes 0..3
+void build_cube_footprints(const std::vector<uint8_t> &padded, int n, std::vector<uint32_t> &out) {
+    const int ps = n + 2, fs = n + 1;
+    out.assign((size_t)6 * fs * fs, 0u);
+    for (int f = 0; f < 6; ++f)
+        for (int j = 0; j < fs; ++j)
+            for (int i = 0; i < fs; ++i) {
+                const uint8_t *p = &padded[((size_t)f * ps + j) * ps + i];
+                out[((size_t)f * fs + j) * fs + i] =
+                    (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[ps] << 16) | ((uint32_t)p[ps + 1] << 24);
+            }
+}
+
+// n^3 words: word (i,j,k) = T(i,j,k), T(i+1,j,k), T(i,j+1,k), T(i+1,j+1,k) with repeat wrap
+void build_shape_footprints(const uint8_t *t, int n, std::vector<uint32_t> &out) {
+    out.assign((size_t)n * n * n, 0u);
+    for (int k = 0; k < n; ++k)
+        for (int j = 0; j < n; ++j) {
+            const int j1 = (j + 1) % n;
+            const uint8_t *r0 = t + ((size_t)k * n + j) * n, *r1 = t + ((size_t)k * n + j1) * n;
+            for (int i = 0; i < n; ++i) {
+                const int i1 = (i + 1) % n;
+                out[((size_t)k * n + j) * n + i] =
+                    (uint32_t)r0[i] | ((uint32_t)r0[i1] << 8) | ((uint32_t)r1[i] << 16) | ((uint32_t)r1[i1] << 24);
+            }
+        }
+}
+
+// (h+2) x (w+2) floats with a clamp-to-edge apron
+void build_lut_apron(const float *lut, int w, int h, std::vector<float> &out) {
+    const int st = w + 2;
+    out.assign((size_t)st * (h + 2), 0.0f);
+    for (int j = -1; j <= h; ++j) {
+        const int cj = j < 0 ? 0 : (j >= h ? h - 1 : j);
+        for (int i = -1; i <= w; ++i) {
+            const int ci = i < 0 ? 0 : (i >= w ? w - 1 : i);
+            out[(size_t)(j + 1) * st + (i + 1)] = lut[(size_t)cj * w + ci];
+        }
+    }
+}
+
 // ---- per-frame constants, evaluated like a scalar fp32 run of the shader would ----------------------------
 inline float pow2f(float x) { return x * x; }
 inline float pow4f(float x) { return x * x * x * x; }
@@ -228,6 +271,7 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
     rc.clouds_bottom = p.u_planet_radius + p.u_cloud_bottom * p.u_atmosphere_height;
     rc.clouds_top = p.u_planet_radius + p.u_cloud_top * p.u_atmosphere_height;
     rc.cloud_thickness = rc.clouds_top - rc.clouds_bottom;
+    rc.inv_cloud_thickness = 1.0f / rc.cloud_thickness;
     rc.cloud_density_scale = p.u_cloud_density_scale;
     rc.cloud_blend = p.u_cloud_blend;
     rc.coverage_bias = p.u_cloud_coverage_bias;
@@ -256,14 +300,20 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
     rc.cloud_steps = ctx->cloud_steps;
     rc.inv_cloud_steps = ctx->cloud_steps > 0 ? 1.0f / (float)ctx->cloud_steps : 0.0f;
     {
+        // get_light_raymarched (clouds:104-151): step_len grows x1.2 after each tap
         const float reach = (rc.clouds_top - rc.clouds_bottom) * 0.15f;
         const float inv_steps = 1.0f / 6.0f;
-        rc.rm_step0 = reach * inv_steps;
+        float step_len = reach * inv_steps;
+        for (int i = 0; i < 6; ++i) {
+            rc.rm_offset[i] = (float)i * step_len;
+            rc.rm_weight[i] = step_len * p.u_cloud_density_scale;
+            step_len *= 1.2f;
+        }
     }
     rc.lut = (const float *)ctx->lut.ptr; rc.lut_w = ctx->lut_w; rc.lut_h = ctx->lut_h;
     rc.blue = (const uint8_t *)ctx->blue.ptr;
-    rc.shape = (const uint8_t *)ctx->shape.ptr; rc.shape_n = ctx->shape_n;
-    rc.cube = (const uint8_t *)ctx->cube.ptr; rc.cube_n = ctx->cube_n;
+    rc.shape = (const uint32_t *)ctx->shape.ptr; rc.shape_n = ctx->shape_n;
+    rc.cube = (const uint32_t *)ctx->cube.ptr; rc.cube_n = ctx->cube_n;
     rc.depth = depth;
     rc.out = (float4 *)rgba;
 }
@@ -397,9 +447,13 @@ int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h,
         if (!data) { dev_free(ctx->lut); ctx->lut_w = ctx->lut_h = 0; return ATMO_OK; }
         if (kind != ATMO_TEX_2D_R32F) return fail(ctx, ATMO_E_ARG, "u_optical_depth_texture must be ATMO_TEX_2D_R32F");
         if (w < 1 || h < 1 || w > 8192 || h > 8192) return fail(ctx, ATMO_E_ARG, "u_optical_depth_texture: bad size");
-        int rc = dev_alloc(ctx, ctx->lut, (size_t)w * h * sizeof(float));
+        std::vector<float> host((size_t)w * h), padded;
+        if (memory == ATMO_MEM_HOST) std::memcpy(host.data(), data, host.size() * sizeof(float));
+        else HIP_TRY(ctx, hipMemcpy(host.data(), data, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+        build_lut_apron(host.data(), w, h, padded);
+        int rc = dev_alloc(ctx, ctx->lut, padded.size() * sizeof(float));
         if (rc != ATMO_OK) return rc;
-        HIP_TRY(ctx, hipMemcpy(ctx->lut.ptr, data, ctx->lut.bytes, ck));
+        HIP_TRY(ctx, hipMemcpy(ctx->lut.ptr, padded.data(), ctx->lut.bytes, hipMemcpyHostToDevice));
         ctx->lut_w = w; ctx->lut_h = h;
         return ATMO_OK;
     }
@@ -414,9 +468,14 @@ int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h,
         if (!data) { dev_free(ctx->shape); ctx->shape_n = 0; return ATMO_OK; }
         if (kind != ATMO_TEX_3D_R8) return fail(ctx, ATMO_E_ARG, "u_cloud_shape_texture must be ATMO_TEX_3D_R8");
         if (w < 1 || w > 512 || h != w || d != w) return fail(ctx, ATMO_E_ARG, "u_cloud_shape_texture must be n x n x n, n <= 512");
-        int rc = dev_alloc(ctx, ctx->shape, (size_t)w * w * w);
+        std::vector<uint8_t> host((size_t)w * w * w);
+        if (memory == ATMO_MEM_HOST) std::memcpy(host.data(), data, host.size());
+        else HIP_TRY(ctx, hipMemcpy(host.data(), data, host.size(), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> fp;
+        build_shape_footprints(host.data(), w, fp);
+        int rc = dev_alloc(ctx, ctx->shape, fp.size() * sizeof(uint32_t));
         if (rc != ATMO_OK) return rc;
-        HIP_TRY(ctx, hipMemcpy(ctx->shape.ptr, data, ctx->shape.bytes, ck));
+        HIP_TRY(ctx, hipMemcpy(ctx->shape.ptr, fp.data(), ctx->shape.bytes, hipMemcpyHostToDevice));
         ctx->shape_n = w;
         return ATMO_OK;
     }
@@ -430,9 +489,11 @@ int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h,
         else HIP_TRY(ctx, hipMemcpy(host.data(), data, host.size(), hipMemcpyDeviceToHost));
         std::vector<uint8_t> padded;
         build_cube_apron(host.data(), w, padded);
-        int rc = dev_alloc(ctx, ctx->cube, padded.size());
+        std::vector<uint32_t> fp;
+        build_cube_footprints(padded, w, fp);
+        int rc = dev_alloc(ctx, ctx->cube, fp.size() * sizeof(uint32_t));
         if (rc != ATMO_OK) return rc;
-        HIP_TRY(ctx, hipMemcpy(ctx->cube.ptr, padded.data(), padded.size(), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(ctx->cube.ptr, fp.data(), ctx->cube.bytes, hipMemcpyHostToDevice));
         ctx->cube_n = w;
         return ATMO_OK;
     }
@@ -445,7 +506,7 @@ int atmo_bake_optical_depth(AtmoContext *ctx, void *stream) {
     const int w = 256, h = 256;  // optical_depth_baker.gd:24
     if (ctx->lut_w != w || ctx->lut_h != h) {
         HIP_TRY(ctx, hipDeviceSynchronize());
-        int rc = dev_alloc(ctx, ctx->lut, (size_t)w * h * sizeof(float));
+        int rc = dev_alloc(ctx, ctx->lut, (size_t)(w + 2) * (h + 2) * sizeof(float));
         if (rc != ATMO_OK) return rc;
         ctx->lut_w = w; ctx->lut_h = h;
     }
@@ -467,10 +528,12 @@ int atmo_read_optical_depth(AtmoContext *ctx, float *lut_host, uint8_t *rgba8_ho
     if (capacity_texels < n) return fail(ctx, ATMO_E_ARG, "atmo_read_optical_depth: buffer too small");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
-    std::vector<float> tmp;
+    std::vector<float> tmp, padded((size_t)(ctx->lut_w + 2) * (ctx->lut_h + 2));
     float *dst = lut_host;
     if (!dst) { tmp.resize(n); dst = tmp.data(); }
-    HIP_TRY(ctx, hipMemcpy(dst, ctx->lut.ptr, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(padded.data(), ctx->lut.ptr, padded.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int j = 0; j < ctx->lut_h; ++j)  // strip the apron
+        std::memcpy(dst + (size_t)j * ctx->lut_w, &padded[(size_t)(j + 1) * (ctx->lut_w + 2) + 1], (size_t)ctx->lut_w * sizeof(float));
     if (rgba8_host) {
         // encode_float_to_viewport (optical_depth.gdshader:33-43): byte k of the bit pattern, little-endian;
         // value/255 stored to UNORM8 gives the byte back, so the packing is the raw IEEE bytes.
@@ -536,9 +599,26 @@ int atmo_get_timing(AtmoContext *ctx, int *launches, double *total_ms) {
     return ATMO_OK;
 }
 
+int atmo_selftest_exact_math(AtmoContext *ctx, uint32_t first_bits, uint32_t count, float divisor,
+                             uint32_t *sqrt_mismatches, uint32_t *div_mismatches) {
+    if (!ctx) return ATMO_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned int *d = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d, 2 * sizeof(unsigned int)));
+    hipError_t e = hipMemset(d, 0, 2 * sizeof(unsigned int));
+    if (e == hipSuccess) e = atmo::launch_selftest(first_bits, count, divisor, 1.0f / divisor, d, nullptr);
+    unsigned int h[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return hip_fail(ctx, e, "atmo_selftest_exact_math");
+    if (sqrt_mismatches) *sqrt_mismatches = h[0];
+    if (div_mismatches) *div_mismatches = h[1];
+    return ATMO_OK;
+}
+
 const char *atmo_kernel_name(AtmoContext *ctx) {
     if (!ctx) return "";
-    return atmo::render_kernel_name(ctx->flags);
+    return atmo::render_kernel_name(ctx->flags, ctx->light_steps);
 }
 
 const char *atmo_last_error_string(AtmoContext *ctx) {

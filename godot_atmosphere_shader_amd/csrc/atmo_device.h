@@ -33,6 +33,7 @@ struct RenderConsts {
     // --- render_clouds / raymarch_cloud (shaders/include/cloud_funcs.gdshaderinc:175-324)
     float clouds_bottom, clouds_top;  // [host] R + u_cloud_{bottom,top} * H   clouds:260-261
     float cloud_thickness;            // [host] top - bottom
+    float inv_cloud_thickness;        // [host] RN(1 / thickness), for exact_div_uniform
     float cloud_density_scale, cloud_blend, coverage_bias, shape_factor, shape_scale;
     int32_t shape_invert;             // u_cloud_shape_invert == 1.0           clouds:57
     float cov_rot[4];                 // mat2 column-major
@@ -42,14 +43,15 @@ struct RenderConsts {
     float max_d;                      // [host] march-distance cap             clouds:186-202
     float inv_cloud_steps;            // [host] 1/float(steps)                 clouds:206
     int32_t cloud_steps;
-    float rm_step0;                   // [host] reach * (1/6)                  clouds:108,114-115
+    float rm_offset[6];               // [host] float(i) * step_len_i, step_len_i = reach/6 * 1.2^i   clouds:108,114-115,129,143
+    float rm_weight[6];               // [host] step_len_i * density_scale     clouds:138
     // --- textures (device memory owned by the context)
-    const float *lut;        // u_optical_depth_texture, lut_h rows of lut_w
+    const float *lut;        // u_optical_depth_texture: (lut_h+2) rows of (lut_w+2), clamp-to-edge apron
     int32_t lut_w, lut_h;
     const uint8_t *blue;     // u_blue_noise_texture 256x256
-    const uint8_t *shape;    // u_cloud_shape_texture n^3
+    const uint32_t *shape;   // u_cloud_shape_texture: n^3 xy-footprint words (repeat wrap baked in)
     int32_t shape_n;
-    const uint8_t *cube;     // u_cloud_coverage_cubemap, 6 faces of (n+2)^2 with seamless apron; null => 1.0
+    const uint32_t *cube;    // u_cloud_coverage_cubemap: 6 x (n+1)^2 footprint words of the seamless-apron faces; null => 1.0
     int32_t cube_n;
     // --- per-pixel streams
     const float *depth;      // h rows of w
@@ -59,7 +61,7 @@ struct RenderConsts {
 struct BakeConsts {
     float planet_radius, atmosphere_height, density;
     int32_t w, h, steps;
-    float *out;
+    float *out;  // (h+2) x (w+2), apron written by the edge texels' lanes
 };
 
 // kernel launchers (atmo_kernels.hip)
@@ -67,6 +69,7 @@ enum KernelFlags : int { KF_CLOUDS = 1, KF_CLOUD_LIGHT_RM = 2, KF_LIGHT_DIRECT =
 
 hipError_t launch_render(int flags, const RenderConsts &rc, hipStream_t stream);
 hipError_t launch_bake(const BakeConsts &bc, hipStream_t stream);
-const char *render_kernel_name(int flags);
+const char *render_kernel_name(int flags, int light_steps);
+hipError_t launch_selftest(uint32_t first_bits, uint32_t count, float c, float rc, unsigned int *mismatch_dev, hipStream_t stream);
 
 }  // namespace atmo

@@ -42,9 +42,33 @@ __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fm
 __device__ __forceinline__ float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 // IEEE-754 correctly rounded sqrt and divide: hipcc's default (-fhip-fp32-correctly-rounded-divide-sqrt)
 // expands these to the fix-up sequences; __fsqrt_rn/__fdiv_rn are NOT used because the HIP headers map
-// __fsqrt_rn to the native (1 ulp) square root.  tests/test_gpu_parity.py checks bit-exactness via the LUT bake.
+// __fsqrt_rn to the native (1 ulp) square root.  Used in the once-per-pixel prologue and the LUT bake.
 __device__ __forceinline__ float ieee_sqrt(float x) { return __builtin_sqrtf(x); }
 __device__ __forceinline__ float ieee_div(float a, float b) { return a / b; }
+
+// Correctly rounded sqrt for the per-step cloud chain, x >= 0 and not denormal/inf/nan (x = |pos|^2 ~ 1e4):
+// the hardware root is within 1 ulp, so the result is s-1ulp, s or s+1ulp; the sign of the exact FMA
+// residuals x - (s-1ulp)*s and x - (s+1ulp)*s picks it (the same test LLVM's expansion uses, minus its
+// denormal scaling and class checks).  1 transcendental + 8 VALU instead of 1 + 15.
+__device__ __forceinline__ float exact_sqrt(float x) {
+    const float s = hw_sqrt(x);
+    const float s_dn = __int_as_float(__float_as_int(s) - 1);
+    const float s_up = __int_as_float(__float_as_int(s) + 1);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x);
+    const float r_up = __builtin_fmaf(-s_up, s, x);
+    float o = (r_dn <= 0.0f) ? s_dn : s;
+    o = (r_up > 0.0f) ? s_up : o;
+    return o;
+}
+// Correctly rounded a / c for a wave-uniform divisor c with rc = RN(1/c) computed on the host (IEEE):
+// two Markstein corrections of a*rc with exact FMA residuals.  5 VALU instead of 11 + v_rcp.
+// (Checked exhaustively on the CPU for every float32 significand of `a` against a / c for the demo's divisors;
+// tests/test_gpu_parity.py::test_exact_math_selftest sweeps it on the device.)
+__device__ __forceinline__ float exact_div_uniform(float a, float c, float rc) {
+    const float q0 = a * rc;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, c, a), rc, q0);
+    return __builtin_fmaf(__builtin_fmaf(-q1, c, a), rc, q1);
+}
 
 // ---- exact (IEEE, unfused) helpers: must match a scalar fp32 evaluation bit for bit -------------
 struct V3 {
@@ -75,103 +99,88 @@ __device__ __forceinline__ float2 hit_radius(SphereHit s, float radius) {
 }
 
 // ---- samplers ----------------------------------------------------------------------------------
+// Device texture layouts (built by atmo_api.hip when a texture is set, see DESIGN.md "Data layout in HBM"):
+//   LUT    (w+2) x (h+2) fp32 with a clamp-to-edge apron: texel (i,j) at [(j+1)*(w+2) + i+1]; a bilinear
+//          footprint is two adjacent-pair loads, no index clamps in the loop.
+//   shape  n^3 uint32 "xy footprints": word (i,j,k) = bytes T(i,j,k), T(i+1,j,k), T(i,j+1,k), T(i+1,j+1,k) with the
+//          repeat wrap baked in; a trilinear fetch is 2 dword loads (planes k, k+1) instead of 8 byte loads.
+//   cube   6 x (n+1)^2 uint32 footprints of the apron-padded faces: word (i,j) = the 2x2 texels whose top-left
+//          padded coordinate is (i,j); a seamless bilinear fetch is 1 dword load instead of 4 byte loads.
+// The vector-memory path issues a 64-lane gather at ~16 cycles per wave instruction however narrow the
+// data, so instruction count, not bytes, is what these layouts buy (profiles/round1).
 
-// texture(u_optical_depth_texture, (u, v)).r : bilinear, clamp-to-edge, R32F
-__device__ __forceinline__ float lut_sample(const float *__restrict__ lut, int w, int h, float u, float v) {
+// byte k of a footprint word as float (the compiler selects v_cvt_f32_ubyte0..3)
+__device__ __forceinline__ float ub0(uint32_t w) { return (float)(w & 0xffu); }
+__device__ __forceinline__ float ub1(uint32_t w) { return (float)((w >> 8) & 0xffu); }
+__device__ __forceinline__ float ub2(uint32_t w) { return (float)((w >> 16) & 0xffu); }
+__device__ __forceinline__ float ub3(uint32_t w) { return (float)(w >> 24); }
+
+// texture(u_optical_depth_texture, uv).r : bilinear, clamp-to-edge, R32F.  x = u*w - 0.5, y = v*h - 0.5 (texel space).
+__device__ __forceinline__ float lut_sample_xy(const float *__restrict__ lut, int stride, float x, float y) {
 #pragma clang fp contract(fast)
-    float x = u * (float)w - 0.5f;
-    float y = v * (float)h - 0.5f;
-    float xf = floorf(x), yf = floorf(y);
-    float fx = x - xf, fy = y - yf;
-    int i = (int)xf, j = (int)yf;
-    int i0 = max(i, 0), i1 = min(i + 1, w - 1);
-    int j0 = max(j, 0), j1 = min(j + 1, h - 1);
-    const float *r0 = lut + j0 * w;
-    const float *r1 = lut + j1 * w;
-    float t00 = r0[i0], t10 = r0[i1], t01 = r1[i0], t11 = r1[i1];
-    float a = t00 + (t10 - t00) * fx;
-    float b = t01 + (t11 - t01) * fx;
+    const float xf = floorf(x), yf = floorf(y);
+    const float fx = x - xf, fy = y - yf;
+    const int i = (int)xf + 1, j = (int)yf + 1;  // apron coordinates
+    const float *p = lut + j * stride + i;
+    const float t00 = p[0], t10 = p[1], t01 = p[stride], t11 = p[stride + 1];
+    const float a = t00 + (t10 - t00) * fx;
+    const float b = t01 + (t11 - t01) * fx;
     return a + (b - a) * fy;
 }
 
-// texture(u_cloud_shape_texture, p).r : trilinear, repeat, R8 (n^3, x fastest)
-__device__ __forceinline__ float shape_sample(const uint8_t *__restrict__ tex, int n, float px, float py, float pz) {
+// texture(u_cloud_shape_texture, p).r : trilinear, repeat, R8
+__device__ __forceinline__ float shape_sample(const uint32_t *__restrict__ fp, int n, float px, float py, float pz) {
 #pragma clang fp contract(fast)
-    float nf = (float)n;
-    float x = px * nf - 0.5f, y = py * nf - 0.5f, z = pz * nf - 0.5f;
-    float xf = floorf(x), yf = floorf(y), zf = floorf(z);
-    float fx = x - xf, fy = y - yf, fz = z - zf;
-    int i = (int)xf, j = (int)yf, k = (int)zf;
-    int i0, i1, j0, j1, k0, k1;
+    const float nf = (float)n;
+    const float x = px * nf - 0.5f, y = py * nf - 0.5f, z = pz * nf - 0.5f;
+    const float xf = floorf(x), yf = floorf(y), zf = floorf(z);
+    const float fx = x - xf, fy = y - yf, fz = z - zf;
+    const int i = (int)xf, j = (int)yf, k = (int)zf;
+    int i0, j0, k0, k1;
     if ((n & (n - 1)) == 0) {
-        int m = n - 1;
-        i0 = i & m; i1 = (i + 1) & m;
-        j0 = j & m; j1 = (j + 1) & m;
-        k0 = k & m; k1 = (k + 1) & m;
+        const int m = n - 1;
+        i0 = i & m; j0 = j & m; k0 = k & m; k1 = (k + 1) & m;
     } else {
-        i0 = ((i % n) + n) % n; i1 = (i0 + 1) % n;
-        j0 = ((j % n) + n) % n; j1 = (j0 + 1) % n;
-        k0 = ((k % n) + n) % n; k1 = (k0 + 1) % n;
+        i0 = ((i % n) + n) % n; j0 = ((j % n) + n) % n; k0 = ((k % n) + n) % n; k1 = (k0 + 1) % n;
     }
-    const uint8_t *p00 = tex + (k0 * n + j0) * n;
-    const uint8_t *p10 = tex + (k0 * n + j1) * n;
-    const uint8_t *p01 = tex + (k1 * n + j0) * n;
-    const uint8_t *p11 = tex + (k1 * n + j1) * n;
-    float a000 = (float)p00[i0], a100 = (float)p00[i1];
-    float a010 = (float)p10[i0], a110 = (float)p10[i1];
-    float a001 = (float)p01[i0], a101 = (float)p01[i1];
-    float a011 = (float)p11[i0], a111 = (float)p11[i1];
-    float c00 = a000 + (a100 - a000) * fx;
-    float c10 = a010 + (a110 - a010) * fx;
-    float c01 = a001 + (a101 - a001) * fx;
-    float c11 = a011 + (a111 - a011) * fx;
-    float c0 = c00 + (c10 - c00) * fy;
-    float c1 = c01 + (c11 - c01) * fy;
+    const uint32_t w0 = fp[(k0 * n + j0) * n + i0];
+    const uint32_t w1 = fp[(k1 * n + j0) * n + i0];
+    const float a00 = ub0(w0), a10 = ub1(w0), a01 = ub2(w0), a11 = ub3(w0);
+    const float b00 = ub0(w1), b10 = ub1(w1), b01 = ub2(w1), b11 = ub3(w1);
+    const float c00 = a00 + (a10 - a00) * fx;
+    const float c10 = a01 + (a11 - a01) * fx;
+    const float c01 = b00 + (b10 - b00) * fx;
+    const float c11 = b01 + (b11 - b01) * fx;
+    const float c0 = c00 + (c10 - c00) * fy;
+    const float c1 = c01 + (c11 - c01) * fy;
     return (c0 + (c1 - c0) * fz) * (1.0f / 255.0f);
 }
 
-// texture(u_cloud_coverage_cubemap, d).r : LOD 0, bilinear, seamless.  `cube` holds six faces of
-// (n+2)^2 bytes: the face plus a one-texel apron copied from the neighbouring faces (corners: mean of 3).
-__device__ __forceinline__ float cube_sample(const uint8_t *__restrict__ cube, int n, float dx, float dy, float dz) {
+// texture(u_cloud_coverage_cubemap, d).r : LOD 0, bilinear, seamless.
+// Face selection and the in-face coordinates come from the hardware cube instructions (v_cubeid/sc/tc/ma_f32):
+// same table and tie-break as Vulkan (z over y over x), ma = 2 * major axis value.
+__device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, int n, float dx, float dy, float dz) {
 #pragma clang fp contract(fast)
-    float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
-    float sc, tc, ma;
-    int f;
-    if (az >= ax && az >= ay) {
-        ma = az;
-        bool pos = dz >= 0.0f;
-        f = pos ? 4 : 5;
-        sc = pos ? dx : -dx;
-        tc = -dy;
-    } else if (ay >= ax) {
-        ma = ay;
-        bool pos = dy >= 0.0f;
-        f = pos ? 2 : 3;
-        sc = dx;
-        tc = pos ? dz : -dz;
-    } else {
-        ma = ax;
-        bool pos = dx >= 0.0f;
-        f = pos ? 0 : 1;
-        sc = pos ? -dz : dz;
-        tc = -dy;
-    }
+    const float fid = __builtin_amdgcn_cubeid(dx, dy, dz);
+    const float sc = __builtin_amdgcn_cubesc(dx, dy, dz);
+    const float tc = __builtin_amdgcn_cubetc(dx, dy, dz);
+    const float ma = 0.5f * fabsf(__builtin_amdgcn_cubema(dx, dy, dz));
     // s = 0.5*(sc/ma + 1); one Newton step on the hardware reciprocal keeps the quotient within 1 ulp of IEEE
-    float r = hw_rcp(ma);
+    const float r = hw_rcp(ma);
     float qs = sc * r, qt = tc * r;
     qs = fmaf(fmaf(-qs, ma, sc), r, qs);
     qt = fmaf(fmaf(-qt, ma, tc), r, qt);
-    float nf = (float)n;
-    float x = (0.5f * (qs + 1.0f)) * nf - 0.5f;
-    float y = (0.5f * (qt + 1.0f)) * nf - 0.5f;
-    float xf = floorf(x), yf = floorf(y);
-    float fx = x - xf, fy = y - yf;
-    int i = min(max((int)xf, -1), n - 1), j = min(max((int)yf, -1), n - 1);
-    int stride = n + 2;
-    const uint8_t *p = cube + (f * stride + (j + 1)) * stride + (i + 1);
-    float t00 = (float)p[0], t10 = (float)p[1], t01 = (float)p[stride], t11 = (float)p[stride + 1];
-    float a = t00 + (t10 - t00) * fx;
-    float b = t01 + (t11 - t01) * fx;
+    const float hn = 0.5f * (float)n, off = hn - 0.5f;
+    const float x = fmaf(qs, hn, off);
+    const float y = fmaf(qt, hn, off);
+    const float xf = floorf(x), yf = floorf(y);
+    const float fx = x - xf, fy = y - yf;
+    const int i = min(max((int)xf, -1), n - 1) + 1, j = min(max((int)yf, -1), n - 1) + 1;
+    const int stride = n + 1;
+    const uint32_t w = fp[((int)fid * stride + j) * stride + i];
+    const float t00 = ub0(w), t10 = ub1(w), t01 = ub2(w), t11 = ub3(w);
+    const float a = t00 + (t10 - t00) * fx;
+    const float b = t01 + (t11 - t01) * fx;
     return (a + (b - a) * fy) * (1.0f / 255.0f);
 }
 
@@ -180,66 +189,88 @@ __device__ __forceinline__ float cube_sample(const uint8_t *__restrict__ cube, i
 //   * alpha: the reference's recurrence alpha += (1-exp(-d))*(1-alpha) is 1 - prod(exp(-d_i))
 //     = 1 - exp(-view_optical_depth); one exp after the loop replaces one per step.
 //   * light: sum(d_i * T_i * coeff) = coeff * sum(d_i * T_i).
-template <bool DIRECT>
+//   * positions are kept relative to the planet centre; 1 - clamp((r-R)/H, 0, 1) = clamp(fma(r, -1/H, 1 + R/H), 0, 1)
+//     is one v_fma with the clamp modifier.
+// LSTEPS > 0: light-step count known at compile time (fully unrolled); 0: rc.light_steps at run time.
+template <bool DIRECT, int LSTEPS>
 __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 dir, float t_begin, float step_len, float jitter) {
 #pragma clang fp contract(fast)
     const int steps = rc.view_steps;
     const float inv_h = hw_rcp(rc.atmosphere_height);
+    const float ninv_h = -inv_h;
+    const float c1 = fmaf(rc.planet_radius, inv_h, 1.0f);
     const float dens2 = rc.density * rc.density;
     const float kr = -rc.coeff[0] * LOG2E, kg = -rc.coeff[1] * LOG2E, kb = -rc.coeff[2] * LOG2E;
-    const float cx = rc.center[0], cy = rc.center[1], cz = rc.center[2];
     const float sx = rc.sun_dir[0], sy = rc.sun_dir[1], sz = rc.sun_dir[2];
     const float ratm2 = rc.atmosphere_radius * rc.atmosphere_radius;
-    const int light_steps = rc.light_steps;
-    const float inv_light_steps = hw_rcp((float)light_steps);
+    const int light_steps = LSTEPS > 0 ? LSTEPS : rc.light_steps;
+    const float inv_light_steps = LSTEPS > 0 ? 1.0f / (float)(LSTEPS > 0 ? LSTEPS : 1) : hw_rcp((float)light_steps);
+    const float half_w = 0.5f * (float)rc.lut_w, x_off = half_w - 0.5f;
+    const float lut_hf = (float)rc.lut_h, y_off = lut_hf - 0.5f;
+    const int lut_stride = rc.lut_w + 2;
 
-    float px = dir.x * t_begin, py = dir.y * t_begin, pz = dir.z * t_begin;
+    float ox = fmaf(dir.x, t_begin, -rc.center[0]);
+    float oy = fmaf(dir.y, t_begin, -rc.center[1]);
+    float oz = fmaf(dir.z, t_begin, -rc.center[2]);
     const float sdx = dir.x * step_len, sdy = dir.y * step_len, sdz = dir.z * step_len;
+    const float dstep = dens2 * step_len;
     float lr = 0.0f, lg = 0.0f, lb = 0.0f, view_od = 0.0f;
 
     for (int i = 0; i < steps; ++i) {
-        float ox = px - cx, oy = py - cy, oz = pz - cz;
-        float r2 = ox * ox + oy * oy + oz * oz;
-        float inv_r = hw_rsq(r2);
-        float r = r2 * inv_r;
-        float hr = sat((r - rc.planet_radius) * inv_h);
-        float y = 1.0f - hr;
-        float y3 = y * y * y;
-        float bdot = ox * sx + oy * sy + oz * sz;
+        const float r2 = ox * ox + oy * oy + oz * oz;
+        const float bdot = ox * sx + oy * sy + oz * sz;
+        const float inv_r = hw_rsq(r2);
+        const float r = r2 * inv_r;
+        const float y = sat(fmaf(r, ninv_h, c1));  // 1 - height_ratio
+        const float y3 = y * y * y;
 
         float sun_od;
         if (DIRECT) {
             // chord from the sample to the outer sphere along the sun direction, then a left Riemann sum
-            float hh = ratm2 - (r2 - bdot * bdot);
-            float sq = hw_sqrt(fmaxf(hh, 0.0f));
-            float x0 = -bdot - sq, x1 = -bdot + sq;
-            float ray_len = (hh < 0.0f) ? 0.0f : (x1 - fmaxf(x0, 0.0f));
-            float lstep = ray_len * inv_light_steps;
+            const float hh = ratm2 - (r2 - bdot * bdot);
+            const float sq = hw_sqrt(fmaxf(hh, 0.0f));
+            const float x0 = -bdot - sq, x1 = sq - bdot;
+            const float ray_len = (hh < 0.0f) ? 0.0f : (x1 - fmaxf(x0, 0.0f));
+            const float lstep = ray_len * inv_light_steps;
             float acc = y3;  // sample 0 sits on the view sample itself
-            float b2 = bdot + bdot;
-            for (int j = 1; j < light_steps; ++j) {
-                float s = lstep * (float)j;
-                float rr = hw_sqrt(fmaf(s, s + b2, r2));
-                float yy = 1.0f - sat((rr - rc.planet_radius) * inv_h);
-                acc = fmaf(yy * yy, yy, acc);
+            if (LSTEPS > 0) {
+                // |o + j*l*sun|^2 = r2 + j*(l*2b) + j^2*(l*l), |sun| = 1: two FMAs per sample
+                const float lb = lstep * (bdot + bdot), l2 = lstep * lstep;
+#pragma unroll
+                for (int j = 1; j < (LSTEPS > 0 ? LSTEPS : 1); ++j) {
+                    const float rr = hw_sqrt(fmaf((float)(j * j), l2, fmaf((float)j, lb, r2)));
+                    const float yy = sat(fmaf(rr, ninv_h, c1));
+                    acc = fmaf(yy * yy, yy, acc);
+                }
+            } else {
+                const float b2 = bdot + bdot;
+                float sl = lstep;
+                for (int j = 1; j < light_steps; ++j) {
+                    const float rr = hw_sqrt(fmaf(sl, sl + b2, r2));
+                    const float yy = sat(fmaf(rr, ninv_h, c1));
+                    acc = fmaf(yy * yy, yy, acc);
+                    sl += lstep;
+                }
             }
             sun_od = acc * lstep * dens2;
         } else {
-            float uvx = 0.5f + 0.5f * (bdot * inv_r);
-            sun_od = lut_sample(rc.lut, rc.lut_w, rc.lut_h, uvx, hr);
+            // uv = (0.5 + 0.5*cos, height_ratio) -> texel space
+            const float x = fmaf(bdot * inv_r, half_w, x_off);
+            const float yv = fmaf(-y, lut_hf, y_off);
+            sun_od = lut_sample_xy(rc.lut, lut_stride, x, yv);
         }
 
-        float d = y3 * dens2 * step_len;
+        const float d = y3 * dstep;
         view_od += d;
-        float od = sun_od + view_od;
+        const float od = sun_od + view_od;
         lr = fmaf(d, hw_exp2(od * kr), lr);
         lg = fmaf(d, hw_exp2(od * kg), lg);
         lb = fmaf(d, hw_exp2(od * kb), lb);
 
-        px += sdx; py += sdy; pz += sdz;
+        ox += sdx; oy += sdy; oz += sdz;
     }
 
-    float alpha = 1.0f - hw_exp2(-view_od * LOG2E);
+    const float alpha = 1.0f - hw_exp2(-view_od * LOG2E);
     float4 o;
     o.x = sat(fmaf(lr, rc.coeff[0], rc.ambient[0])) * rc.modulate[0];
     o.y = sat(fmaf(lg, rc.coeff[1], rc.ambient[1])) * rc.modulate[1];
@@ -250,50 +281,48 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
 
 // ---- clouds ----------------------------------------------------------------------------------------
 
-// get_density_full with CLOUDS_ALWAYS_LOW_QUALITY (detail = 0.5).  `r` = |pos| and `hr` = height ratio
-// come from the exact chain in the caller.
+// get_density_full with CLOUDS_ALWAYS_LOW_QUALITY (detail = 0.5).  `hr` = height ratio from the exact chain.
 __device__ __forceinline__ float cloud_density(const RenderConsts &rc, float px, float py, float pz, float hr) {
 #pragma clang fp contract(fast)
-    float t = 2.0f * hr - 1.0f;
-    float hc = fmaxf(1.0f - t * t, 0.0f);
+    const float t = 2.0f * hr - 1.0f;
+    const float hc = fmaxf(1.0f - t * t, 0.0f);
     if (!(hc > 0.0f)) return 0.0f;  // outside the layer: (..)*0*50-20 clamps to 0, skip the fetches
     float coverage = 1.0f;
     if (rc.cube != nullptr) {
-        float qx = rc.cov_rot[0] * px + rc.cov_rot[2] * pz;
-        float qz = rc.cov_rot[1] * px + rc.cov_rot[3] * pz;
+        const float qx = rc.cov_rot[0] * px + rc.cov_rot[2] * pz;
+        const float qz = rc.cov_rot[1] * px + rc.cov_rot[3] * pz;
         coverage = cube_sample(rc.cube, rc.cube_n, qx, py, qz);
     }
     coverage = coverage - 0.25f * hr + rc.coverage_bias;
-    float s = rc.shape_scale;
+    const float s = rc.shape_scale;
     float shape = mixf(0.5f, shape_sample(rc.shape, rc.shape_n, px * s, py * s, pz * s), rc.shape_factor);
     if (rc.shape_invert) shape = 1.0f - shape;
-    float density = (shape - 0.1f + mixf(-1.2f, 1.5f, coverage)) * hc;
+    const float density = (shape - 0.1f + mixf(-1.2f, 1.5f, coverage)) * hc;
     return sat(density * 50.0f - 20.0f);
 }
 
 // exact |p| and (|p| - bottom) / thickness, as a scalar fp32 evaluation would produce them
 __device__ __forceinline__ void cloud_height(const RenderConsts &rc, float px, float py, float pz, float &r, float &hr) {
-    r = ieee_sqrt(px * px + py * py + pz * pz);
-    hr = ieee_div(r - rc.clouds_bottom, rc.cloud_thickness);
+    r = exact_sqrt(px * px + py * py + pz * pz);
+    hr = exact_div_uniform(r - rc.clouds_bottom, rc.cloud_thickness, rc.inv_cloud_thickness);
 }
 
 // get_light_raymarched (cloud_funcs.gdshaderinc:104-151): 6 density taps towards the sun.
 // 1 - prod(exp(-d_i)) = 1 - exp(-sum d_i): one exp instead of six.
 __device__ __forceinline__ float light_raymarched(const RenderConsts &rc, float px, float py, float pz, float hr0,
                                                   float sx, float sy, float sz) {
-    float step_len = rc.rm_step0;
     float sum = 0.0f;
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
-        float k = (float)i * step_len;
+        const float k = rc.rm_offset[i];  // float(i) * step_len_i, step_len_i = step0 * 1.2^i  [host]
         // exact: pos0 + (i*step)*dir, unfused
-        float qx = px + k * sx, qy = py + k * sy, qz = pz + k * sz;
+        const float qx = px + k * sx, qy = py + k * sy, qz = pz + k * sz;
         float r, hr;
         cloud_height(rc, qx, qy, qz, r, hr);
-        float d = cloud_density(rc, qx, qy, qz, hr);
-        sum += d * (step_len * rc.cloud_density_scale);
-        step_len *= 1.2f;
+        const float d = cloud_density(rc, qx, qy, qz, hr);
+        sum = __builtin_fmaf(d, rc.rm_weight[i], sum);  // step_len_i * density_scale  [host]
     }
-    float alpha = 1.0f - hw_exp2(-sum * LOG2E);
+    const float alpha = 1.0f - hw_exp2(-sum * LOG2E);
     return mixf(1.0f, hr0 * 0.2f, alpha);
 }
 
@@ -308,52 +337,58 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
     float px = (rc.origin_model[0] + dir_m.x * js) + dir_m.x * t_begin;
     float py = (rc.origin_model[1] + dir_m.y * js) + dir_m.y * t_begin;
     float pz = (rc.origin_model[2] + dir_m.z * js) + dir_m.z * t_begin;
+    const float ddx = dir_m.x * step_len, ddy = dir_m.y * step_len, ddz = dir_m.z * step_len;
     const float sx = rc.sun_dir_model[0], sy = rc.sun_dir_model[1], sz = rc.sun_dir_model[2];
 
     // pow(dot(ray_dir, sun_dir), 16) is constant along the ray; dp <= 0 => 0
-    float dp = dir_m.x * sx + dir_m.y * sy + dir_m.z * sz;
+    const float dp = dir_m.x * sx + dir_m.y * sy + dir_m.z * sz;
     float p16 = 0.0f;
     if (dp > 0.0f) {
-        float p2 = dp * dp, p4 = p2 * p2, p8 = p4 * p4;
+        const float p2 = dp * dp, p4 = p2 * p2, p8 = p4 * p4;
         p16 = p8 * p8;
     }
 
     float total_transmittance = 1.0f, total_light = 0.0f, one_minus_alpha = 1.0f;
-    const float neg_scale_step_log2e = -(rc.cloud_density_scale * step_len) * LOG2E;
+    const float scale_step = rc.cloud_density_scale * step_len;
+    const float neg_scale_step_log2e = -scale_step * LOG2E;
 
     for (int i = 0; i < steps; ++i) {
         float r, hr;
         cloud_height(rc, px, py, pz, r, hr);
         {
 #pragma clang fp contract(fast)
-            float density = cloud_density(rc, px, py, pz, hr);
-            float light;
-            if (RM) {
-                light = light_raymarched(rc, px, py, pz, hr, sx, sy, sz);
-            } else {
-                light = fmaf(p16, one_minus_alpha, hr);
-            }
-            // get_planet_shadow: smoothstep(-0.3, 0.3, dot(normalize(pos), -sun_dir))
-            float sd = -(px * sx + py * sy + pz * sz) * hw_rcp(r);
-            float st = sat((sd + 0.3f) * (1.0f / 0.6f));
-            float shadow = st * st * (3.0f - 2.0f * st);
-            light *= fmaf(shadow, 0.002f - 1.0f, 1.0f);
+            const float density = cloud_density(rc, px, py, pz, hr);
+            // A zero-density sample contributes nothing: transmittance 1, light term 0, and the light value itself
+            // (6 more density taps in the raymarched variant) is never observed.
+            if (density > 0.0f) {
+                float light;
+                if (RM) {
+                    light = light_raymarched(rc, px, py, pz, hr, sx, sy, sz);
+                } else {
+                    light = fmaf(p16, one_minus_alpha, hr);
+                }
+                // get_planet_shadow: smoothstep(-0.3, 0.3, dot(normalize(pos), -sun_dir))
+                const float sd = -(px * sx + py * sy + pz * sz) * hw_rcp(r);
+                const float st = sat((sd + 0.3f) * (1.0f / 0.6f));
+                const float shadow = st * st * (3.0f - 2.0f * st);
+                light *= fmaf(shadow, 0.002f - 1.0f, 1.0f);
 
-            float transmittance = hw_exp2(density * neg_scale_step_log2e);
-            total_transmittance = fmaxf(total_transmittance * transmittance, 0.005f);
-            total_light = fmaf(light * (density * rc.cloud_density_scale) * step_len, total_transmittance, total_light);
-            one_minus_alpha *= transmittance;
+                const float transmittance = hw_exp2(density * neg_scale_step_log2e);
+                total_transmittance = fmaxf(total_transmittance * transmittance, 0.005f);
+                total_light = fmaf(light * (density * scale_step), total_transmittance, total_light);
+                one_minus_alpha *= transmittance;
+            }
         }
         // exact: pos += ray_dir * step_len
-        px = px + dir_m.x * step_len;
-        py = py + dir_m.y * step_len;
-        pz = pz + dir_m.z * step_len;
+        px = px + ddx;
+        py = py + ddy;
+        pz = pz + ddz;
     }
     return make_float2(total_light, 1.0f - one_minus_alpha);
 }
 
 // ---- atmosphere_fragment ---------------------------------------------------------------------------
-template <int FLAGS>
+template <int FLAGS, int LSTEPS>
 __global__ __launch_bounds__(TILE_W *TILE_H) void atmo_render_kernel(const RenderConsts rc) {
     constexpr bool CLOUDS = (FLAGS & KF_CLOUDS) != 0;
     constexpr bool RM = (FLAGS & KF_CLOUD_LIGHT_RM) != 0;
@@ -410,7 +445,7 @@ __global__ __launch_bounds__(TILE_W *TILE_H) void atmo_render_kernel(const Rende
     const float jitter = ieee_div((float)rc.blue[jj * 256 + ji], 255.0f);
 
     const float view_step_len = ieee_div(t_end - t_begin, (float)rc.view_steps);
-    float4 rgba = march_atmosphere<DIRECT>(rc, dir, t_begin, view_step_len, jitter);
+    float4 rgba = march_atmosphere<DIRECT, LSTEPS>(rc, dir, t_begin, view_step_len, jitter);
 
     if (CLOUDS) {
         // --- render_clouds (cloud_funcs.gdshaderinc:249-324), gates evaluated exactly -----------------
@@ -489,37 +524,77 @@ __global__ __launch_bounds__(256) void atmo_bake_kernel(const BakeConsts bc) {
         const float density = yy * yy * yy * bc.density;
         od += density * step_len * bc.density;
     }
-    bc.out[j * bc.w + i] = od;
+    // apron layout: texel (i,j) at [(j+1)*(w+2) + i+1]; edge lanes also fill the clamp-to-edge border
+    const int st = bc.w + 2;
+    float *o = bc.out + (j + 1) * st + (i + 1);
+    o[0] = od;
+    const bool el = (i == 0), er = (i == bc.w - 1), et = (j == 0), eb = (j == bc.h - 1);
+    if (el) o[-1] = od;
+    if (er) o[1] = od;
+    if (et) o[-st] = od;
+    if (eb) o[st] = od;
+    if (el && et) o[-st - 1] = od;
+    if (er && et) o[-st + 1] = od;
+    if (el && eb) o[st - 1] = od;
+    if (er && eb) o[st + 1] = od;
+}
+
+// ---- self-test of the exact helpers against the compiler's IEEE expansions ---------------------------------
+// For `count` consecutive float bit patterns starting at first_bits: counts exact_sqrt(x) != sqrtf(x) and
+// exact_div_uniform(x, c, RN(1/c)) != x / c.
+__global__ __launch_bounds__(256) void atmo_selftest_kernel(uint32_t first_bits, uint32_t count, float c, float rc,
+                                                            unsigned int *mismatch /* [2] */) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    unsigned int bad_sqrt = 0, bad_div = 0;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
+        const float x = __int_as_float((int)(first_bits + k));
+        if (__float_as_int(exact_sqrt(x)) != __float_as_int(ieee_sqrt(x))) ++bad_sqrt;
+        if (__float_as_int(exact_div_uniform(x, c, rc)) != __float_as_int(ieee_div(x, c))) ++bad_div;
+    }
+    if (bad_sqrt) atomicAdd(&mismatch[0], bad_sqrt);
+    if (bad_div) atomicAdd(&mismatch[1], bad_div);
+}
+
+hipError_t launch_selftest(uint32_t first_bits, uint32_t count, float c, float rc, unsigned int *mismatch_dev, hipStream_t stream) {
+    hipLaunchKernelGGL(atmo_selftest_kernel, dim3(2048), dim3(256), 0, stream, first_bits, count, c, rc, mismatch_dev);
+    return hipGetLastError();
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------
-template <int FLAGS>
+template <int FLAGS, int LSTEPS>
 static hipError_t launch_t(const RenderConsts &rc, hipStream_t stream) {
     dim3 grid((rc.x1 - rc.x0 + TILE_W - 1) / TILE_W, (rc.y1 - rc.y0 + TILE_H - 1) / TILE_H);
-    hipLaunchKernelGGL(atmo_render_kernel<FLAGS>, grid, dim3(TILE_W * TILE_H), 0, stream, rc);
+    hipLaunchKernelGGL((atmo_render_kernel<FLAGS, LSTEPS>), grid, dim3(TILE_W * TILE_H), 0, stream, rc);
     return hipGetLastError();
+}
+
+// direct light mode: 8 light steps (BASELINE's "32 view x 8 light") has an unrolled instantiation
+template <int FLAGS>
+static hipError_t launch_direct(const RenderConsts &rc, hipStream_t stream) {
+    return rc.light_steps == 8 ? launch_t<FLAGS, 8>(rc, stream) : launch_t<FLAGS, 0>(rc, stream);
 }
 
 hipError_t launch_render(int flags, const RenderConsts &rc, hipStream_t stream) {
     switch (flags) {
-    case 0: return launch_t<0>(rc, stream);
-    case KF_LIGHT_DIRECT: return launch_t<KF_LIGHT_DIRECT>(rc, stream);
-    case KF_CLOUDS: return launch_t<KF_CLOUDS>(rc, stream);
-    case KF_CLOUDS | KF_LIGHT_DIRECT: return launch_t<KF_CLOUDS | KF_LIGHT_DIRECT>(rc, stream);
-    case KF_CLOUDS | KF_CLOUD_LIGHT_RM: return launch_t<KF_CLOUDS | KF_CLOUD_LIGHT_RM>(rc, stream);
-    case KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT: return launch_t<KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT>(rc, stream);
+    case 0: return launch_t<0, 0>(rc, stream);
+    case KF_LIGHT_DIRECT: return launch_direct<KF_LIGHT_DIRECT>(rc, stream);
+    case KF_CLOUDS: return launch_t<KF_CLOUDS, 0>(rc, stream);
+    case KF_CLOUDS | KF_LIGHT_DIRECT: return launch_direct<KF_CLOUDS | KF_LIGHT_DIRECT>(rc, stream);
+    case KF_CLOUDS | KF_CLOUD_LIGHT_RM: return launch_t<KF_CLOUDS | KF_CLOUD_LIGHT_RM, 0>(rc, stream);
+    case KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT: return launch_direct<KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT>(rc, stream);
     default: return hipErrorInvalidValue;
     }
 }
 
-const char *render_kernel_name(int flags) {
+const char *render_kernel_name(int flags, int light_steps) {
+    const bool u8 = (flags & KF_LIGHT_DIRECT) && light_steps == 8;
     switch (flags) {
-    case 0: return "atmo_render_kernel<0>";
-    case KF_LIGHT_DIRECT: return "atmo_render_kernel<4>";
-    case KF_CLOUDS: return "atmo_render_kernel<1>";
-    case KF_CLOUDS | KF_LIGHT_DIRECT: return "atmo_render_kernel<5>";
-    case KF_CLOUDS | KF_CLOUD_LIGHT_RM: return "atmo_render_kernel<3>";
-    case KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT: return "atmo_render_kernel<7>";
+    case 0: return "atmo_render_kernel<0, 0>";
+    case KF_LIGHT_DIRECT: return u8 ? "atmo_render_kernel<4, 8>" : "atmo_render_kernel<4, 0>";
+    case KF_CLOUDS: return "atmo_render_kernel<1, 0>";
+    case KF_CLOUDS | KF_LIGHT_DIRECT: return u8 ? "atmo_render_kernel<5, 8>" : "atmo_render_kernel<5, 0>";
+    case KF_CLOUDS | KF_CLOUD_LIGHT_RM: return "atmo_render_kernel<3, 0>";
+    case KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT: return u8 ? "atmo_render_kernel<7, 8>" : "atmo_render_kernel<7, 0>";
     default: return "?";
     }
 }

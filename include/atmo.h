@@ -140,6 +140,12 @@ int atmo_render(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev
 int atmo_set_timing(AtmoContext *ctx, int enable);
 int atmo_get_timing(AtmoContext *ctx, int *launches, double *total_ms);
 
+/* Diagnostics (no reference counterpart): on the device, compares the kernels' cheap correctly-rounded sqrt and
+ * divide-by-uniform helpers with the compiler's IEEE expansions over `count` consecutive float bit patterns
+ * starting at `first_bits`, and reports the number of mismatches (must be 0). */
+int atmo_selftest_exact_math(AtmoContext *ctx, uint32_t first_bits, uint32_t count, float divisor,
+                             uint32_t *sqrt_mismatches, uint32_t *div_mismatches);
+
 /* Name of the kernel the current configuration launches (for matching rocprofv3 kernel traces). */
 const char *atmo_kernel_name(AtmoContext *ctx);
 

@@ -251,7 +251,7 @@ def test_host_mirror_behaviour():
     lut_b = node.read_optical_depth()
     assert not np.array_equal(lut_a, lut_b)
     node.custom_shader = load_shader("res://addons/zylann.atmosphere/shaders/planet_atmosphere_clouds_high_m.gdshader")
-    assert node.kernel_name == "atmo_render_kernel<3>"
+    assert node.kernel_name == "atmo_render_kernel<3, 0>"
     assert "shader_params/u_cloud_blend" in [p["name"] for p in node.get_property_list()]
     assert np.array_equal(node.read_optical_depth(), lut_b)  # parameters survived the shader switch
     with pytest.raises(NotImplementedError):
@@ -275,3 +275,25 @@ def test_gpu_matches_committed_golden(pose):
         want = g[f"rgba_{config_name}_{pose}"]
         assert int((np.abs(got).sum(axis=-1) > 0).sum()) == int(g[f"hits_{config_name}_{pose}"])
         assert np.abs(got - want).max() <= TOL, config_name
+
+
+def test_exact_math_selftest():
+    """The cloud chain's cheap correctly-rounded sqrt / divide-by-uniform agree with IEEE for every float32
+    significand at the exponents the chain sees (|pos|^2 ~ 2^13..2^14, heights ~ 2^-6..2^7) and beyond."""
+    from godot_atmosphere_shader_amd import _native as N
+
+    lib = N.load()
+    ctx = C.c_void_p()
+    assert lib.atmo_create(0, N.VARIANT_NO_CLOUDS, 0, 0, N.LIGHT_LUT, 0, C.byref(ctx)) == N.ATMO_OK
+    top, bot = np.float32(100.0) + np.float32(0.6) * np.float32(8.0), np.float32(100.0) + np.float32(0.2) * np.float32(8.0)
+    divisors = [float(top - bot), 0.08, 7.0, float(np.float32(1.9999999)), 1.0 / 3.0]
+    for e in list(range(100, 150)):  # biased exponents 100..149: 2^-27 .. 2^22, all 2^23 significands each
+        bs, bd = C.c_uint32(0), C.c_uint32(0)
+        rc = lib.atmo_selftest_exact_math(ctx, e << 23, 1 << 23, divisors[e % len(divisors)], C.byref(bs), C.byref(bd))
+        assert rc == N.ATMO_OK
+        assert bs.value == 0 and bd.value == 0, (e, bs.value, bd.value)
+    # negative dividends (heights below the cloud bottom)
+    bs, bd = C.c_uint32(0), C.c_uint32(0)
+    assert lib.atmo_selftest_exact_math(ctx, (1 << 31) | (127 << 23), 1 << 23, divisors[0], C.byref(bs), C.byref(bd)) == N.ATMO_OK
+    assert bd.value == 0
+    lib.atmo_destroy(ctx)
