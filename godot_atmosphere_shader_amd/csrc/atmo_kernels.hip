@@ -29,6 +29,14 @@ namespace atmo {
 
 constexpr int TILE_W = 16;
 constexpr int TILE_H = 16;
+// Pixels of one 64-lane wave inside the 16x16 workgroup tile: WAVE_W x (64 / WAVE_W).  16x4 keeps a wave's
+// float4 stores in 256-byte runs; 8x8 halves that but makes a wave's rays more coherent (tools/ab_build.sh).
+#ifndef ATMO_WAVE_W
+#define ATMO_WAVE_W 16
+#endif
+constexpr int WAVE_W = ATMO_WAVE_W;
+constexpr int WAVE_H = 64 / WAVE_W;
+static_assert(WAVE_W == 16 || WAVE_W == 8 || WAVE_W == 32, "wave tile");
 constexpr float LOG2E = 1.44269504088896340736f;
 
 // ---- hardware transcendental units (approximate, ~1 ulp) ---------------------------------------
@@ -394,7 +402,10 @@ __global__ __launch_bounds__(TILE_W *TILE_H) void atmo_render_kernel(const Rende
     constexpr bool RM = (FLAGS & KF_CLOUD_LIGHT_RM) != 0;
     constexpr bool DIRECT = (FLAGS & KF_LIGHT_DIRECT) != 0;
 
-    const int lx = threadIdx.x % TILE_W, ly = threadIdx.x / TILE_W;
+    const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    constexpr int WAVES_X = TILE_W / (WAVE_W > TILE_W ? TILE_W : WAVE_W);
+    const int lx = (wave % WAVES_X) * WAVE_W + lane % WAVE_W;
+    const int ly = (wave / WAVES_X) * WAVE_H + lane / WAVE_W;
     const int px = rc.x0 + blockIdx.x * TILE_W + lx;
     const int py = rc.y0 + blockIdx.y * TILE_H + ly;
     if (px >= rc.x1 || py >= rc.y1) return;

@@ -501,6 +501,18 @@ class PlanetAtmosphere:
         self.render_raw(frame, depth.data_ptr(), out.data_ptr(), stream)
         return out
 
+    def prepare_frame(self, camera, time: float = 0.0, rect=None) -> N.AtmoFrame:
+        """The native per-frame argument block for `render_prepared` (build once per camera pose)."""
+        return _to_native_frame(self.make_frame(camera, time, rect))
+
+    def render_prepared(self, native_frame: N.AtmoFrame, depth_ptr: int, out_ptr: int, stream: int = 0):
+        """Enqueue one draw with a frame from `prepare_frame` on raw device addresses: the per-step host cost is
+        one ctypes call (what a render loop that re-draws an unchanged camera would do)."""
+        self._bake_if_needed(stream)
+        rc = self._lib.atmo_render(self._ctx, C.byref(native_frame), C.c_void_p(depth_ptr), C.c_void_p(out_ptr),
+                                   C.c_void_p(stream or 0))
+        N.check(self._ctx, rc)
+
     def render_raw(self, frame: dict, depth_ptr: int, out_ptr: int, stream: int = 0):
         """`render` on raw device addresses (what a non-torch host would call)."""
         self._bake_if_needed(stream)
