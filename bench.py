@@ -72,6 +72,8 @@ WORKLOADS = {
     "clouds": ("clouds", "planet_atmosphere_clouds: 8 view, 32 cloud steps"),
     "clouds_high": ("clouds_high", "planet_atmosphere_clouds_high: 8 view, 64 cloud steps, NoiseCubemap coverage"),
     "clouds_high_rm": ("clouds_high_rm", "planet_atmosphere_clouds_high_rm: 8 view, 64 cloud x 6 light steps"),
+    "v1_no_clouds": ("v1_no_clouds", "planet_atmosphere_v1_no_clouds (ATMOSPHERE_LITE): 16 view steps"),
+    "v1_clouds_high": ("v1_clouds_high", "planet_atmosphere_v1_clouds_high (ATMOSPHERE_LITE): 16 view, 64 cloud steps"),
 }
 
 
@@ -306,7 +308,9 @@ def main():
                 node2.close()
             result["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
-            lut = None if "direct" in config_name else node.read_optical_depth()
+            from common import CONFIGS
+            ocfg = CONFIGS[config_name][1]
+            lut = node.read_optical_depth() if not (ocfg.get("lite") or ocfg.get("light_steps")) else None
             result["cpu_baseline"] = cpu_baseline(config_name, params, textures, cam, depth_np, lut)
         print(json.dumps(result), flush=True)
     node.close()

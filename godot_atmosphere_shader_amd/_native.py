@@ -11,6 +11,7 @@ from .build import LIB_PATH
 
 ATMO_OK, ATMO_E_NAME, ATMO_E_ARG, ATMO_E_STATE, ATMO_E_HIP, ATMO_E_NO_DEVICE = range(6)
 VARIANT_NO_CLOUDS, VARIANT_CLOUDS, VARIANT_CLOUDS_HIGH, VARIANT_CLOUDS_HIGH_RM = range(4)
+VARIANT_V1_NO_CLOUDS, VARIANT_V1_CLOUDS, VARIANT_V1_CLOUDS_HIGH = 4, 5, 6
 LIGHT_LUT, LIGHT_DIRECT = 0, 1
 TEX_2D_R32F, TEX_2D_R8, TEX_3D_R8, TEX_CUBE_R8 = range(4)
 MEM_HOST, MEM_DEVICE = 0, 1

@@ -45,6 +45,12 @@ struct Params {
     float u_cloud_shape_factor = 0.8f;                       // :13
     float u_cloud_shape_scale = 1.0f;                        // :14
     float u_cloud_coverage_rotation[4] = {1, 0, 0, 1};       // :16
+    // atmosphere_funcs_v1.gdshaderinc:8-12 (`source_color` defaults, already linear; alpha unused by the shader)
+    float u_day_color0[4] = {0.21404114f, 0.60382734f, 1.0f, 1.0f};
+    float u_day_color1[4] = {0.21404114f, 0.60382734f, 1.0f, 1.0f};
+    float u_night_color0[4] = {0.03310477f, 0.13286832f, 0.60382734f, 1.0f};
+    float u_night_color1[4] = {0.03310477f, 0.13286832f, 0.60382734f, 1.0f};
+    float u_day_night_transition_scale = 2.0f;
 };
 
 #define PD(field, n) {#field, n, offsetof(Params, field)}
@@ -55,6 +61,8 @@ const ParamDesc kParams[] = {
     PD(u_cloud_density_scale, 1), PD(u_cloud_bottom, 1), PD(u_cloud_top, 1), PD(u_cloud_blend, 1),
     PD(u_world_to_model_matrix, 16), PD(u_cloud_shape_invert, 1), PD(u_cloud_coverage_bias, 1),
     PD(u_cloud_shape_factor, 1), PD(u_cloud_shape_scale, 1), PD(u_cloud_coverage_rotation, 4),
+    PD(u_day_color0, 4), PD(u_day_color1, 4), PD(u_night_color0, 4), PD(u_night_color1, 4),
+    PD(u_day_night_transition_scale, 1),
 };
 #undef PD
 
@@ -266,6 +274,11 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
     }
     rc.view_steps = ctx->view_steps;
     rc.light_steps = ctx->light_steps;
+    for (int i = 0; i < 3; ++i) {
+        rc.day0[i] = p.u_day_color0[i]; rc.day1[i] = p.u_day_color1[i];
+        rc.night0[i] = p.u_night_color0[i]; rc.night1[i] = p.u_night_color1[i];
+    }
+    rc.day_night_transition_scale = p.u_day_night_transition_scale;
 
     // clouds (cloud_funcs.gdshaderinc:260-261, 285-294, 186-206, 108-115)
     rc.clouds_bottom = p.u_planet_radius + p.u_cloud_bottom * p.u_atmosphere_height;
@@ -350,7 +363,7 @@ int atmo_create(int device, int variant, int view_steps, int cloud_steps, int li
                 AtmoContext **out) {
     if (!out) return fail(nullptr, ATMO_E_ARG, "atmo_create: out is null");
     *out = nullptr;
-    if (variant < ATMO_VARIANT_NO_CLOUDS || variant > ATMO_VARIANT_CLOUDS_HIGH_RM)
+    if (variant < ATMO_VARIANT_NO_CLOUDS || variant > ATMO_VARIANT_V1_CLOUDS_HIGH)
         return fail(nullptr, ATMO_E_ARG, "atmo_create: unknown variant");
     if (light_mode != ATMO_LIGHT_LUT && light_mode != ATMO_LIGHT_DIRECT)
         return fail(nullptr, ATMO_E_ARG, "atmo_create: unknown light mode");
@@ -375,14 +388,16 @@ int atmo_create(int device, int variant, int view_steps, int cloud_steps, int li
     if (!ctx) return fail(nullptr, ATMO_E_ARG, "atmo_create: out of host memory");
     ctx->device = device;
     ctx->variant = variant;
-    ctx->view_steps = view_steps > 0 ? view_steps : 8;  // shaders/planet_atmosphere_*.gdshader:4-6
-    static const int shipped_cloud_steps[4] = {0, 32, 64, 64};
-    ctx->cloud_steps = (variant == ATMO_VARIANT_NO_CLOUDS) ? 0 : (cloud_steps > 0 ? cloud_steps : shipped_cloud_steps[variant]);
-    ctx->light_steps = (light_mode == ATMO_LIGHT_DIRECT) ? light_steps : 0;
+    const bool lite = variant >= ATMO_VARIANT_V1_NO_CLOUDS;
+    static const int shipped_cloud_steps[7] = {0, 32, 64, 64, 0, 32, 64};  // shaders/planet_atmosphere_*.gdshader:4-7
+    ctx->view_steps = view_steps > 0 ? view_steps : (lite ? 16 : 8);
+    ctx->cloud_steps = shipped_cloud_steps[variant] == 0 ? 0 : (cloud_steps > 0 ? cloud_steps : shipped_cloud_steps[variant]);
+    ctx->light_steps = (light_mode == ATMO_LIGHT_DIRECT && !lite) ? light_steps : 0;
     ctx->flags = 0;
-    if (variant != ATMO_VARIANT_NO_CLOUDS) ctx->flags |= atmo::KF_CLOUDS;
+    if (ctx->cloud_steps > 0) ctx->flags |= atmo::KF_CLOUDS;
     if (variant == ATMO_VARIANT_CLOUDS_HIGH_RM) ctx->flags |= atmo::KF_CLOUD_LIGHT_RM;
-    if (light_mode == ATMO_LIGHT_DIRECT) ctx->flags |= atmo::KF_LIGHT_DIRECT;
+    if (light_mode == ATMO_LIGHT_DIRECT && !lite) ctx->flags |= atmo::KF_LIGHT_DIRECT;
+    if (lite) ctx->flags |= atmo::KF_LITE;  // the v1 atmosphere reads no optical-depth LUT and has no light march
 
     // u_blue_noise_texture starts all-zero (jitter 0), like an unset sampler
     int rc = dev_alloc(ctx, ctx->blue, 256 * 256);
@@ -557,7 +572,7 @@ int atmo_render(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev
     if (frame->x0 == frame->x1 || frame->y0 == frame->y1) return ATMO_OK;  // empty rect: nothing to shade
     if (!depth_dev || !rgba_dev) return fail(ctx, ATMO_E_ARG, "atmo_render: null device pointer");
     if ((reinterpret_cast<uintptr_t>(rgba_dev) & 15u) != 0) return fail(ctx, ATMO_E_ARG, "atmo_render: rgba_dev must be 16-byte aligned");
-    if (!(ctx->flags & atmo::KF_LIGHT_DIRECT) && !ctx->lut.ptr)
+    if (!(ctx->flags & (atmo::KF_LIGHT_DIRECT | atmo::KF_LITE)) && !ctx->lut.ptr)
         return fail(ctx, ATMO_E_STATE, "atmo_render: u_optical_depth_texture not set (call atmo_bake_optical_depth or atmo_set_texture)");
     if ((ctx->flags & atmo::KF_CLOUDS) && !ctx->shape.ptr)
         return fail(ctx, ATMO_E_STATE, "atmo_render: u_cloud_shape_texture not set");

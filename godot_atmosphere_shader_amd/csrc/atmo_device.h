@@ -30,6 +30,9 @@ struct RenderConsts {
     float ambient[3], modulate[3];
     int32_t view_steps;
     int32_t light_steps;     // direct light mode only
+    // --- compute_atmosphere, v1 "lite" (shaders/include/atmosphere_funcs_v1.gdshaderinc:8-12,48-63)
+    float day0[3], day1[3], night0[3], night1[3];
+    float day_night_transition_scale;
     // --- render_clouds / raymarch_cloud (shaders/include/cloud_funcs.gdshaderinc:175-324)
     float clouds_bottom, clouds_top;  // [host] R + u_cloud_{bottom,top} * H   clouds:260-261
     float cloud_thickness;            // [host] top - bottom
@@ -65,7 +68,7 @@ struct BakeConsts {
 };
 
 // kernel launchers (atmo_kernels.hip)
-enum KernelFlags : int { KF_CLOUDS = 1, KF_CLOUD_LIGHT_RM = 2, KF_LIGHT_DIRECT = 4 };
+enum KernelFlags : int { KF_CLOUDS = 1, KF_CLOUD_LIGHT_RM = 2, KF_LIGHT_DIRECT = 4, KF_LITE = 8 };
 
 hipError_t launch_render(int flags, const RenderConsts &rc, hipStream_t stream);
 hipError_t launch_bake(const BakeConsts &bc, hipStream_t stream);

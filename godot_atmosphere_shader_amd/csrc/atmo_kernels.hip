@@ -18,6 +18,7 @@
 //   include/util.gdshaderinc:20-40                      ray_sphere               -> SphereHit / hit_radius
 //   include/atmosphere_funcs_v2.gdshaderinc:14-29       get_baked_optical_depth  -> lut_sample
 //   include/atmosphere_funcs_v2.gdshaderinc:32-101      compute_atmosphere_v2    -> march_atmosphere
+//   include/atmosphere_funcs_v1.gdshaderinc:15-63       get_atmo_factor, compute_atmosphere -> march_atmosphere_v1
 //   include/cloud_funcs.gdshaderinc:31-68               get_density_full         -> cloud_density
 //   include/cloud_funcs.gdshaderinc:78-167              get_light*               -> inside march_clouds
 //   include/cloud_funcs.gdshaderinc:175-247             raymarch_cloud           -> march_clouds
@@ -178,9 +179,10 @@ __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, in
     float qs = sc * r, qt = tc * r;
     qs = fmaf(fmaf(-qs, ma, sc), r, qs);
     qt = fmaf(fmaf(-qt, ma, tc), r, qt);
-    const float hn = 0.5f * (float)n, off = hn - 0.5f;
-    const float x = fmaf(qs, hn, off);
-    const float y = fmaf(qt, hn, off);
+    // (0.5*(q + 1))*n - 0.5 with the reference's roundings: q + 1 rounds, the scalings are exact for power-of-two n
+    const float hn = 0.5f * (float)n;
+    const float x = fmaf(qs + 1.0f, hn, -0.5f);
+    const float y = fmaf(qt + 1.0f, hn, -0.5f);
     const float xf = floorf(x), yf = floorf(y);
     const float fx = x - xf, fy = y - yf;
     const int i = min(max((int)xf, -1), n - 1) + 1, j = min(max((int)yf, -1), n - 1) + 1;
@@ -284,6 +286,44 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
     o.y = sat(fmaf(lg, rc.coeff[1], rc.ambient[1])) * rc.modulate[1];
     o.z = sat(fmaf(lb, rc.coeff[2], rc.ambient[2])) * rc.modulate[2];
     o.w = clampf(fmaf(jitter, 0.02f, alpha), 0.0f, 0.99f);
+    return o;
+}
+
+// ---- compute_atmosphere, v1 "lite" (shaders/include/atmosphere_funcs_v1.gdshaderinc:15-63) ----------------
+// Faked 4-colour model: no LUT, no exp.  factor = prod(1 - density*step), light = mean(clamp(1.2*cos + 0.5)^2).
+__device__ __forceinline__ float4 march_atmosphere_v1(const RenderConsts &rc, V3 dir, float t_begin, float t_end) {
+#pragma clang fp contract(fast)
+    const int steps = rc.view_steps;
+    const float inv_steps = 1.0f / (float)steps;
+    const float step_len = (t_end - t_begin) * inv_steps;
+    const float inv_h = hw_rcp(rc.atmosphere_height);
+    const float ninv_h = -inv_h;
+    const float c1 = fmaf(rc.planet_radius, inv_h, 1.0f);
+    const float sx = rc.sun_dir[0], sy = rc.sun_dir[1], sz = rc.sun_dir[2];
+    float ox = fmaf(dir.x, t_begin, -rc.center[0]);
+    float oy = fmaf(dir.y, t_begin, -rc.center[1]);
+    float oz = fmaf(dir.z, t_begin, -rc.center[2]);
+    const float sdx = dir.x * step_len, sdy = dir.y * step_len, sdz = dir.z * step_len;
+    const float nds = -rc.density * step_len;
+    float factor = 1.0f, light_sum = 0.0f;
+    for (int i = 0; i < steps; ++i) {
+        const float r2 = ox * ox + oy * oy + oz * oz;
+        const float inv_r = hw_rsq(r2);
+        const float y = sat(fmaf(r2 * inv_r, ninv_h, c1));
+        const float cosang = (ox * sx + oy * sy + oz * sz) * inv_r;
+        const float l = sat(fmaf(1.2f, cosang, 0.5f));
+        light_sum = fmaf(l, l, light_sum);
+        factor *= fmaf(y * y * y, nds, 1.0f);
+        ox += sdx; oy += sdy; oz += sdz;
+    }
+    const float light_factor = light_sum * inv_steps;
+    const float atmo_factor = 1.0f - factor;
+    const float day_factor = sat(light_factor * rc.day_night_transition_scale);
+    float4 o;
+    o.x = mixf(mixf(rc.night0[0], rc.night1[0], atmo_factor), mixf(rc.day0[0], rc.day1[0], atmo_factor), day_factor);
+    o.y = mixf(mixf(rc.night0[1], rc.night1[1], atmo_factor), mixf(rc.day0[1], rc.day1[1], atmo_factor), day_factor);
+    o.z = mixf(mixf(rc.night0[2], rc.night1[2], atmo_factor), mixf(rc.day0[2], rc.day1[2], atmo_factor), day_factor);
+    o.w = sat(atmo_factor);
     return o;
 }
 
@@ -401,6 +441,7 @@ __global__ __launch_bounds__(TILE_W *TILE_H) void atmo_render_kernel(const Rende
     constexpr bool CLOUDS = (FLAGS & KF_CLOUDS) != 0;
     constexpr bool RM = (FLAGS & KF_CLOUD_LIGHT_RM) != 0;
     constexpr bool DIRECT = (FLAGS & KF_LIGHT_DIRECT) != 0;
+    constexpr bool LITE = (FLAGS & KF_LITE) != 0;
 
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
     constexpr int WAVES_X = TILE_W / (WAVE_W > TILE_W ? TILE_W : WAVE_W);
@@ -455,8 +496,13 @@ __global__ __launch_bounds__(TILE_W *TILE_H) void atmo_render_kernel(const Rende
     const int ji = ((int)jx) & 0xff, jj = ((int)jy) & 0xff;
     const float jitter = ieee_div((float)rc.blue[jj * 256 + ji], 255.0f);
 
-    const float view_step_len = ieee_div(t_end - t_begin, (float)rc.view_steps);
-    float4 rgba = march_atmosphere<DIRECT, LSTEPS>(rc, dir, t_begin, view_step_len, jitter);
+    float4 rgba;
+    if (LITE) {
+        rgba = march_atmosphere_v1(rc, dir, t_begin, t_end);  // main:172-175
+    } else {
+        const float view_step_len = ieee_div(t_end - t_begin, (float)rc.view_steps);
+        rgba = march_atmosphere<DIRECT, LSTEPS>(rc, dir, t_begin, view_step_len, jitter);
+    }
 
     if (CLOUDS) {
         // --- render_clouds (cloud_funcs.gdshaderinc:249-324), gates evaluated exactly -----------------
@@ -593,6 +639,8 @@ hipError_t launch_render(int flags, const RenderConsts &rc, hipStream_t stream) 
     case KF_CLOUDS | KF_LIGHT_DIRECT: return launch_direct<KF_CLOUDS | KF_LIGHT_DIRECT>(rc, stream);
     case KF_CLOUDS | KF_CLOUD_LIGHT_RM: return launch_t<KF_CLOUDS | KF_CLOUD_LIGHT_RM, 0>(rc, stream);
     case KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT: return launch_direct<KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT>(rc, stream);
+    case KF_LITE: return launch_t<KF_LITE, 0>(rc, stream);
+    case KF_LITE | KF_CLOUDS: return launch_t<KF_LITE | KF_CLOUDS, 0>(rc, stream);
     default: return hipErrorInvalidValue;
     }
 }
@@ -606,6 +654,8 @@ const char *render_kernel_name(int flags, int light_steps) {
     case KF_CLOUDS | KF_LIGHT_DIRECT: return u8 ? "atmo_render_kernel<5, 8>" : "atmo_render_kernel<5, 0>";
     case KF_CLOUDS | KF_CLOUD_LIGHT_RM: return "atmo_render_kernel<3, 0>";
     case KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT: return u8 ? "atmo_render_kernel<7, 8>" : "atmo_render_kernel<7, 0>";
+    case KF_LITE: return "atmo_render_kernel<8, 0>";
+    case KF_LITE | KF_CLOUDS: return "atmo_render_kernel<9, 0>";
     default: return "?";
     }
 }

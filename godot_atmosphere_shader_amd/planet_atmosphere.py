@@ -43,6 +43,11 @@ _V2_UNIFORMS = [
     "u_scattering_strength", "u_scattering_wavelengths", "u_atmosphere_modulate", "u_atmosphere_ambient_color",
     "u_clip_mode", "u_sphere_depth_factor", "u_blue_noise_texture",
 ]
+_V1_UNIFORMS = [
+    "u_planet_radius", "u_atmosphere_height", "u_sun_position", "u_density", "u_day_color0", "u_day_color1",
+    "u_night_color0", "u_night_color1", "u_day_night_transition_scale", "u_clip_mode", "u_sphere_depth_factor",
+    "u_blue_noise_texture",
+]
 _CLOUD_UNIFORMS = [
     "u_cloud_density_scale", "u_cloud_bottom", "u_cloud_top", "u_cloud_blend", "u_world_to_model_matrix",
     "u_cloud_shape_texture", "u_cloud_shape_invert", "u_cloud_coverage_bias", "u_cloud_shape_factor",
@@ -57,6 +62,10 @@ SHADER_DEFAULTS = {
     "u_clip_mode": False, "u_sphere_depth_factor": 0.0, "u_cloud_density_scale": 50.0, "u_cloud_bottom": 0.2,
     "u_cloud_top": 0.5, "u_cloud_blend": 0.5, "u_cloud_shape_invert": 0.0, "u_cloud_coverage_bias": 0.0,
     "u_cloud_shape_factor": 0.8, "u_cloud_shape_scale": 1.0,
+    # atmosphere_funcs_v1.gdshaderinc:8-12 (sRGB values as written in the shader; converted to linear on upload)
+    "u_day_color0": (0.5, 0.8, 1.0, 1.0), "u_day_color1": (0.5, 0.8, 1.0, 1.0),
+    "u_night_color0": (0.2, 0.4, 0.8, 1.0), "u_night_color1": (0.2, 0.4, 0.8, 1.0),
+    "u_day_night_transition_scale": 2.0,
 }
 
 _FLOAT_COUNTS = {
@@ -65,6 +74,7 @@ _FLOAT_COUNTS = {
     "u_sphere_depth_factor": 1, "u_cloud_density_scale": 1, "u_cloud_bottom": 1, "u_cloud_top": 1, "u_cloud_blend": 1,
     "u_world_to_model_matrix": 16, "u_cloud_shape_invert": 1, "u_cloud_coverage_bias": 1, "u_cloud_shape_factor": 1,
     "u_cloud_shape_scale": 1, "u_cloud_coverage_rotation": 4,
+    "u_day_color0": 4, "u_day_color1": 4, "u_night_color0": 4, "u_night_color1": 4, "u_day_night_transition_scale": 1,
 }
 _TEXTURES = {
     "u_optical_depth_texture": N.TEX_2D_R32F, "u_blue_noise_texture": N.TEX_2D_R8,
@@ -76,16 +86,17 @@ class Shader:
     """Stands for one of the reference's .gdshader variant files: a set of #defines
     (shaders/planet_atmosphere_*.gdshader:4-7)."""
 
-    def __init__(self, name, variant, view_steps, cloud_steps, cloud_light_rm):
+    def __init__(self, name, variant, view_steps, cloud_steps, cloud_light_rm, lite=False):
         self.name = name
         self.variant = variant
+        self.lite = lite                      # ATMOSPHERE_LITE
         self.view_steps = view_steps          # ATMOSPHERE_RAYMARCH_STEPS
         self.cloud_steps = cloud_steps        # CLOUDS_MAX_RAYMARCH_STEPS (0: CLOUDS_ENABLED undefined)
         self.cloud_light_rm = cloud_light_rm  # CLOUDS_RAYMARCHED_LIGHTING
         self.resource_path = _SHADER_DIR + name + ".gdshader"
 
     def get_shader_uniform_list(self):
-        names = list(_V2_UNIFORMS) + (list(_CLOUD_UNIFORMS) if self.cloud_steps else [])
+        names = list(_V1_UNIFORMS if self.lite else _V2_UNIFORMS) + (list(_CLOUD_UNIFORMS) if self.cloud_steps else [])
         return [{"name": n} for n in names]
 
     def __repr__(self):
@@ -97,6 +108,9 @@ SHADERS = {
     "planet_atmosphere_clouds": Shader("planet_atmosphere_clouds", N.VARIANT_CLOUDS, 8, 32, False),
     "planet_atmosphere_clouds_high": Shader("planet_atmosphere_clouds_high", N.VARIANT_CLOUDS_HIGH, 8, 64, False),
     "planet_atmosphere_clouds_high_rm": Shader("planet_atmosphere_clouds_high_rm", N.VARIANT_CLOUDS_HIGH_RM, 8, 64, True),
+    "planet_atmosphere_v1_no_clouds": Shader("planet_atmosphere_v1_no_clouds", N.VARIANT_V1_NO_CLOUDS, 16, 0, False, lite=True),
+    "planet_atmosphere_v1_clouds": Shader("planet_atmosphere_v1_clouds", N.VARIANT_V1_CLOUDS, 16, 32, False, lite=True),
+    "planet_atmosphere_v1_clouds_high": Shader("planet_atmosphere_v1_clouds_high", N.VARIANT_V1_CLOUDS_HIGH, 16, 64, False, lite=True),
 }
 DefaultShader = SHADERS["planet_atmosphere_no_clouds"]  # planet_atmosphere.gd:13-14
 
@@ -109,8 +123,6 @@ def load_shader(path: str) -> Shader:
         name = name[: -len(".gdshader")]
     if name == "planet_atmosphere_clouds_high_m":
         name = "planet_atmosphere_clouds_high_rm"
-    if name.startswith("planet_atmosphere_v1"):
-        raise NotImplementedError("the v1 'lite' atmosphere variants are out of scope (SURVEY.md 8f)")
     if name not in SHADERS:
         raise FileNotFoundError(path)
     return SHADERS[name]

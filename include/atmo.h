@@ -41,7 +41,12 @@ enum AtmoVariant {
     ATMO_VARIANT_NO_CLOUDS = 0,      /* ATMOSPHERE_RAYMARCH_STEPS 8 */
     ATMO_VARIANT_CLOUDS = 1,         /* + CLOUDS_ENABLED, CLOUDS_MAX_RAYMARCH_STEPS 32 */
     ATMO_VARIANT_CLOUDS_HIGH = 2,    /* + CLOUDS_MAX_RAYMARCH_STEPS 64 */
-    ATMO_VARIANT_CLOUDS_HIGH_RM = 3  /* + CLOUDS_RAYMARCHED_LIGHTING (README's "clouds_high_m") */
+    ATMO_VARIANT_CLOUDS_HIGH_RM = 3, /* + CLOUDS_RAYMARCHED_LIGHTING (README's "clouds_high_m") */
+    /* ATMOSPHERE_LITE variants, shaders/planet_atmosphere_v1_{no_clouds,clouds,clouds_high}.gdshader:4-7:
+     * compute_atmosphere of shaders/include/atmosphere_funcs_v1.gdshaderinc, ATMOSPHERE_RAYMARCH_STEPS 16, no LUT */
+    ATMO_VARIANT_V1_NO_CLOUDS = 4,
+    ATMO_VARIANT_V1_CLOUDS = 5,      /* CLOUDS_MAX_RAYMARCH_STEPS 32 */
+    ATMO_VARIANT_V1_CLOUDS_HIGH = 6  /* CLOUDS_MAX_RAYMARCH_STEPS 64 */
 };
 
 /* How the sun-ray optical depth of compute_atmosphere_v2 is obtained. */
@@ -86,7 +91,7 @@ int atmo_device_count(void);
 /*
  * Replaces: assigning a shader variant to the node (`custom_shader`, planet_atmosphere.gd:118-141) and
  * its compile-time #defines (shaders/planet_atmosphere_*.gdshader:4-7).
- * view_steps = ATMOSPHERE_RAYMARCH_STEPS (0 => the variant's shipped value, 8); cloud_steps =
+ * view_steps = ATMOSPHERE_RAYMARCH_STEPS (0 => the variant's shipped value: 8, or 16 for the v1 variants); cloud_steps =
  * CLOUDS_MAX_RAYMARCH_STEPS (0 => shipped 32/64); light_mode/light_steps: see AtmoLightMode
  * (light_steps ignored for ATMO_LIGHT_LUT).  Uniforms start at the shader defaults
  * (SURVEY.md 8b); u_blue_noise_texture starts all-zero, u_cloud_coverage_cubemap unset (= 1.0).

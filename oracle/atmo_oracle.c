@@ -116,6 +116,8 @@ typedef struct {
     REAL world_to_model[16];
     REAL cloud_shape_invert, cloud_coverage_bias, cloud_shape_factor, cloud_shape_scale;
     REAL cov_rot[4];
+    vec3 day0, day1, night0, night1;
+    REAL day_night_transition_scale;
     OracleTextures tex;
     OracleConfig cfg;
 } Ctx;
@@ -140,6 +142,11 @@ static void ctx_init(Ctx *c, const OracleParams *p, const OracleTextures *t, con
     c->cloud_shape_factor = p->u_cloud_shape_factor;
     c->cloud_shape_scale = p->u_cloud_shape_scale;
     for (int i = 0; i < 4; ++i) c->cov_rot[i] = p->u_cloud_coverage_rotation[i];
+    c->day0 = v3(p->u_day_color0[0], p->u_day_color0[1], p->u_day_color0[2]);
+    c->day1 = v3(p->u_day_color1[0], p->u_day_color1[1], p->u_day_color1[2]);
+    c->night0 = v3(p->u_night_color0[0], p->u_night_color0[1], p->u_night_color0[2]);
+    c->night1 = v3(p->u_night_color1[0], p->u_night_color1[1], p->u_night_color1[2]);
+    c->day_night_transition_scale = p->u_day_night_transition_scale;
     if (t) c->tex = *t;
     if (cfg) c->cfg = *cfg;
 }
@@ -368,6 +375,51 @@ static vec4 compute_atmosphere_v2(const Ctx *c, vec3 ray_origin, vec3 ray_dir, v
     return r;
 }
 
+/* ---- atmosphere (v1 "lite") ------------------------------------------------------------- */
+
+/* ref: I/atmosphere_funcs_v1.gdshaderinc:15-45 */
+static REAL get_atmo_factor(const Ctx *c, vec3 ray_origin, vec3 ray_dir, vec3 planet_center,
+                            REAL t_begin, REAL t_end, vec3 sun_dir, REAL *light_factor) {
+    const int steps = c->cfg.view_steps;
+    REAL inv_steps = K(1.0) / K(steps);
+    REAL step_len = (t_end - t_begin) * inv_steps;
+    vec3 stepv = v3_scale(ray_dir, step_len);
+    vec3 pos = v3_add(ray_origin, v3_scale(ray_dir, t_begin));
+    REAL factor = K(1.0);
+    REAL light_sum = K(0.0);
+    for (int i = 0; i < steps; ++i) {
+        vec3 rel = v3_sub(pos, planet_center);
+        REAL d = v3_length(rel);
+        vec3 up = v3(rel.x / d, rel.y / d, rel.z / d);
+        REAL density = get_atmosphere_density(c, d);
+        REAL light = r_clamp(K(1.2) * v3_dot(sun_dir, up) + K(0.5), K(0.0), K(1.0));
+        light = light * light;
+        light_sum += light * inv_steps;
+        factor *= (K(1.0) - density * step_len);
+        pos = v3_add(pos, stepv);
+    }
+    *light_factor = light_sum;
+    return K(1.0) - factor;
+}
+
+/* ref: I/atmosphere_funcs_v1.gdshaderinc:48-63 */
+static vec4 compute_atmosphere_v1(const Ctx *c, vec3 ray_origin, vec3 ray_dir, vec3 planet_center,
+                                  REAL t_begin, REAL t_end, vec3 sun_dir) {
+    REAL light_factor;
+    REAL atmo_factor = get_atmo_factor(c, ray_origin, ray_dir, planet_center, t_begin, t_end, sun_dir, &light_factor);
+    vec3 night_col = v3(r_mix(c->night0.x, c->night1.x, atmo_factor), r_mix(c->night0.y, c->night1.y, atmo_factor),
+                        r_mix(c->night0.z, c->night1.z, atmo_factor));
+    vec3 day_col = v3(r_mix(c->day0.x, c->day1.x, atmo_factor), r_mix(c->day0.y, c->day1.y, atmo_factor),
+                      r_mix(c->day0.z, c->day1.z, atmo_factor));
+    REAL day_factor = r_clamp(light_factor * c->day_night_transition_scale, K(0.0), K(1.0));
+    vec4 r;
+    r.x = r_mix(night_col.x, day_col.x, day_factor);
+    r.y = r_mix(night_col.y, day_col.y, day_factor);
+    r.z = r_mix(night_col.z, day_col.z, day_factor);
+    r.w = r_clamp(atmo_factor, K(0.0), K(1.0));
+    return r;
+}
+
 /* ---- clouds ---------------------------------------------------------------------------- */
 
 /* ref: I/cloud_funcs.gdshaderinc:18-23 */
@@ -562,7 +614,10 @@ static int atmosphere_fragment(const Ctx *c, const OracleFrame *f, const REAL *i
         int ji = ((int)jx) & 0xff, jj = ((int)jy) & 0xff;
         REAL jitter = K(c->tex.blue_noise[jj * 256 + ji]) / K(255.0);
 
-        vec4 atmosphere = compute_atmosphere_v2(c, ray_origin, ray_dir, center, t_begin, t_end, sun_dir, jitter);
+        /* main:172-179 */
+        vec4 atmosphere = c->cfg.lite
+            ? compute_atmosphere_v1(c, ray_origin, ray_dir, center, t_begin, t_end, sun_dir)
+            : compute_atmosphere_v2(c, ray_origin, ray_dir, center, t_begin, t_end, sun_dir, jitter);
         vec3 albedo = v3(atmosphere.x, atmosphere.y, atmosphere.z);
         REAL alpha = atmosphere.w;
 
@@ -711,7 +766,7 @@ REAL SFX(oracle_sample_cube)(const OracleTextures *t, const REAL *d) { return sa
 int SFX(oracle_cube_texel)(const OracleTextures *t, int f, int i, int j) { return cube_texel(t, f, i, j); }
 
 REAL SFX(oracle_get_cloud_density)(const OracleParams *p, const OracleTextures *t, const REAL *pos_model) {
-    OracleConfig cfg = {8, 8, 0, 0};
+    OracleConfig cfg = {8, 8, 0, 0, 0};
     Ctx c;
     ctx_init(&c, p, t, &cfg);
     CloudSettings cs;

@@ -18,6 +18,7 @@
  *   include/atmosphere_common.gdshaderinc:12-24          get_atmosphere_density
  *   include/atmosphere_funcs_v2.gdshaderinc:14-29,32-101 get_baked_optical_depth, compute_atmosphere_v2
  *   include/cloud_funcs.gdshaderinc:18-324               clouds
+ *   include/atmosphere_funcs_v1.gdshaderinc:15-63        get_atmo_factor, compute_atmosphere (ATMOSPHERE_LITE variants)
  *   optical_depth.gdshader:17-68                         LUT bake
  *
  * The same source builds twice: REAL=float (liboracle_f32.so, symbols *_f32; gcc -O2
@@ -66,6 +67,12 @@ typedef struct OracleParams {
     float u_cloud_shape_factor;         /* :13 */
     float u_cloud_shape_scale;          /* :14 */
     float u_cloud_coverage_rotation[4]; /* :16, mat2 column-major */
+    /* v1 "lite" atmosphere (atmosphere_funcs_v1.gdshaderinc:8-12), linear colours, rgb only (alpha unused) */
+    float u_day_color0[4];
+    float u_day_color1[4];
+    float u_night_color0[4];
+    float u_night_color1[4];
+    float u_day_night_transition_scale;
 } OracleParams;
 
 typedef struct OracleTextures {
@@ -94,6 +101,7 @@ typedef struct OracleConfig {
     int32_t cloud_steps;     /* CLOUDS_MAX_RAYMARCH_STEPS; 0 => CLOUDS_ENABLED not defined */
     int32_t cloud_light_rm;  /* 1 => CLOUDS_RAYMARCHED_LIGHTING */
     int32_t light_steps;     /* 0 => baked LUT (reference); >0 => inline sun-ray march of that many steps */
+    int32_t lite;            /* 1 => ATMOSPHERE_LITE: compute_atmosphere of atmosphere_funcs_v1.gdshaderinc */
 } OracleConfig;
 
 #ifdef __cplusplus

@@ -37,6 +37,11 @@ class OracleParams(C.Structure):
         ("u_cloud_shape_factor", C.c_float),
         ("u_cloud_shape_scale", C.c_float),
         ("u_cloud_coverage_rotation", C.c_float * 4),
+        ("u_day_color0", C.c_float * 4),
+        ("u_day_color1", C.c_float * 4),
+        ("u_night_color0", C.c_float * 4),
+        ("u_night_color1", C.c_float * 4),
+        ("u_day_night_transition_scale", C.c_float),
     ]
 
 
@@ -71,6 +76,7 @@ class OracleConfig(C.Structure):
         ("cloud_steps", C.c_int32),
         ("cloud_light_rm", C.c_int32),
         ("light_steps", C.c_int32),
+        ("lite", C.c_int32),
     ]
 
 
@@ -94,6 +100,12 @@ PARAM_DEFAULTS = {
     "u_cloud_shape_factor": 0.8,
     "u_cloud_shape_scale": 1.0,
     "u_cloud_coverage_rotation": (1, 0, 0, 1),
+    # atmosphere_funcs_v1.gdshaderinc:8-12; `source_color` defaults converted sRGB -> linear
+    "u_day_color0": (0.21404114, 0.60382734, 1.0, 1.0),
+    "u_day_color1": (0.21404114, 0.60382734, 1.0, 1.0),
+    "u_night_color0": (0.03310477, 0.13286832, 0.60382734, 1.0),
+    "u_night_color1": (0.03310477, 0.13286832, 0.60382734, 1.0),
+    "u_day_night_transition_scale": 2.0,
 }
 
 
@@ -227,7 +239,8 @@ class Oracle:
     @staticmethod
     def make_config(config: dict) -> OracleConfig:
         return OracleConfig(int(config["view_steps"]), int(config.get("cloud_steps", 0)),
-                            int(config.get("cloud_light_rm", 0)), int(config.get("light_steps", 0)))
+                            int(config.get("cloud_light_rm", 0)), int(config.get("light_steps", 0)),
+                            int(config.get("lite", 0)))
 
     # ---- entry points --------------------------------------------------------------------
     def render(self, params: dict, textures: dict, config: dict, frame: dict, depth: np.ndarray,

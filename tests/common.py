@@ -21,6 +21,10 @@ CONFIGS = {
     "clouds": ("planet_atmosphere_clouds", dict(view_steps=8, cloud_steps=32), {}),
     "clouds_high": ("planet_atmosphere_clouds_high", dict(view_steps=8, cloud_steps=64), {}),
     "clouds_high_rm": ("planet_atmosphere_clouds_high_rm", dict(view_steps=8, cloud_steps=64, cloud_light_rm=1), {}),
+    # ATMOSPHERE_LITE variants
+    "v1_no_clouds": ("planet_atmosphere_v1_no_clouds", dict(view_steps=16, lite=1), {}),
+    "v1_clouds": ("planet_atmosphere_v1_clouds", dict(view_steps=16, lite=1, cloud_steps=32), {}),
+    "v1_clouds_high": ("planet_atmosphere_v1_clouds_high", dict(view_steps=16, lite=1, cloud_steps=64), {}),
 }
 
 _tex_cache = {}

@@ -141,7 +141,8 @@ def test_shader_resources_and_transform2d():
     assert load_shader("res://addons/zylann.atmosphere/shaders/planet_atmosphere_clouds_high_m.gdshader") is SHADERS["planet_atmosphere_clouds_high_rm"]
     assert load_shader("planet_atmosphere_clouds").cloud_steps == 32
     assert load_shader("planet_atmosphere_clouds_high.gdshader").cloud_steps == 64
-    assert all(s.view_steps == 8 for s in SHADERS.values())
+    assert all(s.view_steps == (16 if s.lite else 8) for s in SHADERS.values())
+    assert len(SHADERS) == 7  # the reference's seven spatial shader variants
     with pytest.raises(FileNotFoundError):
         load_shader("nope.gdshader")
     names = [u["name"] for u in SHADERS["planet_atmosphere_no_clouds"].get_shader_uniform_list()]

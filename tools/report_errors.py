@@ -19,7 +19,8 @@ for name in CONFIGS:
         depth = S.depth_ground_sphere(cam)
         node = make_node(name, tex, params)
         got = node.render(cam, torch.from_numpy(depth).cuda()).cpu().numpy()
-        lut = None if "direct" in name else node.read_optical_depth()
+        cfg = CONFIGS[name][1]
+        lut = node.read_optical_depth() if not (cfg.get("lite") or cfg.get("light_steps")) else None
         node.close()
         want, _ = o.render(params, dict(tex, optical_depth=lut), CONFIGS[name][1], demo_frame(cam), depth, nthreads=os.cpu_count())
         e = float(np.abs(got - want).max())
