@@ -329,6 +329,10 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
     rc.cube = (const uint32_t *)ctx->cube.ptr; rc.cube_n = ctx->cube_n;
     rc.depth = depth;
     rc.out = (float4 *)rgba;
+    rc.out_pitch = f->x1 - f->x0;
+    rc.out_x0 = f->x0;
+    rc.out_y0 = f->y0;
+    rc.composite = 0;
 }
 
 void drain_timing(AtmoContext *ctx) {
@@ -561,7 +565,17 @@ int atmo_read_optical_depth(AtmoContext *ctx, float *lut_host, uint8_t *rgba8_ho
     return ATMO_OK;
 }
 
+static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, void *stream, bool composite);
+
 int atmo_render(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, void *stream) {
+    return render_impl(ctx, frame, depth_dev, rgba_dev, stream, false);
+}
+
+int atmo_render_composite(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *scene_rgba_dev, void *stream) {
+    return render_impl(ctx, frame, depth_dev, scene_rgba_dev, stream, true);
+}
+
+static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, void *stream, bool composite) {
     if (!ctx) return ATMO_E_ARG;
     if (!frame) return fail(ctx, ATMO_E_ARG, "atmo_render: null frame");
     if (frame->viewport_w < 1 || frame->viewport_h < 1 || frame->viewport_w > 65536 || frame->viewport_h > 65536)
@@ -580,6 +594,12 @@ int atmo_render(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev
 
     atmo::RenderConsts rc;
     fill_consts(ctx, frame, depth_dev, rgba_dev, rc);
+    if (composite) {  // the target is the whole scene colour buffer, addressed by absolute pixel
+        rc.out_pitch = frame->viewport_w;
+        rc.out_x0 = 0;
+        rc.out_y0 = 0;
+        rc.composite = 1;
+    }
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->timing) {

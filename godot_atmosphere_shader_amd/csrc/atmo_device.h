@@ -58,7 +58,10 @@ struct RenderConsts {
     int32_t cube_n;
     // --- per-pixel streams
     const float *depth;      // h rows of w
-    float4 *out;             // (y1-y0) rows of (x1-x0)
+    float4 *out;             // plain: (y1-y0) rows of (x1-x0); composite: the h x w scene colour buffer, blended in place
+    int32_t out_pitch;       // pixels per output row
+    int32_t out_x0, out_y0;  // viewport pixel that maps to out[0]
+    int32_t composite;       // 1 => straight-alpha "mix" blend over the existing contents, discarded pixels untouched
 };
 
 struct BakeConsts {

@@ -450,7 +450,7 @@ __global__ __launch_bounds__(TILE_W *TILE_H) void atmo_render_kernel(const Rende
     const int px = rc.x0 + blockIdx.x * TILE_W + lx;
     const int py = rc.y0 + blockIdx.y * TILE_H + ly;
     if (px >= rc.x1 || py >= rc.y1) return;
-    float4 *out = rc.out + (size_t)(py - rc.y0) * (size_t)(rc.x1 - rc.x0) + (px - rc.x0);
+    float4 *out = rc.out + (size_t)(py - rc.out_y0) * (size_t)rc.out_pitch + (px - rc.out_x0);
 
     // --- exact prologue (main:128-169) -----------------------------------------------------------
     const float nonlinear_depth = rc.depth[(size_t)py * rc.w + px];
@@ -480,8 +480,8 @@ __global__ __launch_bounds__(TILE_W *TILE_H) void atmo_render_kernel(const Rende
     const SphereHit sh = sphere_setup(center, dir);
     const float2 rs_atmo = hit_radius(sh, rc.atmosphere_radius);
 
-    if (rs_atmo.x == rs_atmo.y) {  // discard
-        *out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (rs_atmo.x == rs_atmo.y) {  // discard: nothing reaches the blend stage
+        if (!rc.composite) *out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         return;
     }
     const float t_begin = fmaxf(rs_atmo.x, 0.0f);
@@ -543,7 +543,21 @@ __global__ __launch_bounds__(TILE_W *TILE_H) void atmo_render_kernel(const Rende
             }
         }
     }
-    *out = rgba;
+    if (rc.composite) {
+        // What the engine's blend stage does with ALBEDO/ALPHA of an unshaded, blend_mix spatial material:
+        // colour: SRC_ALPHA, ONE_MINUS_SRC_ALPHA; alpha: ONE, ONE_MINUS_SRC_ALPHA.
+#pragma clang fp contract(off)
+        const float4 dst = *out;
+        const float ia = 1.0f - rgba.w;
+        float4 o;
+        o.x = rgba.x * rgba.w + dst.x * ia;
+        o.y = rgba.y * rgba.w + dst.y * ia;
+        o.z = rgba.z * rgba.w + dst.z * ia;
+        o.w = rgba.w + dst.w * ia;
+        *out = o;
+    } else {
+        *out = rgba;
+    }
 }
 
 // ---- LUT bake (optical_depth.gdshader:17-31,45-68): exact evaluation, one texel per lane ---------------

@@ -525,6 +525,30 @@ class PlanetAtmosphere:
                                    C.c_void_p(stream or 0))
         N.check(self._ctx, rc)
 
+    def render_composite(self, camera, depth, scene_rgba, rect=None, stream=None, time: float = 0.0):
+        """The draw including the renderer's blend stage: shades `rect` and alpha-blends the result over
+        `scene_rgba` (CUDA float32 (H, W, 4), the scene colour buffer) in place, as Godot's blend_mix does with
+        ALBEDO/ALPHA; discarded fragments leave the scene untouched.  Returns `scene_rgba`."""
+        import torch
+
+        frame = self.make_frame(camera, time, rect)
+        if not (isinstance(scene_rgba, torch.Tensor) and scene_rgba.is_cuda and scene_rgba.dtype == torch.float32
+                and scene_rgba.is_contiguous() and tuple(scene_rgba.shape) == (camera.height, camera.width, 4)):
+            raise ValueError("scene_rgba must be a contiguous CUDA float32 tensor of shape (viewport_h, viewport_w, 4)")
+        if not (isinstance(depth, torch.Tensor) and depth.is_cuda and depth.dtype == torch.float32 and depth.is_contiguous()
+                and tuple(depth.shape) == (camera.height, camera.width)):
+            raise TypeError("depth must be a contiguous CUDA float32 tensor of shape (viewport_h, viewport_w)")
+        if stream is None:
+            stream = torch.cuda.current_stream(depth.device).cuda_stream
+        elif hasattr(stream, "cuda_stream"):
+            stream = stream.cuda_stream
+        self._bake_if_needed(stream)
+        nf = _to_native_frame(frame)
+        rc = self._lib.atmo_render_composite(self._ctx, C.byref(nf), C.c_void_p(depth.data_ptr()),
+                                             C.c_void_p(scene_rgba.data_ptr()), C.c_void_p(stream or 0))
+        N.check(self._ctx, rc)
+        return scene_rgba
+
     def render_raw(self, frame: dict, depth_ptr: int, out_ptr: int, stream: int = 0):
         """`render` on raw device addresses (what a non-torch host would call)."""
         self._bake_if_needed(stream)

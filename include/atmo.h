@@ -140,6 +140,14 @@ int atmo_read_optical_depth(AtmoContext *ctx, float *lut_host, uint8_t *rgba8_ho
  */
 int atmo_render(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, void *stream);
 
+/*
+ * Replaces: the same draw *including the renderer's blend stage* (SURVEY.md 8f row 4): shades the rect and blends
+ * ALBEDO/ALPHA over the scene colour buffer in place, as Godot does for an unshaded `blend_mix` spatial material
+ * (colour: SRC_ALPHA, ONE_MINUS_SRC_ALPHA; alpha: ONE, ONE_MINUS_SRC_ALPHA).  Discarded fragments leave the
+ * buffer untouched.  scene_rgba_dev: viewport_h rows of viewport_w RGBA float4 (the whole viewport, whatever the rect).
+ */
+int atmo_render_composite(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *scene_rgba_dev, void *stream);
+
 /* Average device time of the last `atmo_render` kernels measured with HIP events on their own stream:
  * enable with atmo_set_timing(ctx, 1); atmo_get_timing returns count and total milliseconds since enabling. */
 int atmo_set_timing(AtmoContext *ctx, int enable);

@@ -403,3 +403,39 @@ def test_user_supplied_lut_of_other_size(oracle32):
     node.close()
     want, _ = oracle32.render(params, dict(tex, optical_depth=lut), CONFIGS["no_clouds_32_lut"][1], demo_frame(cam), depth, nthreads=4)
     assert np.abs(got - want).max() <= TOL
+
+
+def test_render_composite_blends_in_place(oracle32):
+    """SURVEY.md 8f row 4: the draw with the blend stage.  scene' = src.rgb*a + scene.rgb*(1-a), a' = a + scene.a*(1-a);
+    discarded pixels and pixels outside the rect keep the scene colour bit for bit."""
+    w, h = 192, 108
+    tex, params = demo_textures(), demo_params()
+    cam = S.Camera.from_pose(w, h, "P_space")
+    depth_np = S.depth_ground_sphere(cam)
+    rng = np.random.default_rng(9)
+    scene_np = rng.random((h, w, 4), dtype=np.float32)
+    node = make_node("clouds_high", tex, params)
+    depth = torch.from_numpy(depth_np).cuda()
+    src = node.render(cam, depth).cpu().numpy()
+    rect = (16, 8, 180, 100)
+    scene = torch.from_numpy(scene_np.copy()).cuda()
+    node.render_composite(cam, depth, scene, rect=rect)
+    torch.cuda.synchronize()
+    got = scene.cpu().numpy()
+    node.close()
+    a = src[..., 3:4]
+    want = scene_np.copy()
+    blended = np.concatenate([src[..., :3] * a + scene_np[..., :3] * (np.float32(1) - a),
+                              a + scene_np[..., 3:4] * (np.float32(1) - a)], axis=-1).astype(np.float32)
+    x0, y0, x1, y1 = rect
+    inside = np.zeros((h, w), dtype=bool)
+    inside[y0:y1, x0:x1] = True
+    hit = np.abs(src).sum(axis=-1) > 0
+    sel = inside & hit
+    want[sel] = blended[sel]
+    assert np.array_equal(got[~sel], scene_np[~sel])     # untouched: outside the rect or discarded
+    assert np.array_equal(got[sel], want[sel])           # the blend itself is unfused fp32: exact
+    # and the source it blended is the oracle's frame within tolerance
+    lut = oracle32.bake_optical_depth(100.0, 8.0, 0.5)
+    ref, _ = _oracle_render(oracle32, "clouds_high", params, tex, cam, depth_np, lut)
+    assert np.abs(src - ref).max() <= TOL
