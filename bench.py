@@ -135,6 +135,32 @@ def cpu_baseline(config_name, params, textures, cam, depth_np, lut):
             "hit_fraction": hits / rays}
 
 
+def bench_noise_cubemap(resolution=256):
+    """the NoiseCubemap generator (noise_cubemap.gd:101-140, 'really slow' on the CPU) as a kernel,
+    demo-scene settings (resolution 256, scale (100,200,100)); CPU figure = the oracle's scalar loop on one core."""
+    from godot_atmosphere_shader_amd import NoiseCubemap, SeededValueNoise
+    from oracle.oracle import Oracle
+
+    nz = SeededValueNoise(seed=11, frequency=0.03, fractal_octaves=4, fractal_gain=0.5)
+    res = NoiseCubemap(noise=nz, resolution=resolution, scale=(100.0, 200.0, 100.0))
+    times = []
+    for _ in range(20):
+        res._request_update()
+        res.process_deferred()
+        times.append(res.last_kernel_ms)
+    res.close()
+    texels = 6 * resolution * resolution
+    k_ms = sorted(times)[len(times) // 2]
+    o = Oracle("f32")
+    t0 = time.perf_counter()
+    o.noise_cubemap(resolution, 11, 0.03, 4, 0.5, (100.0, 200.0, 100.0))
+    cpu_s = time.perf_counter() - t0
+    return {"workload": f"NoiseCubemap 6x{resolution}^2 L8, 4 octaves", "kernel_ms_median": k_ms,
+            "Mtexels/s": texels / (k_ms * 1e-3) / 1e6,
+            "algorithmic_bytes": texels, "hbm_GBps": texels / (k_ms * 1e-3) / 1e9,
+            "cpu_oracle_1core_Mtexels/s": texels / cpu_s / 1e6}
+
+
 def time_workload(torch, node, cam, depth, steps, warmup, out=None):
     """Single-GPU timed loop; returns (seconds, kernel launches, kernel ms from HIP events)."""
     if out is None:
@@ -300,6 +326,9 @@ def main():
         if world == 1 and args.also:
             extra = {}
             for name in [x for x in args.also.split(",") if x]:
+                if name == "noise_cubemap":
+                    extra[name] = bench_noise_cubemap()
+                    continue
                 cfg2, desc2 = WORKLOADS[name]
                 node2 = make_node(cfg2, textures, params, device=local_rank)
                 dt2, n2, ms2, _ = time_workload(torch, node2, cam, depth, max(10, args.steps // 4), max(3, args.warmup // 4))

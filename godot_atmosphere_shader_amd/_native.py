@@ -20,7 +20,7 @@ ABI_VERSION = 1
 # every symbol include/atmo.h declares
 EXPORTED_SYMBOLS = (
     "atmo_abi_version", "atmo_device_count", "atmo_create", "atmo_destroy", "atmo_set_param_f32",
-    "atmo_get_param_f32", "atmo_set_texture", "atmo_bake_optical_depth", "atmo_read_optical_depth",
+    "atmo_get_param_f32", "atmo_set_texture", "atmo_generate_noise_cubemap", "atmo_bake_optical_depth", "atmo_read_optical_depth",
     "atmo_render", "atmo_render_composite", "atmo_set_timing", "atmo_get_timing", "atmo_selftest_exact_math", "atmo_kernel_name",
     "atmo_last_error_string",
 )
@@ -77,6 +77,7 @@ def load() -> C.CDLL:
         "atmo_set_param_f32": (ip, [vp, cp, fp, ip]),
         "atmo_get_param_f32": (ip, [vp, cp, fp, ip]),
         "atmo_set_texture": (ip, [vp, cp, ip, ip, ip, ip, vp, ip]),
+        "atmo_generate_noise_cubemap": (ip, [vp, ip, C.c_uint32, C.c_float, ip, C.c_float, fp, ip, vp, C.POINTER(C.c_double)]),
         "atmo_bake_optical_depth": (ip, [vp, vp]),
         "atmo_read_optical_depth": (ip, [vp, vp, vp, ip, vp]),
         "atmo_render": (ip, [vp, C.POINTER(AtmoFrame), vp, vp, vp]),

@@ -519,6 +519,43 @@ int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h,
     return fail(ctx, ATMO_E_NAME, std::string("atmo_set_texture: unknown texture uniform '") + name + "'");
 }
 
+int atmo_generate_noise_cubemap(AtmoContext *ctx, int resolution, uint32_t seed, float frequency, int octaves, float gain,
+                                const float *scale3, int bind, uint8_t *faces_host, double *kernel_ms) {
+    if (!ctx) return ATMO_E_ARG;
+    if (resolution < 1 || resolution > 4096) return fail(ctx, ATMO_E_ARG, "atmo_generate_noise_cubemap: resolution must be 1..4096 (noise_cubemap.gd:29)");
+    if (octaves < 1 || octaves > 16 || !scale3) return fail(ctx, ATMO_E_ARG, "atmo_generate_noise_cubemap: bad octaves / scale");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)6 * resolution * resolution;
+    uint8_t *dev = nullptr;
+    HIP_TRY(ctx, hipMalloc(&dev, bytes));
+    atmo::NoiseCubemapConsts nc;
+    nc.resolution = resolution; nc.seed = seed; nc.frequency = frequency; nc.gain = gain; nc.octaves = octaves;
+    nc.scale[0] = scale3[0]; nc.scale[1] = scale3[1]; nc.scale[2] = scale3[2];
+    nc.out = dev;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+    if (e == hipSuccess) e = atmo::launch_noise_cubemap(nc, nullptr);
+    if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    int rc = ATMO_OK;
+    if (e != hipSuccess) rc = hip_fail(ctx, e, "atmo_generate_noise_cubemap");
+    if (rc == ATMO_OK && kernel_ms) *kernel_ms = ms;
+    if (rc == ATMO_OK && faces_host) {
+        e = hipMemcpy(faces_host, dev, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(ctx, e, "hipMemcpy");
+    }
+    if (rc == ATMO_OK && bind)
+        rc = atmo_set_texture(ctx, "u_cloud_coverage_cubemap", ATMO_TEX_CUBE_R8, resolution, resolution, 6, dev, ATMO_MEM_DEVICE);
+    (void)hipFree(dev);
+    return rc;
+}
+
 int atmo_bake_optical_depth(AtmoContext *ctx, void *stream) {
     if (!ctx) return ATMO_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -70,11 +70,21 @@ struct BakeConsts {
     float *out;  // (h+2) x (w+2), apron written by the edge texels' lanes
 };
 
+struct NoiseCubemapConsts {
+    int32_t resolution;
+    uint32_t seed;
+    float frequency, gain;
+    int32_t octaves;
+    float scale[3];
+    uint8_t *out;  // 6 faces of resolution^2 bytes
+};
+
 // kernel launchers (atmo_kernels.hip)
 enum KernelFlags : int { KF_CLOUDS = 1, KF_CLOUD_LIGHT_RM = 2, KF_LIGHT_DIRECT = 4, KF_LITE = 8 };
 
 hipError_t launch_render(int flags, const RenderConsts &rc, hipStream_t stream);
 hipError_t launch_bake(const BakeConsts &bc, hipStream_t stream);
+hipError_t launch_noise_cubemap(const NoiseCubemapConsts &nc, hipStream_t stream);
 const char *render_kernel_name(int flags, int light_steps);
 hipError_t launch_selftest(uint32_t first_bits, uint32_t count, float c, float rc, unsigned int *mismatch_dev, hipStream_t stream);
 

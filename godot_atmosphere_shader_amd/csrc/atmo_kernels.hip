@@ -610,6 +610,74 @@ __global__ __launch_bounds__(256) void atmo_bake_kernel(const BakeConsts bc) {
     if (er && eb) o[st + 1] = od;
 }
 
+// ---- NoiseCubemap generator (noise_cubemap.gd:101-140) -------------------------------------------------------
+// One lane per texel, exact fp32 arithmetic (unfused, IEEE sqrt/divide) so the bytes equal a scalar evaluation.
+// The noise itself is this build's seeded value noise (the reference calls Godot's FastNoiseLite, engine code).
+__device__ __forceinline__ uint32_t nz_hash(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float nz_lattice(int ix, int iy, int iz, uint32_t seed) {
+    const uint32_t h = ((uint32_t)ix * 0x9E3779B1u) ^ ((uint32_t)iy * 0x85EBCA77u) ^ ((uint32_t)iz * 0xC2B2AE3Du) ^ seed;
+    return (float)(nz_hash(h) >> 8) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ float nz_value(float px, float py, float pz, uint32_t seed) {
+    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    const float tx = px - fx, ty = py - fy, tz = pz - fz;
+    const float wx = tx * tx * (3.0f - 2.0f * tx), wy = ty * ty * (3.0f - 2.0f * ty), wz = tz * tz * (3.0f - 2.0f * tz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz, x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+    const float c00 = nz_lattice(x0, y0, z0, seed) * (1.0f - wx) + nz_lattice(x1, y0, z0, seed) * wx;
+    const float c10 = nz_lattice(x0, y1, z0, seed) * (1.0f - wx) + nz_lattice(x1, y1, z0, seed) * wx;
+    const float c01 = nz_lattice(x0, y0, z1, seed) * (1.0f - wx) + nz_lattice(x1, y0, z1, seed) * wx;
+    const float c11 = nz_lattice(x0, y1, z1, seed) * (1.0f - wx) + nz_lattice(x1, y1, z1, seed) * wx;
+    const float c0 = c00 * (1.0f - wy) + c10 * wy;
+    const float c1 = c01 * (1.0f - wy) + c11 * wy;
+    return c0 * (1.0f - wz) + c1 * wz;
+}
+
+__global__ __launch_bounds__(256) void atmo_noise_cubemap_kernel(const NoiseCubemapConsts nc) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int side = blockIdx.z;
+    const int res = nc.resolution;
+    if (x >= res || y >= res) return;
+    // noise_cubemap.gd:110-113: pos2d, +X direction
+    const float half = 0.5f * (float)res;
+    const float p2x = ieee_div((float)x + 0.5f, half) - 1.0f;
+    const float p2y = ieee_div((float)(res - y - 1) + 0.5f, half) - 1.0f;
+    float vx = 1.0f, vy = p2y, vz = -p2x;
+    const float len = ieee_sqrt(vx * vx + vy * vy + vz * vz);
+    vx = ieee_div(vx, len); vy = ieee_div(vy, len); vz = ieee_div(vz, len);
+    float ox, oy, oz;  // :116-128
+    switch (side) {
+    case 0: ox = vx;  oy = vy;  oz = vz;  break;
+    case 1: ox = -vx; oy = vy;  oz = -vz; break;
+    case 2: ox = -vz; oy = vx;  oz = -vy; break;
+    case 3: ox = -vz; oy = -vx; oz = vy;  break;
+    case 4: ox = -vz; oy = vy;  oz = vx;  break;
+    default: ox = vz; oy = vy;  oz = -vx; break;
+    }
+    const float px = ox * nc.scale[0], py = oy * nc.scale[1], pz = oz * nc.scale[2];
+    float total = 0.0f, amp = 1.0f, norm = 0.0f, freq = nc.frequency;
+    for (int o = 0; o < nc.octaves; ++o) {
+        total += amp * nz_value(px * freq, py * freq, pz * freq, nc.seed + 1013u * (uint32_t)o);
+        norm += amp;
+        amp *= nc.gain;
+        freq *= 2.0f;
+    }
+    const float n = 2.0f * ieee_div(total, norm) - 1.0f;
+    const float density = 0.5f + 0.5f * n;  // :130
+    float v = density * 255.0f;
+    v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+    nc.out[((size_t)side * res + y) * res + x] = (uint8_t)v;  // L8 store, truncating
+}
+
+hipError_t launch_noise_cubemap(const NoiseCubemapConsts &nc, hipStream_t stream) {
+    dim3 grid((nc.resolution + 63) / 64, (nc.resolution + 3) / 4, 6);
+    hipLaunchKernelGGL(atmo_noise_cubemap_kernel, grid, dim3(256), 0, stream, nc);
+    return hipGetLastError();
+}
+
 // ---- self-test of the exact helpers against the compiler's IEEE expansions ---------------------------------
 // For `count` consecutive float bit patterns starting at first_bits: counts exact_sqrt(x) != sqrtf(x) and
 // exact_div_uniform(x, c, RN(1/c)) != x / c.

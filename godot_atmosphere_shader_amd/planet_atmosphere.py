@@ -368,6 +368,8 @@ class PlanetAtmosphere:
 
     def _upload_texture(self, name: str, value):
         kind = _TEXTURES[name]
+        if hasattr(value, "get_images"):  # a NoiseCubemap resource
+            value = value.get_images()
         if value is None:
             rc = self._lib.atmo_set_texture(self._ctx, name.encode(), kind, 0, 0, 0, None, N.MEM_HOST)
             N.check(self._ctx, rc)

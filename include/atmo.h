@@ -125,6 +125,18 @@ int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h,
  */
 int atmo_bake_optical_depth(AtmoContext *ctx, void *stream);
 
+/*
+ * Replaces: NoiseCubemap._generate_images (noise_cubemap.gd:101-140), the CPU triple loop the reference calls
+ * "really slow" (:100): 6 x resolution^2 L8 texels, density = 0.5 + 0.5 * noise(direction * scale), same
+ * texel -> direction mapping (:110-128).  The noise is this library's seeded fractal value noise (the reference calls
+ * Godot's FastNoiseLite, which is engine code): `seed`, `frequency`, `octaves`, `gain` play the roles of the Noise
+ * resource's properties; scale3 is NoiseCubemap.scale.  bind != 0 sets the result as u_cloud_coverage_cubemap;
+ * faces_host (may be NULL) receives the 6 faces (+X,-X,+Y,-Y,+Z,-Z), rows top to bottom -- lay them out 3 x 2 for
+ * generate_importable_image (:143-155).  kernel_ms (may be NULL) receives the generator kernel's device time.
+ */
+int atmo_generate_noise_cubemap(AtmoContext *ctx, int resolution, uint32_t seed, float frequency, int octaves, float gain,
+                                const float *scale3, int bind, uint8_t *faces_host, double *kernel_ms);
+
 /* Copy the currently bound LUT (w*h floats) to host memory; also writes the RGBA8 packing of
  * shaders/optical_depth.gdshader:33-43 when rgba8 != NULL (w*h*4 bytes). For hosts that want to hand the
  * LUT back to a Godot ImageTexture. Synchronises the stream. */

@@ -737,6 +737,96 @@ void SFX(oracle_bake_optical_depth)(float planet_radius, float atmosphere_height
         }
 }
 
+/* ---- NoiseCubemap generator ------------------------------------------------------ */
+#ifndef ORACLE_F64
+/*
+ * ref: /root/reference/addons/zylann.atmosphere/noise_cubemap.gd:101-140 (_generate_images): for every side and
+ * texel, pos2d -> +X direction -> per-side swizzle (:110-128), density = 0.5 + 0.5 * noise(pos * scale) (:130),
+ * stored as L8 (:107,134).  The reference's noise is Godot's FastNoiseLite (engine code, not in the tree): PARITY
+ * UNPINNED there; this build defines its own "seeded value noise" below, and the restatement pins the
+ * texel->direction mapping, the scale, the 0.5+0.5*n remap and the L8 store.  fp32 only, unfused, IEEE sqrt/div,
+ * so the device kernel reproduces the bytes exactly.
+ * Conventions stated by the build: Vector math in fp32; L8 store = (uint8) clamp(v * 255, 0, 255), truncating
+ * (Godot's Image::set_pixel for FORMAT_L8); mipmaps are not generated (the path samples LOD 0 only).
+ */
+static inline uint32_t nz_hash(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+static inline float nz_lattice(int32_t ix, int32_t iy, int32_t iz, uint32_t seed) {
+    uint32_t h = ((uint32_t)ix * 0x9E3779B1u) ^ ((uint32_t)iy * 0x85EBCA77u) ^ ((uint32_t)iz * 0xC2B2AE3Du) ^ seed;
+    return (float)(nz_hash(h) >> 8) * (1.0f / 16777216.0f);
+}
+static float nz_value(float px, float py, float pz, uint32_t seed) {
+    float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    float tx = px - fx, ty = py - fy, tz = pz - fz;
+    float wx = tx * tx * (3.0f - 2.0f * tx), wy = ty * ty * (3.0f - 2.0f * ty), wz = tz * tz * (3.0f - 2.0f * tz);
+    int32_t x0 = (int32_t)fx, y0 = (int32_t)fy, z0 = (int32_t)fz, x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+    float c00 = nz_lattice(x0, y0, z0, seed) * (1.0f - wx) + nz_lattice(x1, y0, z0, seed) * wx;
+    float c10 = nz_lattice(x0, y1, z0, seed) * (1.0f - wx) + nz_lattice(x1, y1, z0, seed) * wx;
+    float c01 = nz_lattice(x0, y0, z1, seed) * (1.0f - wx) + nz_lattice(x1, y0, z1, seed) * wx;
+    float c11 = nz_lattice(x0, y1, z1, seed) * (1.0f - wx) + nz_lattice(x1, y1, z1, seed) * wx;
+    float c0 = c00 * (1.0f - wy) + c10 * wy;
+    float c1 = c01 * (1.0f - wy) + c11 * wy;
+    return c0 * (1.0f - wz) + c1 * wz;
+}
+/* Noise.get_noise_3d analogue: fractal value noise in [-1, 1] */
+float oracle_noise_get_3d(float x, float y, float z, uint32_t seed, float frequency, int octaves, float gain) {
+    float total = 0.0f, amp = 1.0f, norm = 0.0f, freq = frequency;
+    for (int o = 0; o < octaves; ++o) {
+        total += amp * nz_value(x * freq, y * freq, z * freq, seed + 1013u * (uint32_t)o);
+        norm += amp;
+        amp *= gain;
+        freq *= 2.0f;
+    }
+    return 2.0f * (total / norm) - 1.0f;
+}
+/* ref: noise_cubemap.gd:110-128 -- direction of texel (x, y) of `side` */
+void oracle_noise_cubemap_direction(int resolution, int side, int x, int y, float *dir3) {
+    float half = 0.5f * (float)resolution;
+    float p2x = ((float)x + 0.5f) / half - 1.0f;
+    float p2y = ((float)(resolution - y - 1) + 0.5f) / half - 1.0f;
+    float vx = 1.0f, vy = p2y, vz = -p2x;
+    float len = sqrtf(vx * vx + vy * vy + vz * vz);
+    vx /= len; vy /= len; vz /= len;
+    float ox, oy, oz;
+    switch (side) {
+    case 0: ox = vx;  oy = vy;  oz = vz;  break;   /* +X */
+    case 1: ox = -vx; oy = vy;  oz = -vz; break;   /* -X */
+    case 2: ox = -vz; oy = vx;  oz = -vy; break;   /* +Y */
+    case 3: ox = -vz; oy = -vx; oz = vy;  break;   /* -Y */
+    case 4: ox = -vz; oy = vy;  oz = vx;  break;   /* +Z */
+    default: ox = vz; oy = vy;  oz = -vx; break;   /* -Z */
+    }
+    dir3[0] = ox; dir3[1] = oy; dir3[2] = oz;
+}
+/* ref: noise_cubemap.gd:101-140.  out: 6 faces of resolution^2 bytes, row y, column x. */
+void oracle_noise_cubemap(int resolution, uint32_t seed, float frequency, int octaves, float gain,
+                          const float *scale3, uint8_t *out) {
+    for (int side = 0; side < 6; ++side)
+        for (int y = 0; y < resolution; ++y)
+            for (int x = 0; x < resolution; ++x) {
+                float d[3];
+                oracle_noise_cubemap_direction(resolution, side, x, y, d);
+                float n = oracle_noise_get_3d(d[0] * scale3[0], d[1] * scale3[1], d[2] * scale3[2], seed, frequency, octaves, gain);
+                float density = 0.5f + 0.5f * n;
+                float v = density * 255.0f;
+                v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+                out[((size_t)side * resolution + y) * resolution + x] = (uint8_t)v;
+            }
+}
+/* ref: noise_cubemap.gd:143-155 (_generate_importable_image): 3 x 2 atlas, side = x + 3*y */
+void oracle_noise_cubemap_atlas(int resolution, const uint8_t *faces, uint8_t *atlas) {
+    const int aw = 3 * resolution;
+    for (int sy = 0; sy < 2; ++sy)
+        for (int sx = 0; sx < 3; ++sx) {
+            const uint8_t *f = faces + (size_t)(sx + sy * 3) * resolution * resolution;
+            for (int y = 0; y < resolution; ++y)
+                memcpy(atlas + ((size_t)(sy * resolution + y)) * aw + (size_t)sx * resolution, f + (size_t)y * resolution, (size_t)resolution);
+        }
+}
+#endif
+
 /* ---- single-function probes for the known-answer tests --------------------------------- */
 
 void SFX(oracle_ray_sphere)(const REAL *center, REAL radius, const REAL *origin, const REAL *dir, REAL *out2) {

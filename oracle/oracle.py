@@ -162,6 +162,14 @@ class Oracle:
             self.lib.oracle_encode_float_to_viewport.restype = None
             self.lib.oracle_decode_viewport_to_float.argtypes = [C.POINTER(C.c_uint8)]
             self.lib.oracle_decode_viewport_to_float.restype = C.c_float
+            self.lib.oracle_noise_get_3d.argtypes = [C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_float, C.c_int, C.c_float]
+            self.lib.oracle_noise_get_3d.restype = C.c_float
+            self.lib.oracle_noise_cubemap_direction.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+            self.lib.oracle_noise_cubemap_direction.restype = None
+            self.lib.oracle_noise_cubemap.argtypes = [C.c_int, C.c_uint32, C.c_float, C.c_int, C.c_float, C.POINTER(C.c_float), C.c_void_p]
+            self.lib.oracle_noise_cubemap.restype = None
+            self.lib.oracle_noise_cubemap_atlas.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+            self.lib.oracle_noise_cubemap_atlas.restype = None
 
     def _fn(self, name, restype, argtypes):
         fn = getattr(self.lib, name + self.sfx)
@@ -314,3 +322,25 @@ class Oracle:
     def decode_viewport_to_float(self, b):
         arr = (C.c_uint8 * 4)(*b)
         return float(self.lib.oracle_decode_viewport_to_float(arr))
+
+    # ---- NoiseCubemap generator (fp32 build only) -------------------------------------------------
+    def noise_get_3d(self, p, seed=0, frequency=0.01, octaves=4, gain=0.5):
+        return float(self.lib.oracle_noise_get_3d(p[0], p[1], p[2], seed, frequency, octaves, gain))
+
+    def noise_cubemap_direction(self, resolution, side, x, y):
+        out = (C.c_float * 3)()
+        self.lib.oracle_noise_cubemap_direction(resolution, side, x, y, out)
+        return [float(v) for v in out]
+
+    def noise_cubemap(self, resolution, seed=0, frequency=0.01, octaves=4, gain=0.5, scale=(100.0, 100.0, 100.0)):
+        out = np.empty((6, resolution, resolution), dtype=np.uint8)
+        sc = (C.c_float * 3)(*[float(v) for v in scale])
+        self.lib.oracle_noise_cubemap(resolution, seed, frequency, octaves, gain, sc, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def noise_cubemap_atlas(self, faces):
+        faces = np.ascontiguousarray(faces, dtype=np.uint8)
+        n = faces.shape[1]
+        atlas = np.empty((2 * n, 3 * n), dtype=np.uint8)
+        self.lib.oracle_noise_cubemap_atlas(n, faces.ctypes.data_as(C.c_void_p), atlas.ctypes.data_as(C.c_void_p))
+        return atlas

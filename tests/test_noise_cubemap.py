@@ -1,0 +1,154 @@
+"""NoiseCubemap generator: oracle restatement of noise_cubemap.gd:101-155 vs independent numpy
+statement (CPU) and vs the device kernel (GPU, bit-exact)."""
+import numpy as np
+import pytest
+
+from godot_atmosphere_shader_amd import scene as S
+from godot_atmosphere_shader_amd.noise_cubemap import (SeededValueNoise, generate_images_host, generate_importable_image,
+                                                       texel_directions)
+
+CASES = [
+    dict(res=64, seed=11, frequency=0.03, octaves=4, gain=0.5, scale=(100.0, 200.0, 100.0)),   # demo scene's scale
+    dict(res=17, seed=0, frequency=0.01, octaves=1, gain=0.5, scale=(100.0, 100.0, 100.0)),    # resource defaults, odd size
+    dict(res=128, seed=123456789, frequency=0.11, octaves=6, gain=0.665, scale=(37.0, 5.0, 250.0)),
+    dict(res=1, seed=5, frequency=0.5, octaves=2, gain=0.3, scale=(1.0, 1.0, 1.0)),
+]
+
+
+def _oracle_cube(o, c):
+    return o.noise_cubemap(c["res"], c["seed"], c["frequency"], c["octaves"], c["gain"], c["scale"])
+
+
+def test_texel_direction_mapping_is_the_vulkan_face_table(oracle32):
+    """noise_cubemap.gd:110-128 == the face table the sampler uses (scene.cube_texel_directions, float64)."""
+    for n in (1, 4, 33):
+        ref = S.cube_texel_directions(n)
+        host = texel_directions(n)
+        assert np.abs(host - ref).max() < 1e-6
+        for f in range(6):
+            for (y, x) in {(0, 0), (n - 1, n - 1), (0, n - 1), (n // 2, n // 3)}:
+                assert np.allclose(oracle32.noise_cubemap_direction(n, f, x, y), ref[f, y, x], atol=1e-6)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"res{c['res']}" for c in CASES])
+def test_oracle_equals_independent_numpy_statement(oracle32, case):
+    nz = SeededValueNoise(case["seed"], case["frequency"], case["octaves"], case["gain"])
+    assert np.array_equal(generate_images_host(case["res"], nz, case["scale"]), _oracle_cube(oracle32, case))
+
+
+def test_noise_range_and_remap(oracle32):
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(-500, 500, (2000, 3)).astype(np.float32)
+    nz = SeededValueNoise(7, 0.05, 5, 0.5)
+    v = nz.get_noise_3dv(pts)
+    assert v.min() >= -1.0 and v.max() <= 1.0 and v.std() > 0.1
+    for p, want in zip(pts[:20], v[:20]):
+        assert oracle32.noise_get_3d(p, 7, 0.05, 5, 0.5) == pytest.approx(float(want), abs=0)  # bit-identical
+    cube = _oracle_cube(oracle32, CASES[0])
+    assert 100 < cube.mean() < 155 and cube.std() > 10  # 0.5 + 0.5 n, stored as L8
+
+
+def test_cubemap_is_continuous_across_faces(oracle32):
+    """'can be applied to a sphere seamlessly' (README.md:46): texels either side of every cube edge sample the 3-D
+    noise at neighbouring directions, so they differ no more than neighbours inside a face do."""
+    c = dict(CASES[0], res=96)
+    cube = _oracle_cube(oracle32, c).astype(np.int32)
+    inner = np.abs(np.diff(cube, axis=2)).max()
+    # +X right edge (x = n-1) meets -Z left edge (x = 0); +X left edge meets +Z right edge; rows align (same t)
+    assert np.abs(cube[0][:, -1] - cube[5][:, 0]).max() <= inner
+    assert np.abs(cube[0][:, 0] - cube[4][:, -1]).max() <= inner
+    # +Y bottom row meets +Z top row
+    assert np.abs(cube[2][-1, :] - cube[4][0, :]).max() <= inner
+
+
+def test_importable_image_layout(oracle32):
+    cube = _oracle_cube(oracle32, CASES[1])
+    atlas = generate_importable_image(cube)
+    n = cube.shape[1]
+    assert atlas.shape == (2 * n, 3 * n)
+    for side in range(6):
+        x, y = side % 3, side // 3
+        assert np.array_equal(atlas[y * n:(y + 1) * n, x * n:(x + 1) * n], cube[side])
+    assert np.array_equal(atlas, oracle32.noise_cubemap_atlas(cube))
+
+
+def test_resource_properties_and_deferred_update():
+    """noise_cubemap.gd:13-64: clampi resolution, update requested on every property / noise change, coalesced."""
+    from godot_atmosphere_shader_amd import NoiseCubemap
+
+    calls = []
+
+    class Stub(NoiseCubemap):
+        def _generate_images(self, resolution, noise, scale):
+            calls.append((resolution, noise.seed, scale))
+            return np.zeros((6, resolution, resolution), dtype=np.uint8)
+
+    nc = Stub(resolution=8)
+    changed = []
+    nc.connect_changed(lambda: changed.append(1))
+    assert calls == []                      # deferred: nothing generated yet
+    nc.resolution = 100000
+    assert nc.resolution == 4096
+    nc.resolution = 0
+    assert nc.resolution == 1
+    nc.resolution = 16
+    nc.scale = (1, 2, 3)
+    nc.noise.seed = 42                      # Noise.changed -> _on_noise_changed -> _request_update
+    nc.process_deferred()
+    assert calls == [(16, 42, (1.0, 2.0, 3.0))] and changed == [1]   # several requests, one update
+    nc.process_deferred()
+    assert len(calls) == 1
+    nc.noise = SeededValueNoise(seed=3)
+    assert nc.get_layer_data(2).shape == (16, 16) and len(calls) == 2  # access runs the pending update
+    assert nc.generate_importable_image().shape == (32, 48)
+
+
+# ---- GPU -------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=[f"res{c['res']}" for c in CASES])
+def test_device_generator_is_bit_exact(oracle32, case):
+    from godot_atmosphere_shader_amd import NoiseCubemap
+
+    nc = NoiseCubemap(noise=SeededValueNoise(case["seed"], case["frequency"], case["octaves"], case["gain"]),
+                      resolution=case["res"], scale=case["scale"])
+    got = nc.get_images()
+    assert nc.last_kernel_ms is not None
+    nc.close()
+    assert np.array_equal(got, _oracle_cube(oracle32, case))
+
+
+@pytest.mark.gpu
+def test_generated_cubemap_as_coverage(oracle32):
+    """A NoiseCubemap resource assigned to u_cloud_coverage_cubemap renders like the same bytes given to the oracle;
+    atmo_generate_noise_cubemap(bind=1) binds the device-generated faces without a host round trip of the caller."""
+    import ctypes as C
+
+    import torch
+    from common import CONFIGS, TOL, demo_frame, demo_params, demo_textures, make_node
+    from godot_atmosphere_shader_amd import NoiseCubemap
+    from godot_atmosphere_shader_amd import _native as N
+
+    case = dict(res=128, seed=21, frequency=0.03, octaves=4, gain=0.5, scale=(100.0, 200.0, 100.0))
+    cube = _oracle_cube(oracle32, case)
+    tex, params = demo_textures(), demo_params()
+    tex_o = dict(tex, cubemap=cube)
+    cam = S.Camera.from_pose(160, 90, "P_space")
+    depth_np = S.depth_ground_sphere(cam)
+    depth = torch.from_numpy(depth_np).cuda()
+    lut = oracle32.bake_optical_depth(100.0, 8.0, 0.5)
+    want, _ = oracle32.render(params, dict(tex_o, optical_depth=lut), CONFIGS["clouds_high"][1], demo_frame(cam), depth_np, nthreads=8)
+
+    res = NoiseCubemap(noise=SeededValueNoise(21, 0.03, 4, 0.5), resolution=128, scale=case["scale"])
+    node = make_node("clouds_high", dict(tex, cubemap=None), params)
+    node.set_shader_parameter("u_cloud_coverage_cubemap", res)   # the resource itself, as in the demo scene
+    got = node.render(cam, depth).cpu().numpy()
+    assert np.abs(got - want).max() <= TOL
+    # bind on the device through the C ABI
+    sc = (C.c_float * 3)(*case["scale"])
+    rc = node._lib.atmo_generate_noise_cubemap(node._ctx, 128, 21, 0.03, 4, 0.5, sc, 1, None, None)
+    assert rc == N.ATMO_OK
+    got2 = node.render(cam, depth).cpu().numpy()
+    assert np.array_equal(got, got2)
+    assert node._lib.atmo_generate_noise_cubemap(node._ctx, 0, 1, 0.1, 1, 0.5, sc, 0, None, None) == N.ATMO_E_ARG
+    node.close()
+    res.close()
