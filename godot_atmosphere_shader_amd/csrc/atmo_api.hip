@@ -519,6 +519,33 @@ int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h,
     return fail(ctx, ATMO_E_NAME, std::string("atmo_set_texture: unknown texture uniform '") + name + "'");
 }
 
+// ---- host-only layout helpers (no device needed): what atmo_set_texture uploads -----------------------------------
+int atmo_host_layout_cubemap(const uint8_t *faces, int n, uint32_t *footprints_out) {
+    if (!faces || !footprints_out || n < 1 || n > 4096) return ATMO_E_ARG;
+    std::vector<uint8_t> padded;
+    build_cube_apron(faces, n, padded);
+    std::vector<uint32_t> fp;
+    build_cube_footprints(padded, n, fp);
+    std::memcpy(footprints_out, fp.data(), fp.size() * sizeof(uint32_t));
+    return ATMO_OK;
+}
+
+int atmo_host_layout_shape(const uint8_t *texels, int n, uint32_t *footprints_out) {
+    if (!texels || !footprints_out || n < 1 || n > 512) return ATMO_E_ARG;
+    std::vector<uint32_t> fp;
+    build_shape_footprints(texels, n, fp);
+    std::memcpy(footprints_out, fp.data(), fp.size() * sizeof(uint32_t));
+    return ATMO_OK;
+}
+
+int atmo_host_layout_lut(const float *lut, int w, int h, float *apron_out) {
+    if (!lut || !apron_out || w < 1 || h < 1 || w > 8192 || h > 8192) return ATMO_E_ARG;
+    std::vector<float> padded;
+    build_lut_apron(lut, w, h, padded);
+    std::memcpy(apron_out, padded.data(), padded.size() * sizeof(float));
+    return ATMO_OK;
+}
+
 int atmo_generate_noise_cubemap(AtmoContext *ctx, int resolution, uint32_t seed, float frequency, int octaves, float gain,
                                 const float *scale3, int bind, uint8_t *faces_host, double *kernel_ms) {
     if (!ctx) return ATMO_E_ARG;

@@ -35,6 +35,14 @@ constexpr int TILE_H = 16;
 #ifndef ATMO_WAVE_W
 #define ATMO_WAVE_W 16
 #endif
+// 1: per-lane search-ahead to the next lit cloud sample in the raymarched-light variant (see march_clouds).
+// Measured slower than lock-step marching (profiles/round1/ab_rm_compaction.txt): neighbouring rays meet cloud at
+// the same step indices, so lock step already keeps the light block's lanes full, and search-ahead desynchronises
+// the lanes' texture footprints.  Off by default; kept for A/B.
+#ifndef ATMO_RM_COMPACT
+#define ATMO_RM_COMPACT 0
+#endif
+constexpr bool RM_COMPACT = ATMO_RM_COMPACT != 0;
 constexpr int WAVE_W = ATMO_WAVE_W;
 constexpr int WAVE_H = 64 / WAVE_W;
 static_assert(WAVE_W == 16 || WAVE_W == 8 || WAVE_W == 32, "wave tile");
@@ -400,37 +408,52 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
     const float scale_step = rc.cloud_density_scale * step_len;
     const float neg_scale_step_log2e = -scale_step * LOG2E;
 
-    for (int i = 0; i < steps; ++i) {
-        float r, hr;
-        cloud_height(rc, px, py, pz, r, hr);
-        {
-#pragma clang fp contract(fast)
-            const float density = cloud_density(rc, px, py, pz, hr);
-            // A zero-density sample contributes nothing: transmittance 1, light term 0, and the light value itself
-            // (6 more density taps in the raymarched variant) is never observed.
-            if (density > 0.0f) {
-                float light;
-                if (RM) {
-                    light = light_raymarched(rc, px, py, pz, hr, sx, sy, sz);
-                } else {
-                    light = fmaf(p16, one_minus_alpha, hr);
-                }
-                // get_planet_shadow: smoothstep(-0.3, 0.3, dot(normalize(pos), -sun_dir))
-                const float sd = -(px * sx + py * sy + pz * sz) * hw_rcp(r);
-                const float st = sat((sd + 0.3f) * (1.0f / 0.6f));
-                const float shadow = st * st * (3.0f - 2.0f * st);
-                light *= fmaf(shadow, 0.002f - 1.0f, 1.0f);
-
-                const float transmittance = hw_exp2(density * neg_scale_step_log2e);
-                total_transmittance = fmaxf(total_transmittance * transmittance, 0.005f);
-                total_light = fmaf(light * (density * scale_step), total_transmittance, total_light);
-                one_minus_alpha *= transmittance;
+    // Default (RM_COMPACT = 0): lock-step march, the inner `while` runs exactly once per step.
+    // Experiment (RM_COMPACT = 1, raymarched light only): every lane first searches ahead on its own to its next
+    // non-zero-density sample (cheap iterations, the wave reconverges at the loop exit), then all lanes that found one
+    // evaluate the 6-tap light together.  Per ray the samples are visited in the same order, so the result is
+    // bit-identical; it measured 1.5x SLOWER (see ATMO_RM_COMPACT above), so it is off.
+    int i = 0;
+    for (;;) {
+        float r = 0.0f, hr = 0.0f, density = 0.0f;
+        while (i < steps) {
+            cloud_height(rc, px, py, pz, r, hr);
+            density = cloud_density(rc, px, py, pz, hr);
+            if (RM_COMPACT && RM) {
+                if (density > 0.0f) break;  // a zero-density sample contributes exactly nothing: keep searching
+                px = px + ddx; py = py + ddy; pz = pz + ddz;  // exact: pos += ray_dir * step_len
+                ++i;
+            } else {
+                break;
             }
+        }
+        if (i >= steps) break;
+        // A zero-density sample contributes nothing: transmittance 1, light term 0, and the light value itself
+        // (6 more density taps in the raymarched variant) is never observed.
+        if (density > 0.0f) {
+#pragma clang fp contract(fast)
+            float light;
+            if (RM) {
+                light = light_raymarched(rc, px, py, pz, hr, sx, sy, sz);
+            } else {
+                light = fmaf(p16, one_minus_alpha, hr);
+            }
+            // get_planet_shadow: smoothstep(-0.3, 0.3, dot(normalize(pos), -sun_dir))
+            const float sd = -(px * sx + py * sy + pz * sz) * hw_rcp(r);
+            const float st = sat((sd + 0.3f) * (1.0f / 0.6f));
+            const float shadow = st * st * (3.0f - 2.0f * st);
+            light *= fmaf(shadow, 0.002f - 1.0f, 1.0f);
+
+            const float transmittance = hw_exp2(density * neg_scale_step_log2e);
+            total_transmittance = fmaxf(total_transmittance * transmittance, 0.005f);
+            total_light = fmaf(light * (density * scale_step), total_transmittance, total_light);
+            one_minus_alpha *= transmittance;
         }
         // exact: pos += ray_dir * step_len
         px = px + ddx;
         py = py + ddy;
         pz = pz + ddz;
+        ++i;
     }
     return make_float2(total_light, 1.0f - one_minus_alpha);
 }

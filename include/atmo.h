@@ -165,6 +165,16 @@ int atmo_render_composite(AtmoContext *ctx, const AtmoFrame *frame, const float 
 int atmo_set_timing(AtmoContext *ctx, int enable);
 int atmo_get_timing(AtmoContext *ctx, int *launches, double *total_ms);
 
+/*
+ * Host-only helpers (no device, no context): the device layouts atmo_set_texture builds, exposed so they can be
+ * checked without a GPU.  cubemap: 6*(n+1)^2 words, word (i,j) of a face = the 2x2 texels of the seamless-apron
+ * padded face starting at padded (i,j), bytes 0..3 = (i,j),(i+1,j),(i,j+1),(i+1,j+1).  shape: n^3 words, word
+ * (i,j,k) = T(i,j,k),T(i+1,j,k),T(i,j+1,k),T(i+1,j+1,k) with repeat wrap.  lut: (h+2) x (w+2) floats, clamp apron.
+ */
+int atmo_host_layout_cubemap(const uint8_t *faces, int n, uint32_t *footprints_out);
+int atmo_host_layout_shape(const uint8_t *texels, int n, uint32_t *footprints_out);
+int atmo_host_layout_lut(const float *lut, int w, int h, float *apron_out);
+
 /* Diagnostics (no reference counterpart): on the device, compares the kernels' cheap correctly-rounded sqrt and
  * divide-by-uniform helpers with the compiler's IEEE expansions over `count` consecutive float bit patterns
  * starting at `first_bits`, and reports the number of mismatches (must be 0). */

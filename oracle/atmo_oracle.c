@@ -640,7 +640,7 @@ typedef struct {
     const float *depth;
     REAL *out;
     int x0, y0, x1, y1; /* rect, output is (y1-y0) rows of (x1-x0) RGBA */
-    int row_begin, row_end;
+    int *next_row;      /* shared row counter: threads take rows dynamically (hit and miss rows cost very differently) */
     long hits;
 } Job;
 
@@ -649,11 +649,14 @@ static void *render_rows(void *arg) {
     const int w = j->frame->viewport_w;
     const int rw = j->x1 - j->x0;
     long hits = 0;
-    for (int y = j->row_begin; y < j->row_end; ++y)
+    for (;;) {
+        const int y = __atomic_fetch_add(j->next_row, 1, __ATOMIC_RELAXED);
+        if (y >= j->y1) break;
         for (int x = j->x0; x < j->x1; ++x) {
             REAL *o = j->out + ((size_t)(y - j->y0) * rw + (x - j->x0)) * 4;
             hits += atmosphere_fragment(j->ctx, j->frame, j->inv_p, j->inv_v, x, y, K(j->depth[(size_t)y * w + x]), o);
         }
+    }
     j->hits = hits;
     return NULL;
 }
@@ -661,7 +664,7 @@ static void *render_rows(void *arg) {
 /*
  * Render the rect [x0,x1) x [y0,y1) of the viewport.  depth = full-viewport nonlinear depth buffer
  * (viewport_h rows of viewport_w floats).  out = (y1-y0)*(x1-x0) RGBA REAL, row-major.
- * Rows are split in contiguous bands over nthreads.  Returns the number of non-discarded pixels.
+ * nthreads workers take rows from a shared counter.  Returns the number of non-discarded pixels.
  */
 long SFX(oracle_render)(const OracleParams *p, const OracleTextures *t, const OracleConfig *cfg,
                         const OracleFrame *f, const float *depth, REAL *out,
@@ -669,17 +672,17 @@ long SFX(oracle_render)(const OracleParams *p, const OracleTextures *t, const Or
     Ctx ctx;
     ctx_init(&ctx, p, t, cfg);
     if (nthreads < 1) nthreads = 1;
-    if (nthreads > 256) nthreads = 256;
-    Job jobs[256];
-    pthread_t th[256];
-    int rows = y1 - y0;
+    if (nthreads > 1024) nthreads = 1024;
+    if (nthreads > (y1 - y0)) nthreads = (y1 - y0) > 0 ? (y1 - y0) : 1;
+    Job *jobs = (Job *)malloc(sizeof(Job) * (size_t)nthreads);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    int next_row = y0;
     for (int k = 0; k < nthreads; ++k) {
         Job *j = &jobs[k];
         j->ctx = &ctx; j->frame = f; j->depth = depth; j->out = out;
         for (int i = 0; i < 16; ++i) { j->inv_p[i] = f->inv_projection_matrix[i]; j->inv_v[i] = f->inv_view_matrix[i]; }
         j->x0 = x0; j->y0 = y0; j->x1 = x1; j->y1 = y1;
-        j->row_begin = y0 + (int)((long)rows * k / nthreads);
-        j->row_end = y0 + (int)((long)rows * (k + 1) / nthreads);
+        j->next_row = &next_row;
         j->hits = 0;
     }
     if (nthreads == 1) {
@@ -690,6 +693,8 @@ long SFX(oracle_render)(const OracleParams *p, const OracleTextures *t, const Or
     }
     long hits = 0;
     for (int k = 0; k < nthreads; ++k) hits += jobs[k].hits;
+    free(jobs);
+    free(th);
     return hits;
 }
 

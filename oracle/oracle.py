@@ -141,7 +141,10 @@ class Oracle:
         self.sfx = "_f64" if precision == "f64" else "_f32"
         self.real = C.c_double if precision == "f64" else C.c_float
         self.np_real = np.float64 if precision == "f64" else np.float32
-        self.lib = C.CDLL(os.path.join(_HERE, f"liboracle_{precision}.so"))
+        libname = f"liboracle_{precision}.so"
+        if os.environ.get("ORACLE_SANITIZE") == "1" and precision in ("f32", "f64"):
+            libname = f"liboracle_{precision}_san.so"  # `make -C oracle sanitize`; run under LD_PRELOAD=libasan
+        self.lib = C.CDLL(os.path.join(_HERE, libname))
         R = self.real
         RP = C.POINTER(R)
         f = self._fn

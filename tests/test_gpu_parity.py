@@ -439,3 +439,31 @@ def test_render_composite_blends_in_place(oracle32):
     lut = oracle32.bake_optical_depth(100.0, 8.0, 0.5)
     ref, _ = _oracle_render(oracle32, "clouds_high", params, tex, cam, depth_np, lut)
     assert np.abs(src - ref).max() <= TOL
+
+
+def test_textures_from_device_memory(oracle32):
+    """atmo_set_texture with ATMO_MEM_DEVICE for all four textures == the same bytes from host memory."""
+    from godot_atmosphere_shader_amd import _native as N
+
+    w, h = 128, 72
+    tex, params = demo_textures(cube_n=64, shape_n=32), demo_params()
+    cam = S.Camera.from_pose(w, h, "P_space")
+    depth_np = S.depth_ground_sphere(cam)
+    node = make_node("clouds_high", tex, params)
+    ref = _gpu_render(node, cam, depth_np)
+    lut = node.read_optical_depth()
+    lib, ctx = node._lib, node._ctx
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in
+           dict(lut=lut, blue=tex["blue_noise"], shape=tex["shape"], cube=tex["cubemap"]).items()}
+    # unset everything first so a stale copy cannot make the test pass
+    for name, kind in ((b"u_cloud_shape_texture", N.TEX_3D_R8), (b"u_cloud_coverage_cubemap", N.TEX_CUBE_R8), (b"u_optical_depth_texture", N.TEX_2D_R32F)):
+        assert lib.atmo_set_texture(ctx, name, kind, 0, 0, 0, None, N.MEM_HOST) == N.ATMO_OK
+    node._bake_pending = False
+    f = N.AtmoFrame()
+    assert lib.atmo_set_texture(ctx, b"u_optical_depth_texture", N.TEX_2D_R32F, 256, 256, 1, C.c_void_p(dev["lut"].data_ptr()), N.MEM_DEVICE) == N.ATMO_OK
+    assert lib.atmo_set_texture(ctx, b"u_blue_noise_texture", N.TEX_2D_R8, 256, 256, 1, C.c_void_p(dev["blue"].data_ptr()), N.MEM_DEVICE) == N.ATMO_OK
+    assert lib.atmo_set_texture(ctx, b"u_cloud_shape_texture", N.TEX_3D_R8, 32, 32, 32, C.c_void_p(dev["shape"].data_ptr()), N.MEM_DEVICE) == N.ATMO_OK
+    assert lib.atmo_set_texture(ctx, b"u_cloud_coverage_cubemap", N.TEX_CUBE_R8, 64, 64, 6, C.c_void_p(dev["cube"].data_ptr()), N.MEM_DEVICE) == N.ATMO_OK
+    got = _gpu_render(node, cam, depth_np)
+    node.close()
+    assert np.array_equal(got, ref)

@@ -165,3 +165,40 @@ def test_product_does_not_import_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "liboracle" not in text, f
                 assert "atmo_oracle" not in text, f
+
+
+def test_host_texture_layouts_against_the_oracle(oracle32):
+    """The device layouts atmo_set_texture uploads (built on the host, no GPU needed): cubemap footprints carry the
+    oracle's seamless texels (incl. the folded apron and the rounded-mean corners), shape footprints the repeat
+    wrap, the LUT a clamp-to-edge apron."""
+    from godot_atmosphere_shader_amd import _native as N
+
+    lib = N.load()
+    rng = np.random.default_rng(12)
+    for n in (1, 2, 5, 16):
+        cube = rng.integers(0, 256, (6, n, n), dtype=np.uint8)
+        fp = np.zeros((6, n + 1, n + 1), dtype=np.uint32)
+        assert lib.atmo_host_layout_cubemap(cube.ctypes.data_as(C.c_void_p), n, fp.ctypes.data_as(C.c_void_p)) == N.ATMO_OK
+        for f in range(6):
+            for j in range(n + 1):
+                for i in range(n + 1):
+                    w = int(fp[f, j, i])
+                    got = [(w >> (8 * k)) & 255 for k in range(4)]
+                    # word (i,j) starts at padded (i,j) = texel (i-1, j-1)
+                    want = [oracle32.cube_texel(cube, f, i - 1 + di, j - 1 + dj) for (di, dj) in ((0, 0), (1, 0), (0, 1), (1, 1))]
+                    assert got == want, (n, f, i, j)
+    for n in (1, 3, 8):
+        tex = rng.integers(0, 256, (n, n, n), dtype=np.uint8)
+        fp = np.zeros((n, n, n), dtype=np.uint32)
+        assert lib.atmo_host_layout_shape(tex.ctypes.data_as(C.c_void_p), n, fp.ctypes.data_as(C.c_void_p)) == N.ATMO_OK
+        for k in range(n):
+            for j in range(n):
+                for i in range(n):
+                    w = int(fp[k, j, i])
+                    want = [tex[k, j, i], tex[k, j, (i + 1) % n], tex[k, (j + 1) % n, i], tex[k, (j + 1) % n, (i + 1) % n]]
+                    assert [(w >> (8 * b)) & 255 for b in range(4)] == [int(v) for v in want]
+    lut = rng.random((5, 7), dtype=np.float32)
+    ap = np.zeros((7, 9), dtype=np.float32)
+    assert lib.atmo_host_layout_lut(lut.ctypes.data_as(C.c_void_p), 7, 5, ap.ctypes.data_as(C.c_void_p)) == N.ATMO_OK
+    assert np.array_equal(ap, np.pad(lut, 1, mode="edge"))
+    assert lib.atmo_host_layout_cubemap(None, 4, fp.ctypes.data_as(C.c_void_p)) == N.ATMO_E_ARG
