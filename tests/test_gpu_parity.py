@@ -467,3 +467,43 @@ def test_textures_from_device_memory(oracle32):
     got = _gpu_render(node, cam, depth_np)
     node.close()
     assert np.array_equal(got, ref)
+
+
+def test_native_host_matches_python_binding(tmp_path):
+    """examples/atmo_render_file.cpp uses only include/atmo.h + the HIP runtime (no Python, no torch): its frame is
+    byte-identical to the one the Python binding renders from the same AtmoFrame and depth buffer."""
+    import os
+    import shutil
+    import subprocess
+
+    from godot_atmosphere_shader_amd.build import LIB_PATH
+    from godot_atmosphere_shader_amd.planet_atmosphere import _to_native_frame
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "atmo_render_file"
+    libdir = os.path.dirname(LIB_PATH)
+    subprocess.run([hipcc, "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "atmo_render_file.cpp"),
+                    "-L", libdir, "-latmo_hip", f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
+    w, h = 96, 54
+    cam = S.Camera.from_pose(w, h, "P_limb")
+    depth_np = S.depth_ground_sphere(cam)
+    tex = demo_textures(cube_n=16, shape_n=8)
+    tex["blue_noise"] = np.zeros((256, 256), dtype=np.uint8)  # the native host leaves u_blue_noise_texture unset (zero)
+    params = demo_params()
+    node = make_node("no_clouds_32_lut", tex, params)
+    # the native host sets only radius/height/density/strength; align the remaining uniforms with the shader defaults
+    node.set_shader_parameter("u_atmosphere_modulate", (1.0, 1.0, 1.0))
+    node.set_shader_parameter("u_atmosphere_ambient_color", (0.0, 0.0, 0.002))
+    rect = (8, 4, 90, 50)
+    want = _gpu_render(node, cam, depth_np, rect=rect)
+    frame = _to_native_frame(node.make_frame(cam, 0.0, rect))
+    node.close()
+    (tmp_path / "frame.bin").write_bytes(bytes(frame))
+    depth_np.tofile(tmp_path / "depth.bin")
+    r = subprocess.run([str(exe), str(tmp_path / "frame.bin"), str(tmp_path / "depth.bin"), str(tmp_path / "out.bin"),
+                        "100", "8", "0.5", "32"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "atmo_render_kernel<0, 0>" in r.stdout
+    got = np.fromfile(tmp_path / "out.bin", dtype=np.float32).reshape(want.shape)
+    assert np.array_equal(got, want)
