@@ -43,6 +43,10 @@ constexpr int TILE_H = 16;
 #define ATMO_RM_COMPACT 0
 #endif
 constexpr bool RM_COMPACT = ATMO_RM_COMPACT != 0;
+// unroll factor of the view-ray loop (lets the LUT gathers of step i+1 issue under the exps of step i)
+#ifndef ATMO_VIEW_UNROLL
+#define ATMO_VIEW_UNROLL 1
+#endif
 constexpr int WAVE_W = ATMO_WAVE_W;
 constexpr int WAVE_H = 64 / WAVE_W;
 static_assert(WAVE_W == 16 || WAVE_W == 8 || WAVE_W == 32, "wave tile");
@@ -137,7 +141,9 @@ __device__ __forceinline__ float lut_sample_xy(const float *__restrict__ lut, in
 #pragma clang fp contract(fast)
     const float xf = floorf(x), yf = floorf(y);
     const float fx = x - xf, fy = y - yf;
-    const int i = (int)xf + 1, j = (int)yf + 1;  // apron coordinates
+    // apron coordinates.  Keep the pointer form: the compiler merges each row's pair into one global_load_dwordx2;
+    // unsigned element offsets from the scalar base measured 1.5x slower on this loop (profiles/round1/ab_lut_loop.txt).
+    const int i = (int)xf + 1, j = (int)yf + 1;
     const float *p = lut + j * stride + i;
     const float t00 = p[0], t10 = p[1], t01 = p[stride], t11 = p[stride + 1];
     const float a = t00 + (t10 - t00) * fx;
@@ -234,6 +240,7 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
     const float dstep = dens2 * step_len;
     float lr = 0.0f, lg = 0.0f, lb = 0.0f, view_od = 0.0f;
 
+#pragma unroll ATMO_VIEW_UNROLL
     for (int i = 0; i < steps; ++i) {
         const float r2 = ox * ox + oy * oy + oz * oz;
         const float bdot = ox * sx + oy * sy + oz * sz;
