@@ -43,6 +43,12 @@ constexpr int TILE_H = 16;
 #define ATMO_RM_COMPACT 0
 #endif
 constexpr bool RM_COMPACT = ATMO_RM_COMPACT != 0;
+// Ablation knob for the LDS-staging question (profiles/round1/ab_fetch_ablation.txt): 1 replaces every texture
+// gather (LUT, shape, cubemap) by arithmetic on its address, keeping all address and filter math alive.  The speed-up
+// it shows is an upper bound on what ANY cheaper fetch path (LDS staging included) could give.  Never shipped.
+#ifndef ATMO_ABLATE_FETCH
+#define ATMO_ABLATE_FETCH 0
+#endif
 // unroll factor of the view-ray loop (lets the LUT gathers of step i+1 issue under the exps of step i)
 #ifndef ATMO_VIEW_UNROLL
 #define ATMO_VIEW_UNROLL 1
@@ -145,7 +151,13 @@ __device__ __forceinline__ float lut_sample_xy(const float *__restrict__ lut, in
     // unsigned element offsets from the scalar base measured 1.5x slower on this loop (profiles/round1/ab_lut_loop.txt).
     const int i = (int)xf + 1, j = (int)yf + 1;
     const float *p = lut + j * stride + i;
+#if ATMO_ABLATE_FETCH
+    const float base = (float)(j * stride + i) * 1e-6f;
+    const float t00 = base, t10 = base + 1e-3f, t01 = base + 2e-3f, t11 = base + 3e-3f;
+    (void)p;
+#else
     const float t00 = p[0], t10 = p[1], t01 = p[stride], t11 = p[stride + 1];
+#endif
     const float a = t00 + (t10 - t00) * fx;
     const float b = t01 + (t11 - t01) * fx;
     return a + (b - a) * fy;
@@ -166,8 +178,13 @@ __device__ __forceinline__ float shape_sample(const uint32_t *__restrict__ fp, i
     } else {
         i0 = ((i % n) + n) % n; j0 = ((j % n) + n) % n; k0 = ((k % n) + n) % n; k1 = (k0 + 1) % n;
     }
+#if ATMO_ABLATE_FETCH
+    const uint32_t w0 = (uint32_t)((k0 * n + j0) * n + i0) * 2654435761u;
+    const uint32_t w1 = (uint32_t)((k1 * n + j0) * n + i0) * 2246822519u;
+#else
     const uint32_t w0 = fp[(k0 * n + j0) * n + i0];
     const uint32_t w1 = fp[(k1 * n + j0) * n + i0];
+#endif
     const float a00 = ub0(w0), a10 = ub1(w0), a01 = ub2(w0), a11 = ub3(w0);
     const float b00 = ub0(w1), b10 = ub1(w1), b01 = ub2(w1), b11 = ub3(w1);
     const float c00 = a00 + (a10 - a00) * fx;
@@ -201,7 +218,11 @@ __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, in
     const float fx = x - xf, fy = y - yf;
     const int i = min(max((int)xf, -1), n - 1) + 1, j = min(max((int)yf, -1), n - 1) + 1;
     const int stride = n + 1;
+#if ATMO_ABLATE_FETCH
+    const uint32_t w = (uint32_t)(((int)fid * stride + j) * stride + i) * 2654435761u;
+#else
     const uint32_t w = fp[((int)fid * stride + j) * stride + i];
+#endif
     const float t00 = ub0(w), t10 = ub1(w), t01 = ub2(w), t11 = ub3(w);
     const float a = t00 + (t10 - t00) * fx;
     const float b = t01 + (t11 - t01) * fx;
