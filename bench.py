@@ -39,11 +39,11 @@ VALU_FMA_WINST_PER_S = 8.68e11
 VALU_TRANS_WINST_PER_S = 3.02e11
 # rocprofv3 PMC results for the same command line (tools/profile.sh), keyed by (workload, width, height)
 PMC_FILES = {
-    ("direct32x8", 1920, 1080): "profiles/round1/pmc_v2_direct32x8_1920x1080.json",
-    ("lut32", 1920, 1080): "profiles/round1/pmc_v2_lut32_1920x1080.json",
-    ("clouds_high", 1920, 1080): "profiles/round1/pmc_v2_clouds_high_1920x1080.json",
-    ("clouds_high_rm", 1920, 1080): "profiles/round1/pmc_v2_clouds_high_rm_1920x1080.json",
-    ("clouds_high_rm", 3840, 2160): "profiles/round1/pmc_v2_clouds_high_rm_3840x2160.json",
+    ("direct32x8", 1920, 1080): "profiles/round1/pmc_final_direct32x8_1920x1080.json",
+    ("lut32", 1920, 1080): "profiles/round1/pmc_final_lut32_1920x1080.json",
+    ("clouds_high", 1920, 1080): "profiles/round1/pmc_final_clouds_high_1920x1080.json",
+    ("clouds_high_rm", 1920, 1080): "profiles/round1/pmc_final_clouds_high_rm_1920x1080.json",
+    ("clouds_high_rm", 3840, 2160): "profiles/round1/pmc_final_clouds_high_rm_3840x2160.json",
 }
 
 

@@ -49,6 +49,10 @@ constexpr bool RM_COMPACT = ATMO_RM_COMPACT != 0;
 #ifndef ATMO_ABLATE_FETCH
 #define ATMO_ABLATE_FETCH 0
 #endif
+// 1: index the single-dword footprint gathers (shape, cubemap) with unsigned 32-bit element offsets
+#ifndef ATMO_U32_OFFSETS
+#define ATMO_U32_OFFSETS 1
+#endif
 // unroll factor of the view-ray loop (lets the LUT gathers of step i+1 issue under the exps of step i)
 #ifndef ATMO_VIEW_UNROLL
 #define ATMO_VIEW_UNROLL 1
@@ -182,8 +186,13 @@ __device__ __forceinline__ float shape_sample(const uint32_t *__restrict__ fp, i
     const uint32_t w0 = (uint32_t)((k0 * n + j0) * n + i0) * 2654435761u;
     const uint32_t w1 = (uint32_t)((k1 * n + j0) * n + i0) * 2246822519u;
 #else
+#if ATMO_U32_OFFSETS
+    const uint32_t w0 = fp[(uint32_t)((k0 * n + j0) * n + i0)];
+    const uint32_t w1 = fp[(uint32_t)((k1 * n + j0) * n + i0)];
+#else
     const uint32_t w0 = fp[(k0 * n + j0) * n + i0];
     const uint32_t w1 = fp[(k1 * n + j0) * n + i0];
+#endif
 #endif
     const float a00 = ub0(w0), a10 = ub1(w0), a01 = ub2(w0), a11 = ub3(w0);
     const float b00 = ub0(w1), b10 = ub1(w1), b01 = ub2(w1), b11 = ub3(w1);
@@ -221,7 +230,11 @@ __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, in
 #if ATMO_ABLATE_FETCH
     const uint32_t w = (uint32_t)(((int)fid * stride + j) * stride + i) * 2654435761u;
 #else
+#if ATMO_U32_OFFSETS
+    const uint32_t w = fp[(uint32_t)(((int)fid * stride + j) * stride + i)];
+#else
     const uint32_t w = fp[((int)fid * stride + j) * stride + i];
+#endif
 #endif
     const float t00 = ub0(w), t10 = ub1(w), t01 = ub2(w), t11 = ub3(w);
     const float a = t00 + (t10 - t00) * fx;
