@@ -15,7 +15,7 @@ i=0
 for PMC in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE" \
            "TA_BUSY_avr TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" \
-           "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+           "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "VALUBusy" "VALUUtilization" "OccupancyPercent" "MemUnitStalled"; do
   i=$((i+1))
   rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc_$i -o p -- python3 $R/bench.py $ARGS --steps 6 --warmup 2 > $OUT/pmc_$i.log 2>&1
 done

@@ -43,6 +43,9 @@ if "TCC_HIT_sum" in c:
     d["l2_hit_rate"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1)
 if "TCP_TCC_READ_REQ_sum" in c and "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
     d["l1_miss_ratio_reqs"] = c["TCP_TCC_READ_REQ_sum"] / max(c["TCP_TOTAL_CACHE_ACCESSES_sum"], 1)
+for k in ("VALUBusy", "VALUUtilization", "OccupancyPercent", "MemUnitStalled"):
+    if k in c:
+        d[k + "_derived_gfx94x_formula"] = c[k]
 if "kernel_stats" in out and "SQ_INSTS_VALU" in c:
     d["valu_wave_insts_per_s"] = c["SQ_INSTS_VALU"] / (out["kernel_stats"]["avg_ns"] * 1e-9)
 out["derived"] = d
