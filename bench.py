@@ -182,6 +182,62 @@ def time_workload(torch, node, cam, depth, steps, warmup, out=None):
     return dt, n, ms, out
 
 
+def timed_loop_distributed(torch, dist, render_into, h, w, device, steps, warmup, gather_mode, timing=None):
+    """The N > 1 timed region (also run on CPU/gloo by tests/test_distributed_gloo.py with a stub renderer).
+
+    `render_into(buf)` enqueues one frame into the (h, w, 4) float32 tensor `buf`.  W untimed warm-up steps, then
+    EXACTLY `steps` steps bracketed by barrier + device synchronisation on both sides; returns (max over ranks of the
+    elapsed seconds, kernel launches, kernel ms) -- the last two from `timing = (start, read)` when given.
+    gather_mode: "final" (only the last frame is gathered to rank 0, inside the timed region), "every", "none"."""
+    from godot_atmosphere_shader_amd.sharding import FrameGather
+
+    is_cuda = device.type == "cuda"
+
+    def sync():
+        if is_cuda:
+            torch.cuda.synchronize()
+
+    gather = None if gather_mode == "none" else FrameGather(h, w, device, dst=0, depth=2)
+    scratch = torch.empty((h, w, 4), dtype=torch.float32, device=device)
+
+    def step(last):
+        # "final": frames stay resident in this GPU's HBM; only the last one is gathered.  "every": each frame.
+        if gather is None or (gather_mode == "final" and not last):
+            render_into(scratch)
+        else:
+            buf, slot = gather.next_send_buffer()
+            render_into(buf)
+            gather.submit(slot)
+
+    if gather is not None:  # set up the communicator / p2p channels outside the timed region whatever W is
+        buf, slot = gather.next_send_buffer()
+        buf.zero_()
+        gather.submit(slot)
+        gather.finish()
+    for i in range(warmup):
+        step(i == warmup - 1)
+    if gather is not None:
+        gather.finish()
+    sync()
+    dist.barrier()
+    sync()
+    if timing is not None:
+        timing[0]()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i == steps - 1)
+    result = gather.finish() if gather is not None else None
+    sync()
+    dist.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    launches, kernel_ms = timing[1]() if timing is not None else (0, 0.0)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    timed_loop_distributed.last_gathered = result  # (world, h, w, 4) on rank 0 in gather modes, for tests
+    return float(tmax.item()), launches, kernel_ms
+
+
 def main():
     args = parse_args()
     import numpy as np
@@ -223,44 +279,16 @@ def main():
         dt_max = dt
         gather_mode = "none (single GPU)"
     else:
-        from godot_atmosphere_shader_amd.sharding import FrameGather
-
-        gather = None if args.no_gather else FrameGather(h, w, torch.device("cuda", local_rank), dst=0, depth=2)
-        scratch = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
-
         frame = node.prepare_frame(cam)
         stream = torch.cuda.current_stream().cuda_stream
 
-        def step():
-            if gather is None:
-                node.render_prepared(frame, depth.data_ptr(), scratch.data_ptr(), stream)
-            else:
-                buf, slot = gather.next_send_buffer()
-                node.render_prepared(frame, depth.data_ptr(), buf.data_ptr(), stream)
-                gather.submit(slot)
+        def render_into(buf):
+            node.render_prepared(frame, depth.data_ptr(), buf.data_ptr(), stream)
 
-        for _ in range(args.warmup):
-            step()
-        if gather is not None:
-            gather.finish()
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        node.set_timing(True)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        if gather is not None:
-            gather.finish()
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        launches, kernel_ms = node.get_timing()
+        node_timing = (lambda: node.set_timing(True), node.get_timing)
+        dt_max, launches, kernel_ms = timed_loop_distributed(
+            torch, dist, render_into, h, w, torch.device("cuda", local_rank), args.steps, args.warmup, args.gather, node_timing)
         node.set_timing(False)
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt_max = float(tmax.item())
         gather_mode = {"none": "no collective",
                        "final": "one RCCL gather of each rank's last frame to rank 0, inside the timed region",
                        "every": "RCCL gather of every frame to rank 0, 2 frames in flight, inside the timed region"}[args.gather]

@@ -94,3 +94,50 @@ def test_gather_world_size_2(tmp_path, mode):
     mp.spawn(_worker, args=(world, port, mode, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert (tmp_path / f"ok_{mode}_{r}").exists()
+
+
+def _bench_worker(rank, world, port, mode, tmpdir):
+    """Runs bench.py's N > 1 timed region itself (timed_loop_distributed) over gloo with a stub renderer."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+
+        h, w = 6, 5
+        calls = {"n": 0}
+
+        def render_into(buf):
+            calls["n"] += 1
+            buf.fill_(float(100 * rank + calls["n"]))  # frame k of rank r is the constant 100 r + k
+
+        started = []
+        timing = (lambda: started.append(calls["n"]), lambda: (7, 1.5))
+        steps, warmup = 4, 2
+        dt, launches, kernel_ms = bench.timed_loop_distributed(
+            torch, dist, render_into, h, w, torch.device("cpu"), steps, warmup, mode, timing)
+        assert dt > 0 and (launches, kernel_ms) == (7, 1.5)
+        assert calls["n"] == steps + warmup            # exactly K timed + W warm-up frames rendered
+        assert started == [warmup]                      # timing starts after the warm-up steps
+        res = bench.timed_loop_distributed.last_gathered
+        if mode == "none":
+            assert res is None
+        elif rank == 0:
+            assert res.shape == (world, h, w, 4)
+            for r in range(world):                      # the last frame of every rank arrived on rank 0
+                assert torch.all(res[r] == float(100 * r + steps + warmup))
+        else:
+            assert res is None
+        with open(os.path.join(tmpdir, f"ok_bench_{mode}_{rank}"), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["final", "every", "none"])
+def test_bench_distributed_timed_loop_world_size_2(tmp_path, mode):
+    world = 2
+    port = _free_port()
+    mp.spawn(_bench_worker, args=(world, port, mode, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert (tmp_path / f"ok_bench_{mode}_{r}").exists()
