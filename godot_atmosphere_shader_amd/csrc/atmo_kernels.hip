@@ -28,8 +28,13 @@
 
 namespace atmo {
 
+// Workgroup tile in pixels.  16x16 = 4 waves; 16x4 = one wave per workgroup (finer-grained dispatch: shorter tail when
+// heavy cloud tiles and empty-sky tiles mix).  There is no LDS and no barrier, so the choice is purely scheduling.
+#ifndef ATMO_TILE_H
+#define ATMO_TILE_H 16
+#endif
 constexpr int TILE_W = 16;
-constexpr int TILE_H = 16;
+constexpr int TILE_H = ATMO_TILE_H;
 // Pixels of one 64-lane wave inside the 16x16 workgroup tile: WAVE_W x (64 / WAVE_W).  16x4 keeps a wave's
 // float4 stores in 256-byte runs; 8x8 halves that but makes a wave's rays more coherent (tools/ab_build.sh).
 #ifndef ATMO_WAVE_W

@@ -507,3 +507,29 @@ def test_native_host_matches_python_binding(tmp_path):
     assert "atmo_render_kernel<0, 0>" in r.stdout
     got = np.fromfile(tmp_path / "out.bin", dtype=np.float32).reshape(want.shape)
     assert np.array_equal(got, want)
+
+
+def test_render_on_a_side_stream_is_ordered():
+    """atmo_render only enqueues on the caller's stream: a render on a side stream followed by a consumer on the
+    same stream sees the finished frame; the default stream is not involved."""
+    tex = demo_textures(cube_n=64, shape_n=32)
+    cam = S.Camera.from_pose(640, 360, "P_ground")
+    depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
+    node = make_node("clouds_high", tex)
+    ref = node.render(cam, depth).clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    out = torch.zeros_like(ref)
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            node.render(cam, depth, out=out)      # picks up torch's current stream = side
+        total = out.sum()                          # consumer on the same stream
+    side.synchronize()
+    assert torch.equal(out, ref)
+    assert float(total) == float(ref.sum())
+    # explicit stream argument (raw hipStream_t handle)
+    out2 = torch.zeros_like(ref)
+    node.render(cam, depth, out=out2, stream=side.cuda_stream)
+    side.synchronize()
+    assert torch.equal(out2, ref)
+    node.close()
