@@ -95,16 +95,38 @@ def parse_args():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU box exposes
+    256 logical CPUs but limits the container to 16 CPUs' worth of time; more threads than that only get throttled)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0:
+                cores = max(1, min(cores, q // per))
+        except (OSError, ValueError):
+            pass
+    return cores
+
+
 def cpu_baseline(config_name, params, textures, cam, depth_np, lut):
     """The oracle (a port of the GDShader, not the reference itself: Godot is a GPU-only path) timed on this
     host's cores over one full frame of the same workload."""
     from common import CONFIGS, demo_frame
     from oracle.oracle import Oracle
 
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = usable_cores()
     o = Oracle("f32_fast")
     tex = dict(textures, optical_depth=lut)
     frame = demo_frame(cam)
