@@ -91,7 +91,10 @@ def parse_args():
                     help="N>1: 'final' = one RCCL gather of every rank's last frame to rank 0 inside the timed region "
                          "(default: the path has no exchange step, frames stay resident like the inputs); "
                          "'every' = gather every frame, two in flight, overlapped with the next render; 'none' = no collective")
-    ap.add_argument("--also", default="", help="comma-separated extra workloads to time at N=1 (reported under 'extra')")
+    ap.add_argument("--also", default="lut32,shipped8,clouds_high,clouds_high_rm",
+                    help="comma-separated extra workloads timed at N=1 after the headline and reported under 'extra' "
+                         "(SURVEY.md 8d asks for the reference-exact LUT mode and the shipped 8-step shader next to the "
+                         "32x8 headline); '' to skip")
     return ap.parse_args()
 
 

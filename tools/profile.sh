@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof_${WL}_${W}x${H}
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--workload $WL --width $W --height $H --no-cpu-baseline"
+ARGS="--workload $WL --width $W --height $H --no-cpu-baseline --also ,"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 $R/bench.py $ARGS --steps 50 --warmup 5 > $OUT/stats.log 2>&1
 i=0
 for PMC in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
