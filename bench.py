@@ -33,6 +33,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 BYTES_PER_RAY = 20          # 16 B RGBA32F store + 4 B depth load
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+TIMING_EVERY = 4            # HIP events bracket every 4th kernel launch of the timed region (recording costs ~5 us)
 # Measured VALU issue ceilings of MI355X under load (tools/valu_peak.hip, profiles/round1/valu_peak_mi355x.jsonl),
 # wave-instructions per second chip-wide: plain f32 FMA/MUL/ADD and transcendental (exp/sqrt/rsq/rcp).
 VALU_FMA_WINST_PER_S = 8.68e11
@@ -196,7 +197,7 @@ def time_workload(torch, node, cam, depth, steps, warmup, out=None):
     for _ in range(warmup):
         node.render_prepared(frame, dptr, optr, stream)
     torch.cuda.synchronize()
-    node.set_timing(True)
+    node.set_timing(True, every=TIMING_EVERY)
     t0 = time.perf_counter()
     for _ in range(steps):
         node.render_prepared(frame, dptr, optr, stream)
@@ -310,7 +311,7 @@ def main():
         def render_into(buf):
             node.render_prepared(frame, depth.data_ptr(), buf.data_ptr(), stream)
 
-        node_timing = (lambda: node.set_timing(True), node.get_timing)
+        node_timing = (lambda: node.set_timing(True, every=TIMING_EVERY), node.get_timing)
         dt_max, launches, kernel_ms = timed_loop_distributed(
             torch, dist, render_into, h, w, torch.device("cuda", local_rank), args.steps, args.warmup, args.gather, node_timing)
         node.set_timing(False)
@@ -358,6 +359,7 @@ def main():
                 "traffic_source": None if pmc is None else pmc["source"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bytes per launch)",
                 "kernel_avg_ms": kernel_avg_ms,
                 "kernel_launches_timed": launches,
+                "kernel_timing": f"HIP events around every {TIMING_EVERY}th launch of the timed region, on the launch stream",
                 "algorithmic_bytes_per_launch": BYTES_PER_RAY * rays,
                 "note": "path is VALU/transcendental-bound, not HBM-bound (20 B/ray); see DESIGN.md",
             },

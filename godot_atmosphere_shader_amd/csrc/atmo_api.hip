@@ -90,7 +90,8 @@ struct AtmoContext {
     Params p;
     DeviceBuffer lut, blue, shape, cube;
     int lut_w = 0, lut_h = 0, shape_n = 0, cube_n = 0;
-    bool timing = false;
+    int timing = 0;          // 0 off; k >= 1: bracket every k-th launch with HIP events
+    int launch_counter = 0;
     int timed_launches = 0;
     double timed_ms = 0.0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // events not yet read back
@@ -666,13 +667,14 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     }
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->timing) {
+    const bool timed = ctx->timing > 0 && (ctx->launch_counter++ % ctx->timing) == 0;
+    if (timed) {
         HIP_TRY(ctx, hipEventCreate(&e0));
         HIP_TRY(ctx, hipEventCreate(&e1));
         HIP_TRY(ctx, hipEventRecord(e0, s));
     }
     HIP_TRY(ctx, atmo::launch_render(ctx->flags, rc, s));
-    if (ctx->timing) {
+    if (timed) {
         HIP_TRY(ctx, hipEventRecord(e1, s));
         ctx->pending.emplace_back(e0, e1);
     }
@@ -683,7 +685,8 @@ int atmo_set_timing(AtmoContext *ctx, int enable) {
     if (!ctx) return ATMO_E_ARG;
     (void)hipSetDevice(ctx->device);
     drain_timing(ctx);
-    ctx->timing = enable != 0;
+    ctx->timing = enable > 0 ? enable : 0;
+    ctx->launch_counter = 0;
     ctx->timed_launches = 0;
     ctx->timed_ms = 0.0;
     return ATMO_OK;

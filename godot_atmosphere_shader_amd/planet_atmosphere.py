@@ -559,8 +559,10 @@ class PlanetAtmosphere:
         N.check(self._ctx, rc)
 
     # ---- kernel timing (HIP events on the launch stream) ---------------------------------------------
-    def set_timing(self, enable: bool):
-        N.check(self._ctx, self._lib.atmo_set_timing(self._ctx, 1 if enable else 0))
+    def set_timing(self, enable, every: int = 1):
+        """enable: False/0 off; True = bracket every `every`-th launch with HIP events."""
+        k = 0 if not enable else max(1, int(every))
+        N.check(self._ctx, self._lib.atmo_set_timing(self._ctx, k))
 
     def get_timing(self):
         n, ms = C.c_int(0), C.c_double(0.0)

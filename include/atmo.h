@@ -160,8 +160,10 @@ int atmo_render(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev
  */
 int atmo_render_composite(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *scene_rgba_dev, void *stream);
 
-/* Average device time of the last `atmo_render` kernels measured with HIP events on their own stream:
- * enable with atmo_set_timing(ctx, 1); atmo_get_timing returns count and total milliseconds since enabling. */
+/* Device time of `atmo_render` kernels measured with HIP events recorded around the launch on its own stream:
+ * atmo_set_timing(ctx, k): k = 0 off, k >= 1 brackets every k-th launch (k > 1 keeps the ~5 us cost of recording two
+ * events out of most steps); atmo_get_timing returns the number of bracketed launches and their total milliseconds
+ * since enabling (it waits for them). */
 int atmo_set_timing(AtmoContext *ctx, int enable);
 int atmo_get_timing(AtmoContext *ctx, int *launches, double *total_ms);
 
