@@ -533,3 +533,28 @@ def test_render_on_a_side_stream_is_ordered():
     side.synchronize()
     assert torch.equal(out2, ref)
     node.close()
+
+
+def test_render_is_hip_graph_capturable():
+    """atmo_render does no allocation or synchronisation when timing is off, so a render loop can be captured into a
+    HIP graph and replayed (MI355X_MICROARCH.md 'graph-capture restrictions')."""
+    tex = demo_textures(cube_n=64, shape_n=32)
+    cam = S.Camera.from_pose(320, 180, "P_space")
+    depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
+    node = make_node("clouds_high", tex)
+    ref = node.render(cam, depth).clone()
+    torch.cuda.synchronize()
+    frame = node.prepare_frame(cam)
+    out = torch.zeros_like(ref)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(4):
+                node.render_prepared(frame, depth.data_ptr(), out.data_ptr(), side.cuda_stream)
+    torch.cuda.synchronize()
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    node.close()
