@@ -45,8 +45,9 @@ def _lattice(ix, iy, iz, seed):
 
 
 class SeededValueNoise:
-    """Stands for the `Noise` resource: fractal value noise in [-1, 1].  `get_noise_3dv` is the float32 host
-    evaluation (numpy, unfused) of exactly what the device kernel computes."""
+    """Stands for the `Noise` resource: fractal value noise in [-1, 1].  `get_noise_3dv` mirrors the script-callable
+    `Noise.get_noise_3dv` (float32 numpy, the same arithmetic the device kernel performs per texel); cubemap
+    generation itself never goes through it -- `NoiseCubemap._generate_images` launches the kernel."""
 
     def __init__(self, seed: int = 0, frequency: float = 0.01, fractal_octaves: int = 4, fractal_gain: float = 0.5):
         self._listeners = []
@@ -94,28 +95,6 @@ class SeededValueNoise:
             amp = f32(amp * f32(self.fractal_gain))
             freq = f32(freq * f32(2.0))
         return f32(2.0) * (total / norm) - f32(1.0)
-
-
-def texel_directions(resolution: int) -> np.ndarray:
-    """noise_cubemap.gd:110-128 in float32: direction of every texel, (6, res, res, 3)."""
-    f32 = np.float32
-    half = f32(0.5) * f32(resolution)
-    xs = (np.arange(resolution, dtype=np.float32) + f32(0.5)) / half - f32(1.0)
-    ys = ((resolution - np.arange(resolution) - 1).astype(np.float32) + f32(0.5)) / half - f32(1.0)
-    p2y, p2x = np.meshgrid(ys, xs, indexing="ij")
-    vx, vy, vz = np.ones_like(p2x), p2y, -p2x
-    ln = np.sqrt(vx * vx + vy * vy + vz * vz)
-    vx, vy, vz = vx / ln, vy / ln, vz / ln
-    sides = [(vx, vy, vz), (-vx, vy, -vz), (-vz, vx, -vy), (-vz, -vx, vy), (-vz, vy, vx), (vz, vy, -vx)]
-    return np.stack([np.stack(s, axis=-1) for s in sides], axis=0).astype(np.float32)
-
-
-def generate_images_host(resolution, noise: SeededValueNoise, scale) -> np.ndarray:
-    """`_generate_images` evaluated on the host in float32 numpy (what the reference does on the CPU).  Used by the
-    CPU tests as an independent statement of the generator; the product path is the device kernel."""
-    d = texel_directions(resolution) * np.asarray(scale, dtype=np.float32)
-    dens = np.float32(0.5) + np.float32(0.5) * noise.get_noise_3dv(d)
-    return np.clip(dens * np.float32(255.0), 0.0, 255.0).astype(np.uint8)
 
 
 def generate_importable_image(images: np.ndarray) -> np.ndarray:
