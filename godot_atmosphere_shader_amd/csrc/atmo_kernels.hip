@@ -58,6 +58,11 @@ constexpr bool RM_COMPACT = ATMO_RM_COMPACT != 0;
 #ifndef ATMO_U32_OFFSETS
 #define ATMO_U32_OFFSETS 1
 #endif
+// 1: each of the 6 light taps skips its fetches when it lies outside the cloud layer (divergent branch per tap);
+// 0: taps are evaluated branch-free so the six can overlap (tools/ab_build.sh ... -DATMO_RM_TAPS_EARLY_OUT=0)
+#ifndef ATMO_RM_TAPS_EARLY_OUT
+#define ATMO_RM_TAPS_EARLY_OUT 1
+#endif
 // unroll factor of the view-ray loop (lets the LUT gathers of step i+1 issue under the exps of step i)
 #ifndef ATMO_VIEW_UNROLL
 #define ATMO_VIEW_UNROLL 1
@@ -384,11 +389,14 @@ __device__ __forceinline__ float4 march_atmosphere_v1(const RenderConsts &rc, V3
 // ---- clouds ----------------------------------------------------------------------------------------
 
 // get_density_full with CLOUDS_ALWAYS_LOW_QUALITY (detail = 0.5).  `hr` = height ratio from the exact chain.
+// EARLY_OUT = false evaluates the fetches unconditionally (result is the same: hc = 0 forces the clamp to 0), which
+// removes the divergent branch so that several independent taps can be interleaved by the scheduler.
+template <bool EARLY_OUT = true>
 __device__ __forceinline__ float cloud_density(const RenderConsts &rc, float px, float py, float pz, float hr) {
 #pragma clang fp contract(fast)
     const float t = 2.0f * hr - 1.0f;
     const float hc = fmaxf(1.0f - t * t, 0.0f);
-    if (!(hc > 0.0f)) return 0.0f;  // outside the layer: (..)*0*50-20 clamps to 0, skip the fetches
+    if (EARLY_OUT && !(hc > 0.0f)) return 0.0f;  // outside the layer: (..)*0*50-20 clamps to 0, skip the fetches
     float coverage = 1.0f;
     if (rc.cube != nullptr) {
         const float qx = rc.cov_rot[0] * px + rc.cov_rot[2] * pz;
@@ -421,7 +429,7 @@ __device__ __forceinline__ float light_raymarched(const RenderConsts &rc, float 
         const float qx = px + k * sx, qy = py + k * sy, qz = pz + k * sz;
         float r, hr;
         cloud_height(rc, qx, qy, qz, r, hr);
-        const float d = cloud_density(rc, qx, qy, qz, hr);
+        const float d = cloud_density<ATMO_RM_TAPS_EARLY_OUT != 0>(rc, qx, qy, qz, hr);
         sum = __builtin_fmaf(d, rc.rm_weight[i], sum);  // step_len_i * density_scale  [host]
     }
     const float alpha = 1.0f - hw_exp2(-sum * LOG2E);
