@@ -92,6 +92,9 @@ def parse_args():
                     help="N>1: 'final' = one RCCL gather of every rank's last frame to rank 0 inside the timed region "
                          "(default: the path has no exchange step, frames stay resident like the inputs); "
                          "'every' = gather every frame, two in flight, overlapped with the next render; 'none' = no collective")
+    ap.add_argument("--shard", default="viewports", choices=["viewports", "bands"],
+                    help="N>1: 'viewports' = one full viewport per GPU (weak scaling, default); 'bands' = ONE viewport cut "
+                         "into hit-balanced row bands, one per GPU, gathered in place into the frame on rank 0 (strong scaling)")
     ap.add_argument("--also", default="lut32,shipped8,clouds_high,clouds_high_rm",
                     help="comma-separated extra workloads timed at N=1 after the headline and reported under 'extra' "
                          "(SURVEY.md 8d asks for the reference-exact LUT mode and the shipped 8-step shader next to the "
@@ -208,7 +211,7 @@ def time_workload(torch, node, cam, depth, steps, warmup, out=None):
     return dt, n, ms, out
 
 
-def timed_loop_distributed(torch, dist, render_into, h, w, device, steps, warmup, gather_mode, timing=None):
+def timed_loop_distributed(torch, dist, render_into, h, w, device, steps, warmup, gather_mode, timing=None, bands=None):
     """The N > 1 timed region (also run on CPU/gloo by tests/test_distributed_gloo.py with a stub renderer).
 
     `render_into(buf)` enqueues one frame into the (h, w, 4) float32 tensor `buf`.  W untimed warm-up steps, then
@@ -223,8 +226,9 @@ def timed_loop_distributed(torch, dist, render_into, h, w, device, steps, warmup
         if is_cuda:
             torch.cuda.synchronize()
 
-    gather = None if gather_mode == "none" else FrameGather(h, w, device, dst=0, depth=2)
-    scratch = torch.empty((h, w, 4), dtype=torch.float32, device=device)
+    gather = None if gather_mode == "none" else FrameGather(h, w, device, dst=0, depth=2, bands=bands)
+    rows = h if bands is None else bands[dist.get_rank()][1] - bands[dist.get_rank()][0]
+    scratch = torch.empty((max(rows, 1), w, 4), dtype=torch.float32, device=device)[:rows]
 
     def step(last):
         # "final": frames stay resident in this GPU's HBM; only the last one is gathered.  "every": each frame.
@@ -292,7 +296,8 @@ def main():
     config_name, desc = WORKLOADS[args.workload]
     textures = demo_textures()
     params = demo_params()
-    pose = args.pose if (world == 1 or rank == 0) else S.orbit_pose(rank, world)
+    strong = args.shard == "bands" and (world > 1 or os.environ.get("ATMO_BENCH_FORCE_DIST") == "1")
+    pose = args.pose if (world == 1 or rank == 0 or strong) else S.orbit_pose(rank, world)
     cam = S.Camera.from_pose(w, h, pose)
     depth_np = S.depth_ground_sphere(cam)
     depth = torch.from_numpy(depth_np).cuda()
@@ -305,25 +310,40 @@ def main():
         dt_max = dt
         gather_mode = "none (single GPU)"
     else:
-        frame = node.prepare_frame(cam)
+        bands = None
+        if strong:
+            # one frame, row bands balanced by the number of shell-hitting pixels per row (analytic ray/sphere test)
+            from godot_atmosphere_shader_amd.sharding import balanced_row_bands, band_rect
+            d = cam.pixel_view_dirs()
+            d /= np.linalg.norm(d, axis=-1, keepdims=True)
+            c = (cam.view @ np.array([0.0, 0.0, 0.0, 1.0]))[:3]
+            bq = d @ c
+            hit_rows = ((S.DEMO_PLANET_RADIUS + S.DEMO_ATMOSPHERE_HEIGHT) ** 2 - (c @ c - bq * bq) >= 0).sum(axis=1)
+            bands = balanced_row_bands(hit_rows + 0.02 * w, world)  # + a small per-row cost for the miss pixels
+            frame = node.prepare_frame(cam, rect=band_rect(w, bands[rank]))
+        else:
+            frame = node.prepare_frame(cam)
         stream = torch.cuda.current_stream().cuda_stream
 
         def render_into(buf):
-            node.render_prepared(frame, depth.data_ptr(), buf.data_ptr(), stream)
+            if buf.numel():
+                node.render_prepared(frame, depth.data_ptr(), buf.data_ptr(), stream)
 
         node_timing = (lambda: node.set_timing(True, every=TIMING_EVERY), node.get_timing)
         dt_max, launches, kernel_ms = timed_loop_distributed(
-            torch, dist, render_into, h, w, torch.device("cuda", local_rank), args.steps, args.warmup, args.gather, node_timing)
+            torch, dist, render_into, h, w, torch.device("cuda", local_rank), args.steps, args.warmup, args.gather, node_timing,
+            bands=bands)
         node.set_timing(False)
         gather_mode = {"none": "no collective",
                        "final": "one RCCL gather of each rank's last frame to rank 0, inside the timed region",
                        "every": "RCCL gather of every frame to rank 0, 2 frames in flight, inside the timed region"}[args.gather]
 
     if rank == 0:
-        value = world * rays * args.steps / dt_max / 1e6
-        pmc = pmc_summary(args.workload, w, h)
+        value = (1 if strong else world) * rays * args.steps / dt_max / 1e6
+        pmc = None if strong else pmc_summary(args.workload, w, h)
         kernel_avg_ms = kernel_ms / max(launches, 1)
-        achieved_gbs = BYTES_PER_RAY * rays / (kernel_avg_ms * 1e-3) / 1e9
+        launch_rays = rays if not strong else w * (bands[0][1] - bands[0][0])  # rank 0's kernel shades its band only
+        achieved_gbs = BYTES_PER_RAY * launch_rays / (kernel_avg_ms * 1e-3) / 1e9
         frame = node.render(cam, depth)
         torch.cuda.synchronize()
         hit_fraction = float((frame.abs().sum(dim=-1) > 0).float().mean().item())
@@ -336,7 +356,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -347,6 +367,7 @@ def main():
                 "hit_fraction": hit_fraction,
                 "mrays_per_s_hit_only": value * hit_fraction,
                 "gather": gather_mode,
+                "shard": ("one viewport in hit-balanced row bands: " + str(bands)) if strong else "one viewport per GPU",
                 "kernel": node.kernel_name,
             },
             "roofline": {
@@ -360,7 +381,7 @@ def main():
                 "kernel_avg_ms": kernel_avg_ms,
                 "kernel_launches_timed": launches,
                 "kernel_timing": f"HIP events around every {TIMING_EVERY}th launch of the timed region, on the launch stream",
-                "algorithmic_bytes_per_launch": BYTES_PER_RAY * rays,
+                "algorithmic_bytes_per_launch": BYTES_PER_RAY * launch_rays,
                 "note": "path is VALU/transcendental-bound, not HBM-bound (20 B/ray); see DESIGN.md",
             },
         }

@@ -114,13 +114,23 @@ def _bench_worker(rank, world, port, mode, tmpdir):
         started = []
         timing = (lambda: started.append(calls["n"]), lambda: (7, 1.5))
         steps, warmup = 4, 2
+        bands = None
+        if mode == "bands":   # strong scaling: one frame in unequal row bands, gathered in place
+            bands = [(0, 2), (2, 6)]
+            mode = "every"
         dt, launches, kernel_ms = bench.timed_loop_distributed(
-            torch, dist, render_into, h, w, torch.device("cpu"), steps, warmup, mode, timing)
+            torch, dist, render_into, h, w, torch.device("cpu"), steps, warmup, mode, timing, bands=bands)
         assert dt > 0 and (launches, kernel_ms) == (7, 1.5)
         assert calls["n"] == steps + warmup            # exactly K timed + W warm-up frames rendered
         assert started == [warmup]                      # timing starts after the warm-up steps
         res = bench.timed_loop_distributed.last_gathered
-        if mode == "none":
+        if bands is not None:
+            if rank == 0:
+                assert res.shape == (h, w, 4)
+                for r, (y0, y1) in enumerate(bands):
+                    assert torch.all(res[y0:y1] == float(100 * r + steps + warmup))
+            mode = "bands"
+        elif mode == "none":
             assert res is None
         elif rank == 0:
             assert res.shape == (world, h, w, 4)
@@ -134,7 +144,7 @@ def _bench_worker(rank, world, port, mode, tmpdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["final", "every", "none"])
+@pytest.mark.parametrize("mode", ["final", "every", "none", "bands"])
 def test_bench_distributed_timed_loop_world_size_2(tmp_path, mode):
     world = 2
     port = _free_port()
