@@ -558,3 +558,23 @@ def test_render_is_hip_graph_capturable():
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
     node.close()
+
+
+@pytest.mark.parametrize("config_name,pose", [("no_clouds_32x8_direct", "P_space"), ("clouds_high_rm", "P_ground"), ("v1_clouds", "P_space")])
+def test_parity_full_resolution_1080p(oracle32, config_name, pose):
+    """BASELINE's framebuffer size against the oracle directly (2 M rays; the oracle runs on all host cores).
+    tools/report_errors.py 1920 1080 sweeps all 9 variants x 5 poses: worst 5.1e-5."""
+    import os
+
+    w, h = 1920, 1080
+    tex, params = demo_textures(), demo_params()
+    cam = S.Camera.from_pose(w, h, pose)
+    depth = S.depth_ground_sphere(cam)
+    node = make_node(config_name, tex, params)
+    got = _gpu_render(node, cam, depth)
+    lut = node.read_optical_depth() if _uses_lut(config_name) else None
+    node.close()
+    want, hits = oracle32.render(params, dict(tex, optical_depth=lut), CONFIGS[config_name][1], demo_frame(cam), depth,
+                                 nthreads=min(32, os.cpu_count() or 1))
+    assert np.array_equal(np.all(got == 0.0, axis=-1), np.all(want == 0.0, axis=-1))
+    assert np.abs(got - want).max() <= TOL
