@@ -63,6 +63,11 @@ constexpr bool RM_COMPACT = ATMO_RM_COMPACT != 0;
 #ifndef ATMO_RM_TAPS_EARLY_OUT
 #define ATMO_RM_TAPS_EARLY_OUT 1
 #endif
+// 1: the coverage-cubemap fetch reproduces the scalar fp32 rounding of its quotient and bilinear filter (its error is
+// amplified x135 by the density ramp: mix(-1.2,1.5,cov) * 50); costs ~13 VALU per density evaluation
+#ifndef ATMO_CUBE_EXACT
+#define ATMO_CUBE_EXACT 0
+#endif
 // unroll factor of the view-ray loop (lets the LUT gathers of step i+1 issue under the exps of step i)
 #ifndef ATMO_VIEW_UNROLL
 #define ATMO_VIEW_UNROLL 1
@@ -215,6 +220,23 @@ __device__ __forceinline__ float shape_sample(const uint32_t *__restrict__ fp, i
     return (c0 + (c1 - c0) * fz) * (1.0f / 255.0f);
 }
 
+// Bilinear filter of four UNORM8 texels exactly as a scalar fp32 evaluation of  mix(mix(t00,t10,fx), mix(t01,t11,fx), fy),
+// t = byte / 255 (IEEE), mix(a,b,t) = a*(1-t) + b*t  would round it.  byte * RN(1/255) differs from byte / 255 for 126 of the
+// 256 bytes; one Markstein correction makes all 256 exact (checked exhaustively).  No contraction in this function.
+__device__ __forceinline__ float unorm8_exact(float b) {
+    const float rc = 1.0f / 255.0f;
+    const float q = b * rc;
+    return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, b), rc, q);
+}
+__device__ __forceinline__ float bilinear_unorm8_exact(uint32_t w, float fx, float fy) {
+    const float t00 = unorm8_exact(ub0(w)), t10 = unorm8_exact(ub1(w));
+    const float t01 = unorm8_exact(ub2(w)), t11 = unorm8_exact(ub3(w));
+    const float gx = 1.0f - fx, gy = 1.0f - fy;
+    const float a = t00 * gx + t10 * fx;
+    const float b = t01 * gx + t11 * fx;
+    return a * gy + b * fy;
+}
+
 // texture(u_cloud_coverage_cubemap, d).r : LOD 0, bilinear, seamless.
 // Face selection and the in-face coordinates come from the hardware cube instructions (v_cubeid/sc/tc/ma_f32):
 // same table and tie-break as Vulkan (z over y over x), ma = 2 * major axis value.
@@ -229,6 +251,10 @@ __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, in
     float qs = sc * r, qt = tc * r;
     qs = fmaf(fmaf(-qs, ma, sc), r, qs);
     qt = fmaf(fmaf(-qt, ma, tc), r, qt);
+#if ATMO_CUBE_EXACT
+    qs = fmaf(fmaf(-qs, ma, sc), r, qs);  // second correction: the quotient is now the IEEE one (up to rare ties)
+    qt = fmaf(fmaf(-qt, ma, tc), r, qt);
+#endif
     // (0.5*(q + 1))*n - 0.5 with the reference's roundings: q + 1 rounds, the scalings are exact for power-of-two n
     const float hn = 0.5f * (float)n;
     const float x = fmaf(qs + 1.0f, hn, -0.5f);
@@ -246,10 +272,14 @@ __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, in
     const uint32_t w = fp[((int)fid * stride + j) * stride + i];
 #endif
 #endif
+#if ATMO_CUBE_EXACT
+    return bilinear_unorm8_exact(w, fx, fy);
+#else
     const float t00 = ub0(w), t10 = ub1(w), t01 = ub2(w), t11 = ub3(w);
     const float a = t00 + (t10 - t00) * fx;
     const float b = t01 + (t11 - t01) * fx;
     return (a + (b - a) * fy) * (1.0f / 255.0f);
+#endif
 }
 
 // ---- compute_atmosphere_v2 -----------------------------------------------------------------------
