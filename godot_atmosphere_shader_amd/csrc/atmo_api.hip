@@ -681,6 +681,14 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     return ATMO_OK;
 }
 
+int atmo_set_precision(AtmoContext *ctx, int mode) {
+    if (!ctx) return ATMO_E_ARG;
+    if (mode != 0 && mode != 1) return fail(ctx, ATMO_E_ARG, "atmo_set_precision: mode must be 0 (fast) or 1 (precise cloud density)");
+    if (mode == 1 && (ctx->flags & atmo::KF_CLOUDS)) ctx->flags |= atmo::KF_PRECISE;  // only the cloud kernels have a precise form
+    else ctx->flags &= ~atmo::KF_PRECISE;
+    return ATMO_OK;
+}
+
 int atmo_set_timing(AtmoContext *ctx, int enable) {
     if (!ctx) return ATMO_E_ARG;
     (void)hipSetDevice(ctx->device);

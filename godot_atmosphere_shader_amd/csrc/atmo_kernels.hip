@@ -68,6 +68,7 @@ constexpr bool RM_COMPACT = ATMO_RM_COMPACT != 0;
 #ifndef ATMO_CUBE_EXACT
 #define ATMO_CUBE_EXACT 0
 #endif
+
 // unroll factor of the view-ray loop (lets the LUT gathers of step i+1 issue under the exps of step i)
 #ifndef ATMO_VIEW_UNROLL
 #define ATMO_VIEW_UNROLL 1
@@ -182,7 +183,10 @@ __device__ __forceinline__ float lut_sample_xy(const float *__restrict__ lut, in
     return a + (b - a) * fy;
 }
 
-// texture(u_cloud_shape_texture, p).r : trilinear, repeat, R8
+__device__ __forceinline__ float trilinear_unorm8_exact(uint32_t w0, uint32_t w1, float fx, float fy, float fz);
+
+// texture(u_cloud_shape_texture, p).r : trilinear, repeat, R8.  PRECISE: exact UNORM8 conversions + unfused mixes.
+template <bool PRECISE>
 __device__ __forceinline__ float shape_sample(const uint32_t *__restrict__ fp, int n, float px, float py, float pz) {
 #pragma clang fp contract(fast)
     const float nf = (float)n;
@@ -209,6 +213,7 @@ __device__ __forceinline__ float shape_sample(const uint32_t *__restrict__ fp, i
     const uint32_t w1 = fp[(k1 * n + j0) * n + i0];
 #endif
 #endif
+    if (PRECISE) return trilinear_unorm8_exact(w0, w1, fx, fy, fz);
     const float a00 = ub0(w0), a10 = ub1(w0), a01 = ub2(w0), a11 = ub3(w0);
     const float b00 = ub0(w1), b10 = ub1(w1), b01 = ub2(w1), b11 = ub3(w1);
     const float c00 = a00 + (a10 - a00) * fx;
@@ -237,9 +242,21 @@ __device__ __forceinline__ float bilinear_unorm8_exact(uint32_t w, float fx, flo
     return a * gy + b * fy;
 }
 
+__device__ __forceinline__ float trilinear_unorm8_exact(uint32_t w0, uint32_t w1, float fx, float fy, float fz) {
+    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
+    const float c00 = unorm8_exact(ub0(w0)) * gx + unorm8_exact(ub1(w0)) * fx;
+    const float c10 = unorm8_exact(ub2(w0)) * gx + unorm8_exact(ub3(w0)) * fx;
+    const float c01 = unorm8_exact(ub0(w1)) * gx + unorm8_exact(ub1(w1)) * fx;
+    const float c11 = unorm8_exact(ub2(w1)) * gx + unorm8_exact(ub3(w1)) * fx;
+    const float c0 = c00 * gy + c10 * fy;
+    const float c1 = c01 * gy + c11 * fy;
+    return c0 * gz + c1 * fz;
+}
+
 // texture(u_cloud_coverage_cubemap, d).r : LOD 0, bilinear, seamless.
 // Face selection and the in-face coordinates come from the hardware cube instructions (v_cubeid/sc/tc/ma_f32):
 // same table and tie-break as Vulkan (z over y over x), ma = 2 * major axis value.
+template <bool PRECISE>
 __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, int n, float dx, float dy, float dz) {
 #pragma clang fp contract(fast)
     const float fid = __builtin_amdgcn_cubeid(dx, dy, dz);
@@ -251,10 +268,10 @@ __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, in
     float qs = sc * r, qt = tc * r;
     qs = fmaf(fmaf(-qs, ma, sc), r, qs);
     qt = fmaf(fmaf(-qt, ma, tc), r, qt);
-#if ATMO_CUBE_EXACT
-    qs = fmaf(fmaf(-qs, ma, sc), r, qs);  // second correction: the quotient is now the IEEE one (up to rare ties)
-    qt = fmaf(fmaf(-qt, ma, tc), r, qt);
-#endif
+    if (PRECISE || ATMO_CUBE_EXACT) {
+        qs = fmaf(fmaf(-qs, ma, sc), r, qs);  // second correction: the quotient is now the IEEE one (up to rare ties)
+        qt = fmaf(fmaf(-qt, ma, tc), r, qt);
+    }
     // (0.5*(q + 1))*n - 0.5 with the reference's roundings: q + 1 rounds, the scalings are exact for power-of-two n
     const float hn = 0.5f * (float)n;
     const float x = fmaf(qs + 1.0f, hn, -0.5f);
@@ -272,14 +289,11 @@ __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, in
     const uint32_t w = fp[((int)fid * stride + j) * stride + i];
 #endif
 #endif
-#if ATMO_CUBE_EXACT
-    return bilinear_unorm8_exact(w, fx, fy);
-#else
+    if (PRECISE || ATMO_CUBE_EXACT) return bilinear_unorm8_exact(w, fx, fy);
     const float t00 = ub0(w), t10 = ub1(w), t01 = ub2(w), t11 = ub3(w);
     const float a = t00 + (t10 - t00) * fx;
     const float b = t01 + (t11 - t01) * fx;
     return (a + (b - a) * fy) * (1.0f / 255.0f);
-#endif
 }
 
 // ---- compute_atmosphere_v2 -----------------------------------------------------------------------
@@ -418,11 +432,34 @@ __device__ __forceinline__ float4 march_atmosphere_v1(const RenderConsts &rc, V3
 
 // ---- clouds ----------------------------------------------------------------------------------------
 
-// get_density_full with CLOUDS_ALWAYS_LOW_QUALITY (detail = 0.5).  `hr` = height ratio from the exact chain.
-// EARLY_OUT = false evaluates the fetches unconditionally (result is the same: hc = 0 forces the clamp to 0), which
-// removes the divergent branch so that several independent taps can be interleaved by the scheduler.
-template <bool EARLY_OUT = true>
-__device__ __forceinline__ float cloud_density(const RenderConsts &rc, float px, float py, float pz, float hr) {
+// Precise mode (atmo_set_precision(ctx, 1)): the whole density expression in the reference's operation order, unfused,
+// with exact UNORM8 conversions and filters -- the density ramp (x50) then sees the same X as a scalar fp32 evaluation,
+// bit for bit, and the cloud variants' error drops to the atmosphere's (profiles/round1/ab_clouds_exact.txt); -15 % speed.
+template <bool EARLY_OUT>
+__device__ __forceinline__ float cloud_density_precise(const RenderConsts &rc, float px, float py, float pz, float hr) {
+    const float t = 2.0f * hr - 1.0f;
+    const float hc = fmaxf(1.0f - t * t, 0.0f);
+    if (EARLY_OUT && !(hc > 0.0f)) return 0.0f;
+    float coverage = 1.0f;
+    if (rc.cube != nullptr) {
+        const float qx = rc.cov_rot[0] * px + rc.cov_rot[2] * pz;
+        const float qz = rc.cov_rot[1] * px + rc.cov_rot[3] * pz;
+        coverage = cube_sample<true>(rc.cube, rc.cube_n, qx, py, qz);
+    }
+    coverage = coverage - 0.25f * hr + rc.coverage_bias;
+    const float s = rc.shape_scale;
+    const float tex = shape_sample<true>(rc.shape, rc.shape_n, px * s, py * s, pz * s);
+    float shape = 0.5f * (1.0f - rc.shape_factor) + tex * rc.shape_factor;
+    if (rc.shape_invert) shape = 1.0f - shape;
+    const float m = -1.2f * (1.0f - coverage) + 1.5f * coverage;
+    float density = (shape - 0.1f + m) * hc;
+    density = density * 50.0f - 20.0f;
+    return fminf(fmaxf(density, 0.0f), 1.0f);
+}
+
+// Fast mode (default): fused arithmetic after the exact height chain.
+template <bool EARLY_OUT>
+__device__ __forceinline__ float cloud_density_fast(const RenderConsts &rc, float px, float py, float pz, float hr) {
 #pragma clang fp contract(fast)
     const float t = 2.0f * hr - 1.0f;
     const float hc = fmaxf(1.0f - t * t, 0.0f);
@@ -431,14 +468,22 @@ __device__ __forceinline__ float cloud_density(const RenderConsts &rc, float px,
     if (rc.cube != nullptr) {
         const float qx = rc.cov_rot[0] * px + rc.cov_rot[2] * pz;
         const float qz = rc.cov_rot[1] * px + rc.cov_rot[3] * pz;
-        coverage = cube_sample(rc.cube, rc.cube_n, qx, py, qz);
+        coverage = cube_sample<false>(rc.cube, rc.cube_n, qx, py, qz);
     }
     coverage = coverage - 0.25f * hr + rc.coverage_bias;
     const float s = rc.shape_scale;
-    float shape = mixf(0.5f, shape_sample(rc.shape, rc.shape_n, px * s, py * s, pz * s), rc.shape_factor);
+    float shape = mixf(0.5f, shape_sample<false>(rc.shape, rc.shape_n, px * s, py * s, pz * s), rc.shape_factor);
     if (rc.shape_invert) shape = 1.0f - shape;
     const float density = (shape - 0.1f + mixf(-1.2f, 1.5f, coverage)) * hc;
     return sat(density * 50.0f - 20.0f);
+}
+
+// get_density_full with CLOUDS_ALWAYS_LOW_QUALITY (detail = 0.5).  `hr` = height ratio from the exact chain.
+// EARLY_OUT = false evaluates the fetches unconditionally (result is the same: hc = 0 forces the clamp to 0), which
+// removes the divergent branch so that several independent taps can be interleaved by the scheduler.
+template <bool EARLY_OUT, bool PRECISE>
+__device__ __forceinline__ float cloud_density(const RenderConsts &rc, float px, float py, float pz, float hr) {
+    return PRECISE ? cloud_density_precise<EARLY_OUT>(rc, px, py, pz, hr) : cloud_density_fast<EARLY_OUT>(rc, px, py, pz, hr);
 }
 
 // exact |p| and (|p| - bottom) / thickness, as a scalar fp32 evaluation would produce them
@@ -449,6 +494,7 @@ __device__ __forceinline__ void cloud_height(const RenderConsts &rc, float px, f
 
 // get_light_raymarched (cloud_funcs.gdshaderinc:104-151): 6 density taps towards the sun.
 // 1 - prod(exp(-d_i)) = 1 - exp(-sum d_i): one exp instead of six.
+template <bool PRECISE>
 __device__ __forceinline__ float light_raymarched(const RenderConsts &rc, float px, float py, float pz, float hr0,
                                                   float sx, float sy, float sz) {
     float sum = 0.0f;
@@ -459,7 +505,7 @@ __device__ __forceinline__ float light_raymarched(const RenderConsts &rc, float 
         const float qx = px + k * sx, qy = py + k * sy, qz = pz + k * sz;
         float r, hr;
         cloud_height(rc, qx, qy, qz, r, hr);
-        const float d = cloud_density<ATMO_RM_TAPS_EARLY_OUT != 0>(rc, qx, qy, qz, hr);
+        const float d = cloud_density<ATMO_RM_TAPS_EARLY_OUT != 0, PRECISE>(rc, qx, qy, qz, hr);
         sum = __builtin_fmaf(d, rc.rm_weight[i], sum);  // step_len_i * density_scale  [host]
     }
     const float alpha = 1.0f - hw_exp2(-sum * LOG2E);
@@ -467,7 +513,7 @@ __device__ __forceinline__ float light_raymarched(const RenderConsts &rc, float 
 }
 
 // raymarch_cloud (cloud_funcs.gdshaderinc:175-247).  Returns (total_light, alpha).
-template <bool RM>
+template <bool RM, bool PRECISE>
 __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m, float t_begin, float t_end, float jitter) {
     const int steps = rc.cloud_steps;
     // exact: positions
@@ -502,7 +548,7 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
         float r = 0.0f, hr = 0.0f, density = 0.0f;
         while (i < steps) {
             cloud_height(rc, px, py, pz, r, hr);
-            density = cloud_density(rc, px, py, pz, hr);
+            density = cloud_density<true, PRECISE>(rc, px, py, pz, hr);
             if (RM_COMPACT && RM) {
                 if (density > 0.0f) break;  // a zero-density sample contributes exactly nothing: keep searching
                 px = px + ddx; py = py + ddy; pz = pz + ddz;  // exact: pos += ray_dir * step_len
@@ -518,7 +564,7 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
 #pragma clang fp contract(fast)
             float light;
             if (RM) {
-                light = light_raymarched(rc, px, py, pz, hr, sx, sy, sz);
+                light = light_raymarched<PRECISE>(rc, px, py, pz, hr, sx, sy, sz);
             } else {
                 light = fmaf(p16, one_minus_alpha, hr);
             }
@@ -549,6 +595,7 @@ __global__ __launch_bounds__(TILE_W *TILE_H) void atmo_render_kernel(const Rende
     constexpr bool RM = (FLAGS & KF_CLOUD_LIGHT_RM) != 0;
     constexpr bool DIRECT = (FLAGS & KF_LIGHT_DIRECT) != 0;
     constexpr bool LITE = (FLAGS & KF_LITE) != 0;
+    constexpr bool PRECISE = (FLAGS & KF_PRECISE) != 0;
 
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
     constexpr int WAVES_X = TILE_W / (WAVE_W > TILE_W ? TILE_W : WAVE_W);
@@ -624,7 +671,7 @@ __global__ __launch_bounds__(TILE_W *TILE_H) void atmo_render_kernel(const Rende
                 dir_m.x = M[0] * dir.x + M[4] * dir.y + M[8] * dir.z;
                 dir_m.y = M[1] * dir.x + M[5] * dir.y + M[9] * dir.z;
                 dir_m.z = M[2] * dir.x + M[6] * dir.y + M[10] * dir.z;
-                const float2 rr = march_clouds<RM>(rc, dir_m, c0, c1, jitter);
+                const float2 rr = march_clouds<RM, PRECISE>(rc, dir_m, c0, c1, jitter);
                 {
 #pragma clang fp contract(fast)
                     const float cl = rr.x, ca = rr.y;
@@ -830,6 +877,13 @@ hipError_t launch_render(int flags, const RenderConsts &rc, hipStream_t stream) 
     case KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT: return launch_direct<KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT>(rc, stream);
     case KF_LITE: return launch_t<KF_LITE, 0>(rc, stream);
     case KF_LITE | KF_CLOUDS: return launch_t<KF_LITE | KF_CLOUDS, 0>(rc, stream);
+    // precise cloud density (atmo_set_precision)
+    case KF_PRECISE | KF_CLOUDS: return launch_t<KF_PRECISE | KF_CLOUDS, 0>(rc, stream);
+    case KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT: return launch_direct<KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT>(rc, stream);
+    case KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM: return launch_t<KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM, 0>(rc, stream);
+    case KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT:
+        return launch_direct<KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT>(rc, stream);
+    case KF_PRECISE | KF_LITE | KF_CLOUDS: return launch_t<KF_PRECISE | KF_LITE | KF_CLOUDS, 0>(rc, stream);
     default: return hipErrorInvalidValue;
     }
 }
@@ -845,6 +899,11 @@ const char *render_kernel_name(int flags, int light_steps) {
     case KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT: return u8 ? "atmo_render_kernel<7, 8>" : "atmo_render_kernel<7, 0>";
     case KF_LITE: return "atmo_render_kernel<8, 0>";
     case KF_LITE | KF_CLOUDS: return "atmo_render_kernel<9, 0>";
+    case KF_PRECISE | KF_CLOUDS: return "atmo_render_kernel<17, 0>";
+    case KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT: return u8 ? "atmo_render_kernel<21, 8>" : "atmo_render_kernel<21, 0>";
+    case KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM: return "atmo_render_kernel<19, 0>";
+    case KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT: return u8 ? "atmo_render_kernel<23, 8>" : "atmo_render_kernel<23, 0>";
+    case KF_PRECISE | KF_LITE | KF_CLOUDS: return "atmo_render_kernel<25, 0>";
     default: return "?";
     }
 }

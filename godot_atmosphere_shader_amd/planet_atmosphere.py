@@ -197,13 +197,15 @@ class PlanetAtmosphere:
     _shader_params_affecting_optical_depth = {"u_density": True}  # planet_atmosphere.gd:79-81
 
     def __init__(self, device: int = 0, light_mode: str = "lut", light_steps: int = 0,
-                 view_steps: int | None = None, cloud_steps: int | None = None, blue_noise=None):
+                 view_steps: int | None = None, cloud_steps: int | None = None, blue_noise=None,
+                 precise_clouds: bool = False):
         self._lib = N.load()
         self._device = int(device)
         self._light_mode = {"lut": N.LIGHT_LUT, "direct": N.LIGHT_DIRECT}[light_mode]
         self._light_steps = int(light_steps)
         self._view_steps_override = view_steps    # macro override of ATMOSPHERE_RAYMARCH_STEPS
         self._cloud_steps_override = cloud_steps  # macro override of CLOUDS_MAX_RAYMARCH_STEPS
+        self._precise_clouds = bool(precise_clouds)  # atmo_set_precision: bit-faithful cloud density, ~15 % slower
         self._ctx = C.c_void_p()
         self._planet_radius = 1.0
         self._atmosphere_height = 0.1
@@ -238,6 +240,7 @@ class PlanetAtmosphere:
         rc = self._lib.atmo_create(self._device, sh.variant, vs, cs, self._light_mode, self._light_steps, C.byref(ctx))
         N.check(None, rc)
         self._ctx = ctx
+        N.check(ctx, self._lib.atmo_set_precision(ctx, 1 if self._precise_clouds else 0))
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:

@@ -51,12 +51,12 @@ def demo_frame(cam, rect=None):
     return make_frame(cam, np.eye(4), S.DEMO_SUN_POSITION, 0.0, rect)
 
 
-def make_node(config_name, textures, params=None, device=0):
+def make_node(config_name, textures, params=None, device=0, **extra):
     """A PlanetAtmosphere set up like the demo scene for one of CONFIGS."""
     from godot_atmosphere_shader_amd import PlanetAtmosphere, Transform2D, load_shader
 
     shader, _, kw = CONFIGS[config_name]
-    node = PlanetAtmosphere(device=device, blue_noise=textures["blue_noise"], **kw)
+    node = PlanetAtmosphere(device=device, blue_noise=textures["blue_noise"], **kw, **extra)
     node.custom_shader = load_shader(shader)
     params = params or demo_params()
     node.planet_radius = params["u_planet_radius"]
