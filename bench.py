@@ -95,7 +95,7 @@ def parse_args():
     ap.add_argument("--shard", default="viewports", choices=["viewports", "bands"],
                     help="N>1: 'viewports' = one full viewport per GPU (weak scaling, default); 'bands' = ONE viewport cut "
                          "into hit-balanced row bands, one per GPU, gathered in place into the frame on rank 0 (strong scaling)")
-    ap.add_argument("--also", default="lut32,shipped8,clouds_high,clouds_high_rm",
+    ap.add_argument("--also", default="lut32,shipped8,clouds_high,clouds_high_rm,noise_cubemap",
                     help="comma-separated extra workloads timed at N=1 after the headline and reported under 'extra' "
                          "(SURVEY.md 8d asks for the reference-exact LUT mode and the shipped 8-step shader next to the "
                          "32x8 headline); '' to skip")
