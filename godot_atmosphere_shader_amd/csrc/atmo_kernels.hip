@@ -332,18 +332,19 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
     for (int i = 0; i < steps; ++i) {
         const float r2 = ox * ox + oy * oy + oz * oz;
         const float bdot = ox * sx + oy * sy + oz * sz;
-        const float inv_r = hw_rsq(r2);
-        const float r = r2 * inv_r;
+        // LUT mode needs 1/r for the cosine; the direct light march only needs r
+        const float inv_r = DIRECT ? 0.0f : hw_rsq(r2);
+        const float r = DIRECT ? hw_sqrt(r2) : r2 * inv_r;
         const float y = sat(fmaf(r, ninv_h, c1));  // 1 - height_ratio
         const float y3 = y * y * y;
 
         float sun_od;
         if (DIRECT) {
-            // chord from the sample to the outer sphere along the sun direction, then a left Riemann sum
+            // chord from the sample to the outer sphere along the sun direction, then a left Riemann sum.
+            // x1 - max(x0, 0) with x0 = -b - sq, x1 = sq - b  ==  min(x1 - x0, x1) = min(2 sq, sq - b)
             const float hh = ratm2 - (r2 - bdot * bdot);
             const float sq = hw_sqrt(fmaxf(hh, 0.0f));
-            const float x0 = -bdot - sq, x1 = sq - bdot;
-            const float ray_len = (hh < 0.0f) ? 0.0f : (x1 - fmaxf(x0, 0.0f));
+            const float ray_len = (hh < 0.0f) ? 0.0f : fminf(sq + sq, sq - bdot);
             const float lstep = ray_len * inv_light_steps;
             float acc = y3;  // sample 0 sits on the view sample itself
             if (LSTEPS > 0) {
