@@ -29,7 +29,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 BYTES_PER_RAY = 20          # 16 B RGBA32F store + 4 B depth load
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
@@ -66,7 +65,7 @@ def pmc_summary(workload, w, h):
     return out
 
 WORKLOADS = {
-    # name: (tests/common.py CONFIGS key, description)
+    # name: (godot_atmosphere_shader_amd.demo.CONFIGS key, description)
     "direct32x8": ("no_clouds_32x8_direct", "planet_atmosphere_no_clouds, 32 view x 8 light steps (direct light march)"),
     "lut32": ("no_clouds_32_lut", "planet_atmosphere_no_clouds, 32 view steps, baked-LUT light (reference algorithm)"),
     "shipped8": ("no_clouds_8", "planet_atmosphere_no_clouds as shipped: 8 view steps, baked-LUT light"),
@@ -130,7 +129,7 @@ def usable_cores():
 def cpu_baseline(config_name, params, textures, cam, depth_np, lut):
     """The oracle (a port of the GDShader, not the reference itself: Godot is a GPU-only path) timed on this
     host's cores over one full frame of the same workload."""
-    from common import CONFIGS, demo_frame
+    from godot_atmosphere_shader_amd.demo import CONFIGS, demo_frame
     from oracle.oracle import Oracle
 
     cores = usable_cores()
@@ -273,7 +272,7 @@ def main():
     import numpy as np
     import torch
 
-    from common import demo_params, demo_textures, make_node
+    from godot_atmosphere_shader_amd.demo import demo_params, demo_textures, make_node
     from godot_atmosphere_shader_amd import scene as S
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -413,7 +412,7 @@ def main():
                 node2.close()
             result["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
-            from common import CONFIGS
+            from godot_atmosphere_shader_amd.demo import CONFIGS
             ocfg = CONFIGS[config_name][1]
             lut = node.read_optical_depth() if not (ocfg.get("lite") or ocfg.get("light_steps")) else None
             result["cpu_baseline"] = cpu_baseline(config_name, params, textures, cam, depth_np, lut)

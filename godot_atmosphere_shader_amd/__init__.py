@@ -4,6 +4,7 @@ Zylann/godot_atmosphere_shader, behind the reference's `PlanetAtmosphere` / `sha
   csrc/                 hand-written HIP kernels + the C ABI of include/atmo.h (libatmo_hip.so)
   planet_atmosphere.py  host-side mirror of addons/zylann.atmosphere/planet_atmosphere.gd
   noise_cubemap.py      host-side mirror of addons/zylann.atmosphere/noise_cubemap.gd (generation on the GPU)
+  demo.py               the reference's demo scene + named shader configurations (tests, bench.py, smoke())
   scene.py              synthetic inputs (camera, depth, jitter, cloud textures) for tests and bench
   sharding.py           row-band / viewport sharding across the GPUs of a node + RCCL gather
 """

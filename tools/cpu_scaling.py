@@ -1,7 +1,7 @@
 import sys, time, os
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+sys.path.insert(0,'.')
 from oracle.oracle import Oracle
-from common import *
+from godot_atmosphere_shader_amd.demo import *
 from godot_atmosphere_shader_amd import scene as S
 print('affinity', len(os.sched_getaffinity(0)), 'cpu_count', os.cpu_count())
 for f in ('/sys/fs/cgroup/cpu.max','/sys/fs/cgroup/cpu/cpu.cfs_quota_us','/sys/fs/cgroup/cpu/cpu.cfs_period_us'):

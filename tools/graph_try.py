@@ -1,7 +1,7 @@
 import sys, time
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+sys.path.insert(0,'.')
 import torch, numpy as np
-from common import *
+from godot_atmosphere_shader_amd.demo import *
 from godot_atmosphere_shader_amd import scene as S
 tex=demo_textures(); params=demo_params()
 cam=S.Camera.from_pose(1920,1080,'P_space'); depth=torch.from_numpy(S.depth_ground_sphere(cam)).cuda()

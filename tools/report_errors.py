@@ -2,9 +2,8 @@
 """Prints the max |HIP - fp32 oracle| per config and pose (needs an MI355X). Used to watch the parity margin."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np, torch
-from common import CONFIGS, demo_frame, demo_params, demo_textures, make_node
+sys.path.insert(0, ROOT); import numpy as np, torch
+from godot_atmosphere_shader_amd.demo import CONFIGS, demo_frame, demo_params, demo_textures, make_node
 from godot_atmosphere_shader_amd import scene as S
 from oracle.oracle import Oracle
 
