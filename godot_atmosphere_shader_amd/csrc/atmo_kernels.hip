@@ -69,6 +69,10 @@ constexpr bool RM_COMPACT = ATMO_RM_COMPACT != 0;
 #define ATMO_CUBE_EXACT 0
 #endif
 
+// 1: texture gathers as buffer loads (SRSRC + 32-bit offset) instead of flat 64-bit addresses
+#ifndef ATMO_BUFFER_LOADS
+#define ATMO_BUFFER_LOADS 1
+#endif
 // unroll factor of the view-ray loop (lets the LUT gathers of step i+1 issue under the exps of step i)
 #ifndef ATMO_VIEW_UNROLL
 #define ATMO_VIEW_UNROLL 1
@@ -156,6 +160,19 @@ __device__ __forceinline__ float2 hit_radius(SphereHit s, float radius) {
 // The vector-memory path issues a 64-lane gather at ~16 cycles per wave instruction however narrow the
 // data, so instruction count, not bytes, is what these layouts buy (profiles/round1).
 
+// Texture gathers through buffer descriptors (buffer_load ... offen: scalar SRSRC base + one 32-bit VGPR byte offset +
+// immediate offset) instead of 64-bit flat addresses: ~5 fewer address instructions per fetch (ATMO_BUFFER_LOADS).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint32_t buf_u32(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ f32x2 buf_f32x2(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0));
+}
+
 // byte k of a footprint word as float (the compiler selects v_cvt_f32_ubyte0..3)
 __device__ __forceinline__ float ub0(uint32_t w) { return (float)(w & 0xffu); }
 __device__ __forceinline__ float ub1(uint32_t w) { return (float)((w >> 8) & 0xffu); }
@@ -163,10 +180,20 @@ __device__ __forceinline__ float ub2(uint32_t w) { return (float)((w >> 16) & 0x
 __device__ __forceinline__ float ub3(uint32_t w) { return (float)(w >> 24); }
 
 // texture(u_optical_depth_texture, uv).r : bilinear, clamp-to-edge, R32F.  x = u*w - 0.5, y = v*h - 0.5 (texel space).
-__device__ __forceinline__ float lut_sample_xy(const float *__restrict__ lut, int stride, float x, float y) {
+__device__ __forceinline__ float lut_sample_xy(const float *__restrict__ lut, int stride, int rows, float x, float y) {
 #pragma clang fp contract(fast)
     const float xf = floorf(x), yf = floorf(y);
     const float fx = x - xf, fy = y - yf;
+#if ATMO_BUFFER_LOADS && !ATMO_ABLATE_FETCH
+    {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(lut, (uint32_t)(stride * rows) * 4u);
+        const uint32_t off = (uint32_t)(((int)yf + 1) * stride + ((int)xf + 1)) * 4u;
+        const f32x2 r0 = buf_f32x2(rs, off), r1 = buf_f32x2(rs, off + (uint32_t)stride * 4u);
+        const float a = r0.x + (r0.y - r0.x) * fx;
+        const float b = r1.x + (r1.y - r1.x) * fx;
+        return a + (b - a) * fy;
+    }
+#endif
     // apron coordinates.  Keep the pointer form: the compiler merges each row's pair into one global_load_dwordx2;
     // unsigned element offsets from the scalar base measured 1.5x slower on this loop (profiles/round1/ab_lut_loop.txt).
     const int i = (int)xf + 1, j = (int)yf + 1;
@@ -205,7 +232,11 @@ __device__ __forceinline__ float shape_sample(const uint32_t *__restrict__ fp, i
     const uint32_t w0 = (uint32_t)((k0 * n + j0) * n + i0) * 2654435761u;
     const uint32_t w1 = (uint32_t)((k1 * n + j0) * n + i0) * 2246822519u;
 #else
-#if ATMO_U32_OFFSETS
+#if ATMO_BUFFER_LOADS
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(fp, (uint32_t)(n * n * n) * 4u);
+    const uint32_t w0 = buf_u32(rs, (uint32_t)((k0 * n + j0) * n + i0) * 4u);
+    const uint32_t w1 = buf_u32(rs, (uint32_t)((k1 * n + j0) * n + i0) * 4u);
+#elif ATMO_U32_OFFSETS
     const uint32_t w0 = fp[(uint32_t)((k0 * n + j0) * n + i0)];
     const uint32_t w1 = fp[(uint32_t)((k1 * n + j0) * n + i0)];
 #else
@@ -283,7 +314,9 @@ __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, in
 #if ATMO_ABLATE_FETCH
     const uint32_t w = (uint32_t)(((int)fid * stride + j) * stride + i) * 2654435761u;
 #else
-#if ATMO_U32_OFFSETS
+#if ATMO_BUFFER_LOADS
+    const uint32_t w = buf_u32(make_rsrc(fp, (uint32_t)(6 * stride * stride) * 4u), (uint32_t)(((int)fid * stride + j) * stride + i) * 4u);
+#elif ATMO_U32_OFFSETS
     const uint32_t w = fp[(uint32_t)(((int)fid * stride + j) * stride + i)];
 #else
     const uint32_t w = fp[((int)fid * stride + j) * stride + i];
@@ -371,7 +404,7 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
             // uv = (0.5 + 0.5*cos, height_ratio) -> texel space
             const float x = fmaf(bdot * inv_r, half_w, x_off);
             const float yv = fmaf(-y, lut_hf, y_off);
-            sun_od = lut_sample_xy(rc.lut, lut_stride, x, yv);
+            sun_od = lut_sample_xy(rc.lut, lut_stride, rc.lut_h + 2, x, yv);
         }
 
         const float d = y3 * dstep;
