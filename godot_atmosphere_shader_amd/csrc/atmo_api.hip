@@ -23,7 +23,8 @@ struct ParamDesc {
     size_t offset;
 };
 
-// The reference's uniforms with their GDShader defaults.
+// The reference's uniforms with their GDShader defaults.  `source_color` defaults are stored linear
+// (include/atmo.h: "colours are linear"), i.e. after the engine's sRGB -> linear conversion of the written value.
 struct Params {
     float u_planet_radius = 1.0f;                            // planet_common.gdshaderinc:4
     float u_atmosphere_height = 0.1f;                        // :5
@@ -32,7 +33,7 @@ struct Params {
     float u_scattering_strength = 20.0f;                     // atmosphere_funcs_v2.gdshaderinc:8
     float u_scattering_wavelengths[3] = {700, 530, 440};     // :9
     float u_atmosphere_modulate[3] = {1, 1, 1};              // :10
-    float u_atmosphere_ambient_color[3] = {0, 0, 0.002f};    // :11
+    float u_atmosphere_ambient_color[3] = {0, 0, 0.002f / 12.92f};  // :11 `source_color` vec3(0,0,0.002), linear
     float u_clip_mode = 0.0f;                                // main:55 (rasteriser only; stored, unused)
     float u_sphere_depth_factor = 0.0f;                      // main:60
     float u_cloud_density_scale = 50.0f;                     // cloud_funcs.gdshaderinc:5
@@ -90,6 +91,7 @@ struct AtmoContext {
     Params p;
     DeviceBuffer lut, blue, shape, cube;
     int lut_w = 0, lut_h = 0, shape_n = 0, cube_n = 0;
+    int host_double_precision = 0;  // DOUBLE_PRECISION (main:25,118-125)
     int timing = 0;          // 0 off; k >= 1: bracket every k-th launch with HIP events
     int launch_counter = 0;
     int timed_launches = 0;
@@ -399,7 +401,7 @@ int atmo_create(int device, int variant, int view_steps, int cloud_steps, int li
     ctx->cloud_steps = shipped_cloud_steps[variant] == 0 ? 0 : (cloud_steps > 0 ? cloud_steps : shipped_cloud_steps[variant]);
     ctx->light_steps = (light_mode == ATMO_LIGHT_DIRECT && !lite) ? light_steps : 0;
     ctx->flags = 0;
-    if (ctx->cloud_steps > 0) ctx->flags |= atmo::KF_CLOUDS;
+    if (ctx->cloud_steps > 0) ctx->flags |= atmo::KF_CLOUDS | atmo::KF_PRECISE;  // precise cloud density is the default
     if (variant == ATMO_VARIANT_CLOUDS_HIGH_RM) ctx->flags |= atmo::KF_CLOUD_LIGHT_RM;
     if (light_mode == ATMO_LIGHT_DIRECT && !lite) ctx->flags |= atmo::KF_LIGHT_DIRECT;
     if (lite) ctx->flags |= atmo::KF_LITE;  // the v1 atmosphere reads no optical-depth LUT and has no light march
@@ -658,6 +660,14 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     atmo::RenderConsts rc;
+    AtmoFrame fixed;
+    if (ctx->host_double_precision) {  // main:118-125: undo the engine's negated INV_VIEW_MATRIX origin
+        fixed = *frame;
+        fixed.inv_view_matrix[12] *= -1.0f;
+        fixed.inv_view_matrix[13] *= -1.0f;
+        fixed.inv_view_matrix[14] *= -1.0f;
+        frame = &fixed;
+    }
     fill_consts(ctx, frame, depth_dev, rgba_dev, rc);
     if (composite) {  // the target is the whole scene colour buffer, addressed by absolute pixel
         rc.out_pitch = frame->viewport_w;
@@ -686,6 +696,12 @@ int atmo_set_precision(AtmoContext *ctx, int mode) {
     if (mode != 0 && mode != 1) return fail(ctx, ATMO_E_ARG, "atmo_set_precision: mode must be 0 (fast) or 1 (precise cloud density)");
     if (mode == 1 && (ctx->flags & atmo::KF_CLOUDS)) ctx->flags |= atmo::KF_PRECISE;  // only the cloud kernels have a precise form
     else ctx->flags &= ~atmo::KF_PRECISE;
+    return ATMO_OK;
+}
+
+int atmo_set_host_double_precision(AtmoContext *ctx, int enable) {
+    if (!ctx) return ATMO_E_ARG;
+    ctx->host_double_precision = enable ? 1 : 0;
     return ATMO_OK;
 }
 

@@ -62,9 +62,13 @@ def make_node(config_name, textures, params=None, device=0, **extra):
     node.planet_radius = params["u_planet_radius"]
     node.atmosphere_height = params["u_atmosphere_height"]
     node.sun_path = S.DEMO_SUN_POSITION
+    from .planet_atmosphere import _SOURCE_COLOR, LinearColor
+
     for k, v in params.items():
         if k in ("u_planet_radius", "u_atmosphere_height", "u_cloud_coverage_rotation", "u_world_to_model_matrix"):
             continue
+        if k in _SOURCE_COLOR:
+            v = LinearColor(v)  # the scene dictionaries (scene.DEMO_SHADER_PARAMS, the oracle's inputs) hold linear colours
         node.set(f"shader_params/{k}", v)
     node._process(0.0, None, time=0.0)
     node.set_shader_parameter("u_cloud_coverage_rotation", np.asarray(params["u_cloud_coverage_rotation"], dtype=np.float32))

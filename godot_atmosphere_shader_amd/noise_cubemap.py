@@ -23,31 +23,10 @@ import numpy as np
 
 from . import _native as N
 
-_M32 = np.uint32(0xFFFFFFFF)
-
-
-def _hash_u32(x):
-    x = x.astype(np.uint32, copy=True)
-    with np.errstate(over="ignore"):
-        x ^= x >> np.uint32(16)
-        x *= np.uint32(0x7FEB352D)
-        x ^= x >> np.uint32(15)
-        x *= np.uint32(0x846CA68B)
-        x ^= x >> np.uint32(16)
-    return x
-
-
-def _lattice(ix, iy, iz, seed):
-    with np.errstate(over="ignore"):
-        h = (ix.astype(np.int32).view(np.uint32) * np.uint32(0x9E3779B1)) ^ (iy.astype(np.int32).view(np.uint32) * np.uint32(0x85EBCA77)) \
-            ^ (iz.astype(np.int32).view(np.uint32) * np.uint32(0xC2B2AE3D)) ^ np.uint32(seed & 0xFFFFFFFF)
-    return (_hash_u32(h) >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
-
-
 class SeededValueNoise:
-    """Stands for the `Noise` resource: fractal value noise in [-1, 1].  `get_noise_3dv` mirrors the script-callable
-    `Noise.get_noise_3dv` (float32 numpy, the same arithmetic the device kernel performs per texel); cubemap
-    generation itself never goes through it -- `NoiseCubemap._generate_images` launches the kernel."""
+    """Stands for the `Noise` resource: the settings of this package's fractal value noise in [-1, 1] (seed, frequency,
+    octaves, gain) plus Godot's `changed` signal.  The arithmetic lives in the device kernel only
+    (`atmo_noise_cubemap_kernel`); a float32 numpy statement of it for the CPU tests is tests/noise_host.py."""
 
     def __init__(self, seed: int = 0, frequency: float = 0.01, fractal_octaves: int = 4, fractal_gain: float = 0.5):
         self._listeners = []
@@ -65,36 +44,6 @@ class SeededValueNoise:
     def disconnect_changed(self, cb):
         if cb in self._listeners:
             self._listeners.remove(cb)
-
-    def _value(self, p, seed):
-        f32 = np.float32
-        fl = np.floor(p)
-        t = p - fl
-        w = t * t * (f32(3.0) - f32(2.0) * t)
-        i0 = fl.astype(np.int32)
-        i1 = i0 + np.int32(1)
-        x0, y0, z0, x1, y1, z1 = i0[..., 0], i0[..., 1], i0[..., 2], i1[..., 0], i1[..., 1], i1[..., 2]
-        wx, wy, wz = w[..., 0], w[..., 1], w[..., 2]
-        one = f32(1.0)
-        c00 = _lattice(x0, y0, z0, seed) * (one - wx) + _lattice(x1, y0, z0, seed) * wx
-        c10 = _lattice(x0, y1, z0, seed) * (one - wx) + _lattice(x1, y1, z0, seed) * wx
-        c01 = _lattice(x0, y0, z1, seed) * (one - wx) + _lattice(x1, y0, z1, seed) * wx
-        c11 = _lattice(x0, y1, z1, seed) * (one - wx) + _lattice(x1, y1, z1, seed) * wx
-        c0 = c00 * (one - wy) + c10 * wy
-        c1 = c01 * (one - wy) + c11 * wy
-        return c0 * (one - wz) + c1 * wz
-
-    def get_noise_3dv(self, p) -> np.ndarray:
-        p = np.asarray(p, dtype=np.float32)
-        f32 = np.float32
-        total = np.zeros(p.shape[:-1], dtype=np.float32)
-        amp, norm, freq = f32(1.0), f32(0.0), f32(self.frequency)
-        for o in range(int(self.fractal_octaves)):
-            total = total + amp * self._value(p * freq, (self.seed + 1013 * o) & 0xFFFFFFFF)
-            norm = f32(norm + amp)
-            amp = f32(amp * f32(self.fractal_gain))
-            freq = f32(freq * f32(2.0))
-        return f32(2.0) * (total / norm) - f32(1.0)
 
 
 def generate_importable_image(images: np.ndarray) -> np.ndarray:

@@ -29,7 +29,7 @@ import warnings
 import numpy as np
 
 from . import _native as N
-from .scene import col_major
+from .scene import col_major, srgb_to_linear
 
 MODE_NEAR = 0
 MODE_FAR = 1
@@ -62,7 +62,8 @@ SHADER_DEFAULTS = {
     "u_clip_mode": False, "u_sphere_depth_factor": 0.0, "u_cloud_density_scale": 50.0, "u_cloud_bottom": 0.2,
     "u_cloud_top": 0.5, "u_cloud_blend": 0.5, "u_cloud_shape_invert": 0.0, "u_cloud_coverage_bias": 0.0,
     "u_cloud_shape_factor": 0.8, "u_cloud_shape_scale": 1.0,
-    # atmosphere_funcs_v1.gdshaderinc:8-12 (sRGB values as written in the shader; converted to linear on upload)
+    # `source_color` uniforms hold the sRGB values written in the shader / shown by the inspector; `_forward` applies
+    # the engine's sRGB -> linear conversion on upload (atmosphere_funcs_v2.gdshaderinc:10-11, _v1.gdshaderinc:8-12)
     "u_day_color0": (0.5, 0.8, 1.0, 1.0), "u_day_color1": (0.5, 0.8, 1.0, 1.0),
     "u_night_color0": (0.2, 0.4, 0.8, 1.0), "u_night_color1": (0.2, 0.4, 0.8, 1.0),
     "u_day_night_transition_scale": 2.0,
@@ -76,6 +77,21 @@ _FLOAT_COUNTS = {
     "u_cloud_shape_scale": 1, "u_cloud_coverage_rotation": 4,
     "u_day_color0": 4, "u_day_color1": 4, "u_night_color0": 4, "u_night_color1": 4, "u_day_night_transition_scale": 1,
 }
+# uniforms declared `source_color`: Godot converts their rgb from sRGB to linear when the material uploads them
+_SOURCE_COLOR = frozenset(["u_atmosphere_modulate", "u_atmosphere_ambient_color", "u_day_color0", "u_day_color1",
+                           "u_night_color0", "u_night_color1"])
+
+
+class LinearColor(tuple):
+    """A colour value that is ALREADY linear: `set_shader_parameter(name, LinearColor(rgb))` uploads it unchanged
+    (the opt-out of the `source_color` conversion, for hosts that keep linear colours)."""
+
+    def __new__(cls, *v):
+        if len(v) == 1 and not isinstance(v[0], (int, float)):
+            v = tuple(v[0])
+        return super().__new__(cls, tuple(float(x) for x in v))
+
+
 _TEXTURES = {
     "u_optical_depth_texture": N.TEX_2D_R32F, "u_blue_noise_texture": N.TEX_2D_R8,
     "u_cloud_shape_texture": N.TEX_3D_R8, "u_cloud_coverage_cubemap": N.TEX_CUBE_R8,
@@ -198,14 +214,15 @@ class PlanetAtmosphere:
 
     def __init__(self, device: int = 0, light_mode: str = "lut", light_steps: int = 0,
                  view_steps: int | None = None, cloud_steps: int | None = None, blue_noise=None,
-                 precise_clouds: bool = False):
+                 precise_clouds: bool = True, double_precision: bool = False):
         self._lib = N.load()
         self._device = int(device)
         self._light_mode = {"lut": N.LIGHT_LUT, "direct": N.LIGHT_DIRECT}[light_mode]
         self._light_steps = int(light_steps)
         self._view_steps_override = view_steps    # macro override of ATMOSPHERE_RAYMARCH_STEPS
         self._cloud_steps_override = cloud_steps  # macro override of CLOUDS_MAX_RAYMARCH_STEPS
-        self._precise_clouds = bool(precise_clouds)  # atmo_set_precision: bit-faithful cloud density, ~15 % slower
+        self._precise_clouds = bool(precise_clouds)  # atmo_set_precision: bit-faithful cloud density (default); False = fast mode
+        self._double_precision = bool(double_precision)  # `#define DOUBLE_PRECISION` (main:25): engine negates INV_VIEW origin
         self._ctx = C.c_void_p()
         self._planet_radius = 1.0
         self._atmosphere_height = 0.1
@@ -241,6 +258,7 @@ class PlanetAtmosphere:
         N.check(None, rc)
         self._ctx = ctx
         N.check(ctx, self._lib.atmo_set_precision(ctx, 1 if self._precise_clouds else 0))
+        N.check(ctx, self._lib.atmo_set_host_double_precision(ctx, 1 if self._double_precision else 0))
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
@@ -365,6 +383,10 @@ class PlanetAtmosphere:
                 arr = a.reshape(-1).astype(np.float32)
         if arr.size != n:
             raise ValueError(f"{name} takes {n} floats, got {arr.size}")
+        if name in _SOURCE_COLOR and not isinstance(value, LinearColor):
+            a = np.asarray(arr, dtype=np.float64).copy()
+            a[:3] = srgb_to_linear(a[:3])  # alpha (v1 colours) is not converted
+            arr = a.astype(np.float32)
         arr = np.ascontiguousarray(arr, dtype=np.float32)
         rc = self._lib.atmo_set_param_f32(self._ctx, name.encode(), arr.ctypes.data_as(C.POINTER(C.c_float)), n)
         N.check(self._ctx, rc)

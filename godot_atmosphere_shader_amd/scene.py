@@ -30,8 +30,10 @@ def col_major(m: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(m, dtype=np.float64).T.reshape(-1).astype(np.float32))
 
 
-def perspective(fovy_deg: float, aspect: float, near: float, far: float) -> np.ndarray:
-    """View -> clip, Vulkan-style as Godot 4.3 hands it to shaders: y down, reversed z in [0,1]."""
+def perspective(fovy_deg: float, aspect: float, near: float, far: float, reverse_z: bool = True) -> np.ndarray:
+    """View -> clip, Vulkan-style as Godot 4.3 hands it to shaders: y down, reversed z in [0,1].
+    reverse_z=False: Godot 4.2 and older (the reference's `REVERSE_Z` define commented out, main:21-22):
+    forward z in [0,1], 0 = near plane, 1 = far plane."""
     f = 1.0 / math.tan(math.radians(fovy_deg) * 0.5)
     gl = np.array(
         [
@@ -42,8 +44,9 @@ def perspective(fovy_deg: float, aspect: float, near: float, far: float) -> np.n
         ],
         dtype=np.float64,
     )
-    # y flip, z_gl in [-1,1] -> reversed [1,0]
-    fix = np.array([[1, 0, 0, 0], [0, -1, 0, 0], [0, 0, -0.5, 0.5], [0, 0, 0, 1]], dtype=np.float64)
+    # y flip, z_gl in [-1,1] -> reversed [1,0] (or forward [0,1])
+    zs = -0.5 if reverse_z else 0.5
+    fix = np.array([[1, 0, 0, 0], [0, -1, 0, 0], [0, 0, zs, 0.5], [0, 0, 0, 1]], dtype=np.float64)
     return fix @ gl
 
 
@@ -250,10 +253,12 @@ def orbit_pose(k: int, n: int, radius: float = 158.0) -> dict:
 
 
 class Camera:
-    def __init__(self, width: int, height: int, eye, target, up=(0.0, 1.0, 0.0), fovy_deg=75.0, near=0.1, far=800.0):
+    def __init__(self, width: int, height: int, eye, target, up=(0.0, 1.0, 0.0), fovy_deg=75.0, near=0.1, far=800.0,
+                 reverse_z: bool = True):
         self.width, self.height = int(width), int(height)
         self.near, self.far, self.fovy_deg = near, far, fovy_deg
-        self.projection = perspective(fovy_deg, width / height, near, far)
+        self.reverse_z = bool(reverse_z)
+        self.projection = perspective(fovy_deg, width / height, near, far, reverse_z)
         self.inv_projection = np.linalg.inv(self.projection)
         self.inv_view = look_at(eye, target, up)
         self.view = np.linalg.inv(self.inv_view)
@@ -271,18 +276,20 @@ class Camera:
         xs = (np.arange(self.width) + 0.5) / self.width * 2.0 - 1.0
         ys = (np.arange(self.height) + 0.5) / self.height * 2.0 - 1.0
         gx, gy = np.meshgrid(xs, ys)
-        ndc = np.stack([gx, gy, np.ones_like(gx), np.ones_like(gx)], axis=-1)
+        near_z = np.ones_like(gx) if self.reverse_z else np.zeros_like(gx)  # a point on the near plane
+        ndc = np.stack([gx, gy, near_z, np.ones_like(gx)], axis=-1)
         v = ndc @ self.inv_projection.T
         return v[..., :3] / v[..., 3:4]
 
 
 def depth_far(cam: Camera) -> np.ndarray:
-    """Empty scene: reversed-Z depth 0 everywhere (far plane)."""
-    return np.zeros((cam.height, cam.width), dtype=np.float32)
+    """Empty scene: the far plane everywhere (reversed-Z depth 0; forward-Z depth 1)."""
+    return np.full((cam.height, cam.width), 0.0 if cam.reverse_z else 1.0, dtype=np.float32)
 
 
 def depth_ground_sphere(cam: Camera, center_world=(0.0, 0.0, 0.0), radius: float = DEMO_PLANET_RADIUS) -> np.ndarray:
-    """Depth buffer of an opaque sphere (the demo's Ground mesh): reversed-Z nonlinear depth, 0 where missed."""
+    """Depth buffer of an opaque sphere (the demo's Ground mesh): nonlinear depth in the camera's convention, the far
+    plane (reversed-Z 0 / forward-Z 1) where missed."""
     d = cam.pixel_view_dirs()
     d /= np.linalg.norm(d, axis=-1, keepdims=True)
     c = (cam.view @ np.array([*center_world, 1.0]))[:3]
@@ -296,5 +303,5 @@ def depth_ground_sphere(cam: Camera, center_world=(0.0, 0.0, 0.0), radius: float
     p = cam.projection
     zc = p[2, 2] * z_view + p[2, 3]
     wc = p[3, 2] * z_view + p[3, 3]
-    depth = np.where(hit, zc / np.where(hit, wc, 1.0), 0.0)
+    depth = np.where(hit, zc / np.where(hit, wc, 1.0), 0.0 if cam.reverse_z else 1.0)
     return depth.astype(np.float32)

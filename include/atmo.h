@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ATMO_ABI_VERSION 1
+#define ATMO_ABI_VERSION 2
 
 typedef struct AtmoContext AtmoContext;
 
@@ -162,13 +162,23 @@ int atmo_render_composite(AtmoContext *ctx, const AtmoFrame *frame, const float 
 
 /*
  * Numerical mode of the cloud kernels (no reference counterpart; the atmosphere-only variants have a single form).
- * 0 (default, fast): the well-conditioned part of the cloud density expression runs fused; max deviation from a scalar
- *   fp32 evaluation of the GDShader measured 5.1e-5 at 1920x1080, 6.9e-5 at 3840x2160 (within the 1e-4 contract).
- * 1 (precise): the whole density expression, both texture filters included, is evaluated in the reference's operation
- *   order with exact UNORM8 conversions, so the x50 density ramp sees bit-identical inputs; deviation drops to that of
- *   the atmosphere term (<= 2.1e-5) at ~15 % lower cloud-kernel throughput.
+ * 1 (default, precise): the whole cloud density expression, both texture filters included, is evaluated in the
+ *   reference's operation order with exact UNORM8 conversions, so the x50 density ramp sees bit-identical inputs; the
+ *   deviation from a scalar fp32 evaluation of the GDShader is that of the atmosphere term (<= 2.1e-5) on every
+ *   planet scale tested (tests/test_gpu_parity.py::test_parity_other_planet_scales).
+ * 0 (fast): the well-conditioned part of the density expression runs fused: ~15 % more cloud-kernel throughput, max
+ *   deviation 5.1e-5 at 1920x1080 and 6.9e-5 at 3840x2160 on the demo scene, but it grows with u_cloud_density_scale
+ *   (1.8e-4 at 10x the demo's value), i.e. the 1e-4 contract is scene-dependent in this mode.
  */
 int atmo_set_precision(AtmoContext *ctx, int mode);
+
+/*
+ * Replaces: the compile switch `#define DOUBLE_PRECISION` (shaders/include/planet_atmosphere_main.gdshaderinc:25,118-125).
+ * A double-precision Godot build hands INV_VIEW_MATRIX with its origin negated (godotengine/godot#93108); with the
+ * switch on, the library negates inv_view_matrix[12..14] of every AtmoFrame back, exactly as the shader does, so such
+ * a host passes the engine's matrix unchanged.  0 (default) = single-precision engine build.
+ */
+int atmo_set_host_double_precision(AtmoContext *ctx, int enable);
 
 /* Device time of `atmo_render` kernels measured with HIP events recorded around the launch on its own stream:
  * atmo_set_timing(ctx, k): k = 0 off, k >= 1 brackets every k-th launch (k > 1 keeps the ~5 us cost of recording two

@@ -681,6 +681,10 @@ long SFX(oracle_render)(const OracleParams *p, const OracleTextures *t, const Or
         Job *j = &jobs[k];
         j->ctx = &ctx; j->frame = f; j->depth = depth; j->out = out;
         for (int i = 0; i < 16; ++i) { j->inv_p[i] = f->inv_projection_matrix[i]; j->inv_v[i] = f->inv_view_matrix[i]; }
+        if (cfg->double_precision) {
+            /* ref: I/planet_atmosphere_main.gdshaderinc:118-125 (#ifdef DOUBLE_PRECISION) */
+            j->inv_v[12] *= K(-1.0); j->inv_v[13] *= K(-1.0); j->inv_v[14] *= K(-1.0);
+        }
         j->x0 = x0; j->y0 = y0; j->x1 = x1; j->y1 = y1;
         j->next_row = &next_row;
         j->hits = 0;
@@ -861,7 +865,7 @@ REAL SFX(oracle_sample_cube)(const OracleTextures *t, const REAL *d) { return sa
 int SFX(oracle_cube_texel)(const OracleTextures *t, int f, int i, int j) { return cube_texel(t, f, i, j); }
 
 REAL SFX(oracle_get_cloud_density)(const OracleParams *p, const OracleTextures *t, const REAL *pos_model) {
-    OracleConfig cfg = {8, 8, 0, 0, 0};
+    OracleConfig cfg = {8, 8, 0, 0, 0, 0};
     Ctx c;
     ctx_init(&c, p, t, &cfg);
     CloudSettings cs;

@@ -102,6 +102,7 @@ typedef struct OracleConfig {
     int32_t cloud_light_rm;  /* 1 => CLOUDS_RAYMARCHED_LIGHTING */
     int32_t light_steps;     /* 0 => baked LUT (reference); >0 => inline sun-ray march of that many steps */
     int32_t lite;            /* 1 => ATMOSPHERE_LITE: compute_atmosphere of atmosphere_funcs_v1.gdshaderinc */
+    int32_t double_precision;/* 1 => DOUBLE_PRECISION (main:25,118-125): the engine hands INV_VIEW_MATRIX with its origin negated */
 } OracleConfig;
 
 #ifdef __cplusplus

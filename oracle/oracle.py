@@ -77,10 +77,12 @@ class OracleConfig(C.Structure):
         ("cloud_light_rm", C.c_int32),
         ("light_steps", C.c_int32),
         ("lite", C.c_int32),
+        ("double_precision", C.c_int32),
     ]
 
 
-# Shader defaults (declared at the cited reference lines).
+# Shader defaults (declared at the cited reference lines).  The oracle works on linear colours:
+# `source_color` defaults are listed after Godot's sRGB -> linear conversion (stated engine convention).
 PARAM_DEFAULTS = {
     "u_planet_radius": 1.0,
     "u_atmosphere_height": 0.1,
@@ -88,7 +90,7 @@ PARAM_DEFAULTS = {
     "u_scattering_strength": 20.0,
     "u_scattering_wavelengths": (700.0, 530.0, 440.0),
     "u_atmosphere_modulate": (1.0, 1.0, 1.0),
-    "u_atmosphere_ambient_color": (0.0, 0.0, 0.002),
+    "u_atmosphere_ambient_color": (0.0, 0.0, 0.002 / 12.92),  # `source_color` vec3(0,0,0.002) converted sRGB -> linear
     "u_sphere_depth_factor": 0.0,
     "u_cloud_density_scale": 50.0,
     "u_cloud_bottom": 0.2,
@@ -109,13 +111,17 @@ PARAM_DEFAULTS = {
 }
 
 
+_built = False
+
+
 def build(force: bool = False) -> None:
     """Compile the oracle shared objects with the committed Makefile."""
-    need = force or not all(
-        os.path.exists(os.path.join(_HERE, n)) for n in ("liboracle_f32.so", "liboracle_f64.so", "liboracle_f32_fast.so")
-    )
-    if need:
-        subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
+    global _built
+    if _built and not force:
+        return
+    # always through make: it is mtime-aware, so an edited atmo_oracle.c can never be checked against a stale .so
+    subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
+    _built = True
 
 
 def _host_has_avx2_fma() -> bool:
@@ -251,7 +257,7 @@ class Oracle:
     def make_config(config: dict) -> OracleConfig:
         return OracleConfig(int(config["view_steps"]), int(config.get("cloud_steps", 0)),
                             int(config.get("cloud_light_rm", 0)), int(config.get("light_steps", 0)),
-                            int(config.get("lite", 0)))
+                            int(config.get("lite", 0)), int(config.get("double_precision", 0)))
 
     # ---- entry points --------------------------------------------------------------------
     def render(self, params: dict, textures: dict, config: dict, frame: dict, depth: np.ndarray,

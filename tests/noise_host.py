@@ -2,7 +2,59 @@
 numpy -- an independent statement of the generator used to cross-check the C oracle.  The product generates on the GPU."""
 import numpy as np
 
-from godot_atmosphere_shader_amd.noise_cubemap import SeededValueNoise  # noqa: F401  (the Noise mirror)
+from godot_atmosphere_shader_amd.noise_cubemap import SeededValueNoise  # noqa: F401  (the Noise mirror: settings only)
+
+
+def _hash_u32(x):
+    x = x.astype(np.uint32, copy=True)
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint32(16)
+        x *= np.uint32(0x7FEB352D)
+        x ^= x >> np.uint32(15)
+        x *= np.uint32(0x846CA68B)
+        x ^= x >> np.uint32(16)
+    return x
+
+
+def _lattice(ix, iy, iz, seed):
+    with np.errstate(over="ignore"):
+        h = (ix.astype(np.int32).view(np.uint32) * np.uint32(0x9E3779B1)) ^ (iy.astype(np.int32).view(np.uint32) * np.uint32(0x85EBCA77)) \
+            ^ (iz.astype(np.int32).view(np.uint32) * np.uint32(0xC2B2AE3D)) ^ np.uint32(seed & 0xFFFFFFFF)
+    return (_hash_u32(h) >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+
+def _value(p, seed):
+    f32 = np.float32
+    fl = np.floor(p)
+    t = p - fl
+    w = t * t * (f32(3.0) - f32(2.0) * t)
+    i0 = fl.astype(np.int32)
+    i1 = i0 + np.int32(1)
+    x0, y0, z0, x1, y1, z1 = i0[..., 0], i0[..., 1], i0[..., 2], i1[..., 0], i1[..., 1], i1[..., 2]
+    wx, wy, wz = w[..., 0], w[..., 1], w[..., 2]
+    one = f32(1.0)
+    c00 = _lattice(x0, y0, z0, seed) * (one - wx) + _lattice(x1, y0, z0, seed) * wx
+    c10 = _lattice(x0, y1, z0, seed) * (one - wx) + _lattice(x1, y1, z0, seed) * wx
+    c01 = _lattice(x0, y0, z1, seed) * (one - wx) + _lattice(x1, y0, z1, seed) * wx
+    c11 = _lattice(x0, y1, z1, seed) * (one - wx) + _lattice(x1, y1, z1, seed) * wx
+    c0 = c00 * (one - wy) + c10 * wy
+    c1 = c01 * (one - wy) + c11 * wy
+    return c0 * (one - wz) + c1 * wz
+
+
+def get_noise_3dv(noise: SeededValueNoise, p) -> np.ndarray:
+    """`Noise.get_noise_3dv` for the SeededValueNoise settings, float32 numpy: the arithmetic the device kernel and
+    the C oracle perform per texel."""
+    p = np.asarray(p, dtype=np.float32)
+    f32 = np.float32
+    total = np.zeros(p.shape[:-1], dtype=np.float32)
+    amp, norm, freq = f32(1.0), f32(0.0), f32(noise.frequency)
+    for o in range(int(noise.fractal_octaves)):
+        total = total + amp * _value(p * freq, (noise.seed + 1013 * o) & 0xFFFFFFFF)
+        norm = f32(norm + amp)
+        amp = f32(amp * f32(noise.fractal_gain))
+        freq = f32(freq * f32(2.0))
+    return f32(2.0) * (total / norm) - f32(1.0)
 
 
 def texel_directions(resolution: int) -> np.ndarray:
@@ -23,7 +75,7 @@ def generate_images_host(resolution, noise: SeededValueNoise, scale) -> np.ndarr
     """`_generate_images` evaluated on the host in float32 numpy (what the reference does on the CPU).  Used by the
     CPU tests as an independent statement of the generator; the product path is the device kernel."""
     d = texel_directions(resolution) * np.asarray(scale, dtype=np.float32)
-    dens = np.float32(0.5) + np.float32(0.5) * noise.get_noise_3dv(d)
+    dens = np.float32(0.5) + np.float32(0.5) * get_noise_3dv(noise, d)
     return np.clip(dens * np.float32(255.0), 0.0, 255.0).astype(np.uint8)
 
 

@@ -202,3 +202,78 @@ def test_host_texture_layouts_against_the_oracle(oracle32):
     assert lib.atmo_host_layout_lut(lut.ctypes.data_as(C.c_void_p), 7, 5, ap.ctypes.data_as(C.c_void_p)) == N.ATMO_OK
     assert np.array_equal(ap, np.pad(lut, 1, mode="edge"))
     assert lib.atmo_host_layout_cubemap(None, 4, fp.ctypes.data_as(C.c_void_p)) == N.ATMO_E_ARG
+
+
+class _RecordingLib:
+    """Stands in for libatmo_hip.so in the CPU tests of the node mirror: records what `_forward` uploads."""
+
+    def __init__(self):
+        self.uploads = {}
+
+    def atmo_set_param_f32(self, ctx, name, ptr, n):
+        self.uploads[name.decode()] = [float(ptr[i]) for i in range(n)]
+        return 0
+
+
+def _bare_node():
+    from godot_atmosphere_shader_amd.planet_atmosphere import DefaultShader, PlanetAtmosphere
+
+    node = object.__new__(PlanetAtmosphere)  # no context: the GPU is not needed for the upload logic
+    node._lib = _RecordingLib()
+    node._ctx = C.c_void_p()
+    node._params = {}
+    node._shader = DefaultShader
+    node._uses_baked_optical_depth = False
+    node._bake_pending = False
+    return node
+
+
+def test_source_color_uniforms_are_converted_on_upload_and_round_trip():
+    """`source_color` uniforms hold sRGB values on the node (what the inspector shows) and are
+    converted to linear when the material uploads them, as the engine does; `set(k, get(k))` -- the inspector's round
+    trip over get_property_list -- does not change the uploaded floats; LinearColor opts out of the conversion."""
+    from godot_atmosphere_shader_amd.planet_atmosphere import SHADER_DEFAULTS, LinearColor, load_shader
+
+    node = _bare_node()
+    node._shader = load_shader("planet_atmosphere_v1_clouds")
+    up = node._lib.uploads
+    node.set("shader_params/u_atmosphere_modulate", (1.0, 0.980392, 0.964706))
+    assert up["u_atmosphere_modulate"] == pytest.approx(S.srgb_to_linear((1.0, 0.980392, 0.964706)).tolist(), rel=1e-6)
+    # defaults as the inspector shows them (sRGB) upload as the library's linear defaults
+    node.set("shader_params/u_day_color0", node.get("shader_params/u_day_color0"))
+    assert node.get("shader_params/u_day_color0") == SHADER_DEFAULTS["u_day_color0"] == (0.5, 0.8, 1.0, 1.0)
+    assert up["u_day_color0"] == pytest.approx([0.21404114, 0.60382734, 1.0, 1.0], rel=1e-6)  # alpha not converted
+    node.set("shader_params/u_atmosphere_ambient_color", node.get("shader_params/u_atmosphere_ambient_color"))
+    assert up["u_atmosphere_ambient_color"] == pytest.approx([0.0, 0.0, 0.002 / 12.92], rel=1e-6)
+    # the round trip is a fixed point: set(k, get(k)) twice uploads the same floats
+    for prop in node.get_property_list():
+        k = prop["name"]
+        v = node.get(k)
+        if v is None or k.endswith("_texture") or k.endswith("_cubemap"):
+            continue
+        node.set(k, v)
+        first = list(up[k[len("shader_params/"):]])
+        node.set(k, node.get(k))
+        assert up[k[len("shader_params/"):]] == first, k
+    # hosts that keep linear colours opt out
+    node.set_shader_parameter("u_atmosphere_modulate", LinearColor(0.25, 0.5, 0.75))
+    assert up["u_atmosphere_modulate"] == [0.25, 0.5, 0.75]
+    assert node.get_shader_parameter("u_atmosphere_modulate") == (0.25, 0.5, 0.75)
+    node.set("shader_params/u_atmosphere_modulate", node.get("shader_params/u_atmosphere_modulate"))
+    assert up["u_atmosphere_modulate"] == [0.25, 0.5, 0.75]  # the wrapper survives get(): still a no-op
+    # non-colour uniforms are never touched
+    node.set("shader_params/u_scattering_wavelengths", (0.5, 0.5, 0.5))
+    assert up["u_scattering_wavelengths"] == [0.5, 0.5, 0.5]
+
+
+def test_forward_z_camera_conventions():
+    cam = S.Camera.from_pose(64, 36, "P_space", reverse_z=False)
+    v = cam.inv_projection @ np.array([0.0, 0.0, 0.0, 1.0])
+    assert (v[:3] / v[3])[2] == pytest.approx(-cam.near)
+    v = cam.inv_projection @ np.array([0.0, 0.0, 1.0, 1.0])
+    assert (v[:3] / v[3])[2] == pytest.approx(-cam.far, rel=1e-4)
+    d = S.depth_ground_sphere(cam)
+    assert d.max() == 1.0 and 0.9 < d.min() < 1.0 and np.array_equal(S.depth_far(cam), np.ones_like(d))
+    rev = S.Camera.from_pose(64, 36, "P_space")
+    assert np.allclose(cam.pixel_view_dirs(), rev.pixel_view_dirs())
+    assert np.array_equal(d < 1.0, S.depth_ground_sphere(rev) > 0.0)
