@@ -294,6 +294,15 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
     rc.shape_factor = p.u_cloud_shape_factor;
     rc.shape_scale = p.u_cloud_shape_scale;
     rc.shape_invert = (p.u_cloud_shape_invert == 1.0f) ? 1 : 0;
+    {   // range of `shape - 0.2 * detail` (clouds:52-58, detail = 0.5) over tex in [0, 1 + 2^-20]: every fp32 step of the
+        // mix / invert is monotone in tex, so the two end points bound it whatever the sign of u_cloud_shape_factor
+        const float f = p.u_cloud_shape_factor;
+        const float t_hi = 1.0f + 9.5367431640625e-07f;
+        float a = 0.5f * (1.0f - f) + 0.0f * f, b = 0.5f * (1.0f - f) + t_hi * f;
+        if (rc.shape_invert) { a = 1.0f - a; b = 1.0f - b; }
+        rc.shape_lo01 = std::fmin(a, b) - 0.1f;
+        rc.shape_hi01 = std::fmax(a, b) - 0.1f;
+    }
     std::memcpy(rc.cov_rot, p.u_cloud_coverage_rotation, sizeof(rc.cov_rot));
     const float *A = p.u_world_to_model_matrix;
     for (int col = 0; col < 4; ++col)

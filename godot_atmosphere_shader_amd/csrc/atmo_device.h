@@ -39,6 +39,7 @@ struct RenderConsts {
     float inv_cloud_thickness;        // [host] RN(1 / thickness), for exact_div_uniform
     float cloud_density_scale, cloud_blend, coverage_bias, shape_factor, shape_scale;
     int32_t shape_invert;             // u_cloud_shape_invert == 1.0           clouds:57
+    float shape_lo01, shape_hi01;     // [host] bounds of (shape - 0.1) over every filtered texel value: coverage-first early outs
     float cov_rot[4];                 // mat2 column-major
     float view_to_model[16];          // [host] u_world_to_model_matrix * inv_view   clouds:285
     float origin_model[3];            // [host] (view_to_model * (0,0,0,1)).xyz      clouds:286

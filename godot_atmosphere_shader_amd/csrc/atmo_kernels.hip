@@ -258,11 +258,13 @@ __device__ __forceinline__ float shape_sample(const uint32_t *__restrict__ fp, i
 
 // Bilinear filter of four UNORM8 texels exactly as a scalar fp32 evaluation of  mix(mix(t00,t10,fx), mix(t01,t11,fx), fy),
 // t = byte / 255 (IEEE), mix(a,b,t) = a*(1-t) + b*t  would round it.  byte * RN(1/255) differs from byte / 255 for 126 of the
-// 256 bytes; one Markstein correction makes all 256 exact (checked exhaustively).  No contraction in this function.
+// 256 bytes; with 1/255 split into C_HI + C_LO (two floats), fma(b, C_HI, RN(b * C_LO)) is the correctly rounded quotient
+// for all 256 bytes (checked exhaustively, tests/test_oracle_kat.py::test_unorm8_two_op_conversion_is_exact).
+// No contraction in this function.
 __device__ __forceinline__ float unorm8_exact(float b) {
-    const float rc = 1.0f / 255.0f;
-    const float q = b * rc;
-    return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, b), rc, q);
+    const float c_hi = __uint_as_float(0x3b808081u);  // RN(1/255)
+    const float c_lo = __uint_as_float(0xaf7efeffu);  // RN(1/255 - c_hi)
+    return __builtin_fmaf(b, c_hi, b * c_lo);
 }
 __device__ __forceinline__ float bilinear_unorm8_exact(uint32_t w, float fx, float fy) {
     const float t00 = unorm8_exact(ub0(w)), t10 = unorm8_exact(ub1(w));
@@ -481,11 +483,23 @@ __device__ __forceinline__ float cloud_density_precise(const RenderConsts &rc, f
         coverage = cube_sample<true>(rc.cube, rc.cube_n, qx, py, qz);
     }
     coverage = coverage - 0.25f * hr + rc.coverage_bias;
+    const float m = -1.2f * (1.0f - coverage) + 1.5f * coverage;
+    if (EARLY_OUT) {
+        // Coverage decides most samples before the shape texture is touched.  Every step of
+        //   density(shape) = clamp((((shape - 0.1) + m) * hc) * 50 - 20, 0, 1)      (hc > 0 here)
+        // is a monotone non-decreasing fp32 operation of `shape`, and shape lies in [shape_lo, shape_hi] (host: the
+        // mix/invert of a filtered UNORM8 value in [0, 1 + 2^-20]).  So if the expression is <= 0 at shape_hi the exact
+        // result is 0, and if it is >= 1 at shape_lo the exact result is 1: bit-identical, no trilinear fetch (the
+        // 8-texel exact filter is ~45 % of a density evaluation).
+        const float d_hi = ((rc.shape_hi01 + m) * hc) * 50.0f - 20.0f;
+        if (d_hi <= 0.0f) return 0.0f;
+        const float d_lo = ((rc.shape_lo01 + m) * hc) * 50.0f - 20.0f;
+        if (d_lo >= 1.0f) return 1.0f;
+    }
     const float s = rc.shape_scale;
     const float tex = shape_sample<true>(rc.shape, rc.shape_n, px * s, py * s, pz * s);
     float shape = 0.5f * (1.0f - rc.shape_factor) + tex * rc.shape_factor;
     if (rc.shape_invert) shape = 1.0f - shape;
-    const float m = -1.2f * (1.0f - coverage) + 1.5f * coverage;
     float density = (shape - 0.1f + m) * hc;
     density = density * 50.0f - 20.0f;
     return fminf(fmaxf(density, 0.0f), 1.0f);
@@ -505,10 +519,15 @@ __device__ __forceinline__ float cloud_density_fast(const RenderConsts &rc, floa
         coverage = cube_sample<false>(rc.cube, rc.cube_n, qx, py, qz);
     }
     coverage = coverage - 0.25f * hr + rc.coverage_bias;
+    const float m = mixf(-1.2f, 1.5f, coverage);
+    if (EARLY_OUT) {  // coverage-first early outs, see cloud_density_precise (here within the fast mode's tolerance)
+        if (((rc.shape_hi01 + m) * hc) * 50.0f - 20.0f <= 0.0f) return 0.0f;
+        if (((rc.shape_lo01 + m) * hc) * 50.0f - 20.0f >= 1.0f) return 1.0f;
+    }
     const float s = rc.shape_scale;
     float shape = mixf(0.5f, shape_sample<false>(rc.shape, rc.shape_n, px * s, py * s, pz * s), rc.shape_factor);
     if (rc.shape_invert) shape = 1.0f - shape;
-    const float density = (shape - 0.1f + mixf(-1.2f, 1.5f, coverage)) * hc;
+    const float density = (shape - 0.1f + m) * hc;
     return sat(density * 50.0f - 20.0f);
 }
 
