@@ -21,7 +21,7 @@ ABI_VERSION = 2
 EXPORTED_SYMBOLS = (
     "atmo_abi_version", "atmo_device_count", "atmo_create", "atmo_destroy", "atmo_set_param_f32",
     "atmo_get_param_f32", "atmo_set_texture", "atmo_generate_noise_cubemap", "atmo_bake_optical_depth", "atmo_read_optical_depth",
-    "atmo_render", "atmo_render_composite", "atmo_set_precision", "atmo_set_host_double_precision", "atmo_set_timing", "atmo_get_timing", "atmo_selftest_exact_math", "atmo_host_layout_cubemap",
+    "atmo_render", "atmo_render_composite", "atmo_set_precision", "atmo_set_host_double_precision", "atmo_set_lane_split", "atmo_set_tile_feedback", "atmo_set_timing", "atmo_get_timing", "atmo_selftest_exact_math", "atmo_host_layout_cubemap",
     "atmo_host_layout_shape", "atmo_host_layout_lut", "atmo_kernel_name",
     "atmo_last_error_string",
 )
@@ -85,6 +85,8 @@ def load() -> C.CDLL:
         "atmo_render_composite": (ip, [vp, C.POINTER(AtmoFrame), vp, vp, vp]),
         "atmo_set_precision": (ip, [vp, ip]),
         "atmo_set_host_double_precision": (ip, [vp, ip]),
+        "atmo_set_lane_split": (ip, [vp, ip]),
+        "atmo_set_tile_feedback": (ip, [vp, ip]),
         "atmo_set_timing": (ip, [vp, ip]),
         "atmo_get_timing": (ip, [vp, C.POINTER(ip), C.POINTER(C.c_double)]),
         "atmo_selftest_exact_math": (ip, [vp, C.c_uint32, C.c_uint32, C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -92,6 +93,17 @@ struct AtmoContext {
     DeviceBuffer lut, blue, shape, cube;
     int lut_w = 0, lut_h = 0, shape_n = 0, cube_n = 0;
     int host_double_precision = 0;  // DOUBLE_PRECISION (main:25,118-125)
+    int lane_split = 0;             // 0 = choose per launch by size, 1 = one lane per ray, 2 = two lanes per ray
+    int last_split = 1;             // what the most recent launch used (atmo_kernel_name)
+    // tile order with cost feedback (atmo_set_tile_feedback): -1 = by variant (clouds_high_rm on), 0 off, 1 on
+    int tile_feedback = -1;
+    DeviceBuffer tile_cost[2], tile_order[2];          // double-buffered: draw N uses [N & 1]
+    int fb_tiles_x = 0, fb_tiles_y = 0, fb_split = 0;  // launch grid the buffers belong to
+    unsigned fb_n = 0;                                 // draws of that grid so far
+    bool fb_cost_valid[2] = {false, false};            // tile_cost[k] holds the costs of an enqueued draw
+    bool fb_order_valid[2] = {false, false};           // tile_order[k] was (or is being) written by the sort kernel
+    hipStream_t fb_stream = nullptr;                   // the sort kernel runs here, beside the draw
+    hipEvent_t fb_ev_draw[2] = {nullptr, nullptr}, fb_ev_order[2] = {nullptr, nullptr};
     int timing = 0;          // 0 off; k >= 1: bracket every k-th launch with HIP events
     int launch_counter = 0;
     int timed_launches = 0;
@@ -347,6 +359,19 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
     rc.composite = 0;
 }
 
+// Lanes per ray for one launch (atmo_set_lane_split; ATMO_LANE_SPLIT overrides for A/B runs).  Two lanes per ray double
+// the wave count at the price of a duplicated per-pixel prologue and regrouped view sums; measured on MI355X it pays
+// only where a few very long waves set the kernel time (clouds_high_rm, 1920x1080, pose P_space: -11 %) and costs
+// 5-40 % elsewhere (profiles/round2/ab_lane_split.txt), so "auto" (0) is one lane per ray.
+int choose_split(const AtmoContext *ctx, const AtmoFrame *f) {
+    (void)f;
+    if (const char *e = std::getenv("ATMO_LANE_SPLIT")) {
+        if (e[0] == '1') return 1;
+        if (e[0] == '2') return 2;
+    }
+    return ctx->lane_split == 2 ? 2 : 1;
+}
+
 void drain_timing(AtmoContext *ctx) {
     for (auto &pr : ctx->pending) {
         if (hipEventSynchronize(pr.second) == hipSuccess) {
@@ -439,6 +464,18 @@ int atmo_destroy(AtmoContext *ctx) {
     dev_free(ctx->blue);
     dev_free(ctx->shape);
     dev_free(ctx->cube);
+    if (ctx->fb_stream) {
+        (void)hipStreamSynchronize(ctx->fb_stream);
+        (void)hipStreamDestroy(ctx->fb_stream);
+        for (int k = 0; k < 2; ++k) {
+            if (ctx->fb_ev_draw[k]) (void)hipEventDestroy(ctx->fb_ev_draw[k]);
+            if (ctx->fb_ev_order[k]) (void)hipEventDestroy(ctx->fb_ev_order[k]);
+        }
+    }
+    for (int k = 0; k < 2; ++k) {
+        dev_free(ctx->tile_cost[k]);
+        dev_free(ctx->tile_order[k]);
+    }
     delete ctx;
     return ATMO_OK;
 }
@@ -685,6 +722,48 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         rc.composite = 1;
     }
     hipStream_t s = (hipStream_t)stream;
+    const int split = choose_split(ctx, frame);
+    int gx = 0, gy = 0;
+    atmo::render_grid(rc, split, &gx, &gy);
+    rc.tiles_x = gx;
+    // default (-1): on for the raymarched-light variant, whose wave costs are the most skewed (profiles/round2/ab_tile_feedback.txt)
+    bool feedback = ctx->tile_feedback == 1 || (ctx->tile_feedback < 0 && (ctx->flags & atmo::KF_CLOUD_LIGHT_RM));
+    if (const char *e = std::getenv("ATMO_TILE_FEEDBACK")) feedback = e[0] == '1';  // A/B runs
+    if (feedback) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) feedback = false;  // no side-stream work inside a graph
+    }
+    int fbk = -1;
+    if (feedback && (long long)gx * gy >= 512) {  // tiny launches: nothing to schedule
+        const size_t bytes = (size_t)gx * gy * sizeof(uint32_t);
+        if (ctx->fb_tiles_x != gx || ctx->fb_tiles_y != gy || ctx->fb_split != split || !ctx->tile_cost[0].ptr) {
+            // first launch of this grid: allocate (synchronous, once) and start recording
+            if (!ctx->fb_stream) {
+                HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->fb_stream, hipStreamNonBlocking));
+                for (int k = 0; k < 2; ++k) {
+                    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fb_ev_draw[k], hipEventDisableTiming));
+                    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fb_ev_order[k], hipEventDisableTiming));
+                }
+            }
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->fb_stream));
+            for (int k = 0; k < 2; ++k) {
+                int rc1 = dev_alloc(ctx, ctx->tile_cost[k], bytes);
+                if (rc1 == ATMO_OK) rc1 = dev_alloc(ctx, ctx->tile_order[k], bytes);
+                if (rc1 != ATMO_OK) return rc1;
+                HIP_TRY(ctx, hipMemsetAsync(ctx->tile_cost[k].ptr, 0, bytes, s));
+                ctx->fb_cost_valid[k] = ctx->fb_order_valid[k] = false;
+            }
+            ctx->fb_tiles_x = gx; ctx->fb_tiles_y = gy; ctx->fb_split = split;
+            ctx->fb_n = 0;
+        }
+        fbk = (int)(ctx->fb_n & 1u);
+        if (ctx->fb_order_valid[fbk]) {  // sorted during the previous draw from the costs of the draw before it
+            HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->fb_ev_order[fbk], 0));
+            rc.tile_order = (const uint32_t *)ctx->tile_order[fbk].ptr;
+        }
+        rc.tile_cost = (uint32_t *)ctx->tile_cost[fbk].ptr;
+    }
+    // kernel timing brackets the draw kernel alone (the tile-order kernel in front of it shows in the step time)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = ctx->timing > 0 && (ctx->launch_counter++ % ctx->timing) == 0;
     if (timed) {
@@ -692,7 +771,23 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         HIP_TRY(ctx, hipEventCreate(&e1));
         HIP_TRY(ctx, hipEventRecord(e0, s));
     }
-    HIP_TRY(ctx, atmo::launch_render(ctx->flags, rc, s));
+    HIP_TRY(ctx, atmo::launch_render(ctx->flags, split, rc, s));
+    if (fbk >= 0) {
+        // While this draw runs, sort the tiles for the NEXT draw on the side stream, from the costs the PREVIOUS draw
+        // left in the other buffer (the sort also clears them for the next draw to write).
+        HIP_TRY(ctx, hipEventRecord(ctx->fb_ev_draw[fbk], s));
+        ctx->fb_cost_valid[fbk] = true;
+        const int o = fbk ^ 1;
+        if (ctx->fb_cost_valid[o]) {
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->fb_stream, ctx->fb_ev_draw[o], 0));
+            HIP_TRY(ctx, atmo::launch_tile_order((uint32_t *)ctx->tile_cost[o].ptr, (uint32_t *)ctx->tile_order[o].ptr, gx * gy, ctx->fb_stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->fb_ev_order[o], ctx->fb_stream));
+            ctx->fb_order_valid[o] = true;
+            ctx->fb_cost_valid[o] = false;
+        }
+        ctx->fb_n += 1;
+    }
+    ctx->last_split = split;
     if (timed) {
         HIP_TRY(ctx, hipEventRecord(e1, s));
         ctx->pending.emplace_back(e0, e1);
@@ -711,6 +806,21 @@ int atmo_set_precision(AtmoContext *ctx, int mode) {
 int atmo_set_host_double_precision(AtmoContext *ctx, int enable) {
     if (!ctx) return ATMO_E_ARG;
     ctx->host_double_precision = enable ? 1 : 0;
+    return ATMO_OK;
+}
+
+int atmo_set_tile_feedback(AtmoContext *ctx, int mode) {
+    if (!ctx) return ATMO_E_ARG;
+    if (mode < -1 || mode > 1) return fail(ctx, ATMO_E_ARG, "atmo_set_tile_feedback: -1 (by variant), 0 (off) or 1 (on)");
+    ctx->tile_feedback = mode;
+    ctx->fb_tiles_x = ctx->fb_tiles_y = 0;  // restart the feedback state at the next launch
+    return ATMO_OK;
+}
+
+int atmo_set_lane_split(AtmoContext *ctx, int lanes_per_ray) {
+    if (!ctx) return ATMO_E_ARG;
+    if (lanes_per_ray < 0 || lanes_per_ray > 2) return fail(ctx, ATMO_E_ARG, "atmo_set_lane_split: 0 (auto), 1 or 2 lanes per ray");
+    ctx->lane_split = lanes_per_ray;
     return ATMO_OK;
 }
 
@@ -753,7 +863,7 @@ int atmo_selftest_exact_math(AtmoContext *ctx, uint32_t first_bits, uint32_t cou
 
 const char *atmo_kernel_name(AtmoContext *ctx) {
     if (!ctx) return "";
-    return atmo::render_kernel_name(ctx->flags, ctx->light_steps);
+    return atmo::render_kernel_name(ctx->flags, ctx->light_steps, ctx->last_split);
 }
 
 const char *atmo_last_error_string(AtmoContext *ctx) {

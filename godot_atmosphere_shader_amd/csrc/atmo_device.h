@@ -63,6 +63,10 @@ struct RenderConsts {
     int32_t out_pitch;       // pixels per output row
     int32_t out_x0, out_y0;  // viewport pixel that maps to out[0]
     int32_t composite;       // 1 => straight-alpha "mix" blend over the existing contents, discarded pixels untouched
+    // --- launch order (atmo_set_tile_feedback)
+    int32_t tiles_x;                // tiles per row of the launch grid
+    const uint32_t *tile_order;     // null => tile = linear block index; else the tile each block shades (heaviest first)
+    uint32_t *tile_cost;            // null => no feedback; else per-tile max wave duration in shader cycles (atomicMax)
 };
 
 struct BakeConsts {
@@ -83,10 +87,12 @@ struct NoiseCubemapConsts {
 // kernel launchers (atmo_kernels.hip)
 enum KernelFlags : int { KF_CLOUDS = 1, KF_CLOUD_LIGHT_RM = 2, KF_LIGHT_DIRECT = 4, KF_LITE = 8, KF_PRECISE = 16 };
 
-hipError_t launch_render(int flags, const RenderConsts &rc, hipStream_t stream);
+hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream_t stream);
 hipError_t launch_bake(const BakeConsts &bc, hipStream_t stream);
+hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int n, hipStream_t stream);
+void render_grid(const RenderConsts &rc, int split, int *tiles_x, int *tiles_y);
 hipError_t launch_noise_cubemap(const NoiseCubemapConsts &nc, hipStream_t stream);
-const char *render_kernel_name(int flags, int light_steps);
+const char *render_kernel_name(int flags, int light_steps, int split);
 hipError_t launch_selftest(uint32_t first_bits, uint32_t count, float c, float rc, unsigned int *mismatch_dev, hipStream_t stream);
 
 }  // namespace atmo

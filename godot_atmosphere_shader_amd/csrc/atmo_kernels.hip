@@ -26,6 +26,8 @@
 //   optical_depth.gdshader:17-31,45-68                  LUT bake                 -> atmo_bake_kernel
 #include "atmo_device.h"
 
+#include <cstdio>
+
 namespace atmo {
 
 // Workgroup tile in pixels.  16x16 = 4 waves; 16x4 = one wave per workgroup (finer-grained dispatch: shorter tail when
@@ -40,14 +42,6 @@ constexpr int TILE_H = ATMO_TILE_H;
 #ifndef ATMO_WAVE_W
 #define ATMO_WAVE_W 16
 #endif
-// 1: per-lane search-ahead to the next lit cloud sample in the raymarched-light variant (see march_clouds).
-// Measured slower than lock-step marching (profiles/round1/ab_rm_compaction.txt): neighbouring rays meet cloud at
-// the same step indices, so lock step already keeps the light block's lanes full, and search-ahead desynchronises
-// the lanes' texture footprints.  Off by default; kept for A/B.
-#ifndef ATMO_RM_COMPACT
-#define ATMO_RM_COMPACT 0
-#endif
-constexpr bool RM_COMPACT = ATMO_RM_COMPACT != 0;
 // Ablation knob for the LDS-staging question (profiles/round1/ab_fetch_ablation.txt): 1 replaces every texture
 // gather (LUT, shape, cubemap) by arithmetic on its address, keeping all address and filter math alive.  The speed-up
 // it shows is an upper bound on what ANY cheaper fetch path (LDS staging included) could give.  Never shipped.
@@ -119,6 +113,17 @@ __device__ __forceinline__ float exact_div_uniform(float a, float c, float rc) {
     const float q0 = a * rc;
     const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, c, a), rc, q0);
     return __builtin_fmaf(__builtin_fmaf(-q1, c, a), rc, q1);
+}
+
+// ---- lane-split mode: two adjacent lanes share one ray (SPLIT = 2) -------------------------------------------------
+// At 1920x1080 a frame is only ~20 000 busy waves for 1024 SIMDs x 7-8 wave slots: too few to keep two waves' fast
+// instructions pairing on a SIMD and to cover the gathers (tools/concurrency_probe.py: two concurrent frames finish in
+// 1.3x, not 2x, the time of one).  With SPLIT = 2 a wave holds 32 rays; lanes 2r and 2r+1 march the same ray, each takes
+// every second cloud step / half of the view steps, and the partner's per-step results cross over with one DPP
+// quad_perm move -- the one cross-lane exchange this algorithm has a use for.  The host picks SPLIT per launch by size.
+__device__ __forceinline__ float swap_adjacent(float x) {
+    // v_mov_b32_dpp quad_perm:[1,0,3,2]: lane 2r <-> lane 2r+1
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
 }
 
 // ---- exact (IEEE, unfused) helpers: must match a scalar fp32 evaluation bit for bit -------------
@@ -339,10 +344,16 @@ __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, in
 //   * positions are kept relative to the planet centre; 1 - clamp((r-R)/H, 0, 1) = clamp(fma(r, -1/H, 1 + R/H), 0, 1)
 //     is one v_fma with the clamp modifier.
 // LSTEPS > 0: light-step count known at compile time (fully unrolled); 0: rc.light_steps at run time.
-template <bool DIRECT, int LSTEPS>
-__device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 dir, float t_begin, float step_len, float jitter) {
+// SPLIT = 2: lane `half` integrates its half of the view steps ([0, n0) / [n0, steps)) with the optical depth counted
+// from its own first sample; exp(-(V_A + v) k) = exp(-V_A k) exp(-v k) folds the first half's total V_A into the
+// second half's sum afterwards (same real function, one extra exp per channel per ray).
+template <bool DIRECT, int LSTEPS, int SPLIT>
+__device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 dir, float t_begin, float step_len, float jitter, int half) {
 #pragma clang fp contract(fast)
-    const int steps = rc.view_steps;
+    const int n0 = SPLIT == 2 ? (rc.view_steps + 1) / 2 : rc.view_steps;
+    const int first = (SPLIT == 2 && half) ? n0 : 0;
+    const int steps = (SPLIT == 2 && half) ? rc.view_steps - n0 : n0;
+    t_begin = SPLIT == 2 ? fmaf((float)first, step_len, t_begin) : t_begin;
     const float inv_h = hw_rcp(rc.atmosphere_height);
     const float ninv_h = -inv_h;
     const float c1 = fmaf(rc.planet_radius, inv_h, 1.0f);
@@ -419,6 +430,14 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
         ox += sdx; oy += sdy; oz += sdz;
     }
 
+    if (SPLIT == 2) {
+        // lane 0 of the pair: total = A + exp2(V_A k) * B  (its own sums are A, the partner's are B); lane 1's result is unused
+        const float od_b = swap_adjacent(view_od), lr_b = swap_adjacent(lr), lg_b = swap_adjacent(lg), lb_b = swap_adjacent(lb);
+        lr = fmaf(lr_b, hw_exp2(view_od * kr), lr);
+        lg = fmaf(lg_b, hw_exp2(view_od * kg), lg);
+        lb = fmaf(lb_b, hw_exp2(view_od * kb), lb);
+        view_od += od_b;
+    }
     const float alpha = 1.0f - hw_exp2(-view_od * LOG2E);
     float4 o;
     o.x = sat(fmaf(lr, rc.coeff[0], rc.ambient[0])) * rc.modulate[0];
@@ -430,11 +449,14 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
 
 // ---- compute_atmosphere, v1 "lite" (shaders/include/atmosphere_funcs_v1.gdshaderinc:15-63) ----------------
 // Faked 4-colour model: no LUT, no exp.  factor = prod(1 - density*step), light = mean(clamp(1.2*cos + 0.5)^2).
-__device__ __forceinline__ float4 march_atmosphere_v1(const RenderConsts &rc, V3 dir, float t_begin, float t_end) {
+template <int SPLIT>
+__device__ __forceinline__ float4 march_atmosphere_v1(const RenderConsts &rc, V3 dir, float t_begin, float t_end, int half) {
 #pragma clang fp contract(fast)
-    const int steps = rc.view_steps;
-    const float inv_steps = 1.0f / (float)steps;
+    const float inv_steps = 1.0f / (float)rc.view_steps;
     const float step_len = (t_end - t_begin) * inv_steps;
+    const int n0 = SPLIT == 2 ? (rc.view_steps + 1) / 2 : rc.view_steps;
+    const int steps = (SPLIT == 2 && half) ? rc.view_steps - n0 : n0;
+    t_begin = (SPLIT == 2 && half) ? fmaf((float)n0, step_len, t_begin) : t_begin;
     const float inv_h = hw_rcp(rc.atmosphere_height);
     const float ninv_h = -inv_h;
     const float c1 = fmaf(rc.planet_radius, inv_h, 1.0f);
@@ -454,6 +476,10 @@ __device__ __forceinline__ float4 march_atmosphere_v1(const RenderConsts &rc, V3
         light_sum = fmaf(l, l, light_sum);
         factor *= fmaf(y * y * y, nds, 1.0f);
         ox += sdx; oy += sdy; oz += sdz;
+    }
+    if (SPLIT == 2) {  // product and sum over both halves
+        factor *= swap_adjacent(factor);
+        light_sum += swap_adjacent(light_sum);
     }
     const float light_factor = light_sum * inv_steps;
     const float atmo_factor = 1.0f - factor;
@@ -566,8 +592,12 @@ __device__ __forceinline__ float light_raymarched(const RenderConsts &rc, float 
 }
 
 // raymarch_cloud (cloud_funcs.gdshaderinc:175-247).  Returns (total_light, alpha).
-template <bool RM, bool PRECISE>
-__device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m, float t_begin, float t_end, float jitter) {
+// SPLIT = 2: lane `half` of a pair evaluates the samples with step index = half (mod 2) -- position chain, density,
+// light -- while the recurrence over the samples (transmittance floor, light sum, alpha) runs in step order on the
+// pair's values exchanged by DPP.  Every sample is evaluated with the same arithmetic as in the one-lane form (the
+// position is still advanced one rounded addition per step), so the result is bit-identical; only lane 0's is used.
+template <bool RM, bool PRECISE, int SPLIT>
+__device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m, float t_begin, float t_end, float jitter, int half) {
     const int steps = rc.cloud_steps;
     // exact: positions
     t_end = t_begin + fminf(t_end - t_begin, rc.max_d);
@@ -578,6 +608,9 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
     float pz = (rc.origin_model[2] + dir_m.z * js) + dir_m.z * t_begin;
     const float ddx = dir_m.x * step_len, ddy = dir_m.y * step_len, ddz = dir_m.z * step_len;
     const float sx = rc.sun_dir_model[0], sy = rc.sun_dir_model[1], sz = rc.sun_dir_model[2];
+    if (SPLIT == 2 && half) {  // lane 1 starts on sample 1
+        px = px + ddx; py = py + ddy; pz = pz + ddz;
+    }
 
     // pow(dot(ray_dir, sun_dir), 16) is constant along the ray; dp <= 0 => 0
     const float dp = dir_m.x * sx + dir_m.y * sy + dir_m.z * sz;
@@ -591,59 +624,58 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
     const float scale_step = rc.cloud_density_scale * step_len;
     const float neg_scale_step_log2e = -scale_step * LOG2E;
 
-    // Default (RM_COMPACT = 0): lock-step march, the inner `while` runs exactly once per step.
-    // Experiment (RM_COMPACT = 1, raymarched light only): every lane first searches ahead on its own to its next
-    // non-zero-density sample (cheap iterations, the wave reconverges at the loop exit), then all lanes that found one
-    // evaluate the 6-tap light together.  Per ray the samples are visited in the same order, so the result is
-    // bit-identical; it measured 1.5x SLOWER (see ATMO_RM_COMPACT above), so it is off.
-    int i = 0;
-    for (;;) {
-        float r = 0.0f, hr = 0.0f, density = 0.0f;
-        while (i < steps) {
-            cloud_height(rc, px, py, pz, r, hr);
-            density = cloud_density<true, PRECISE>(rc, px, py, pz, hr);
-            if (RM_COMPACT && RM) {
-                if (density > 0.0f) break;  // a zero-density sample contributes exactly nothing: keep searching
-                px = px + ddx; py = py + ddy; pz = pz + ddz;  // exact: pos += ray_dir * step_len
-                ++i;
-            } else {
-                break;
-            }
-        }
-        if (i >= steps) break;
-        // A zero-density sample contributes nothing: transmittance 1, light term 0, and the light value itself
-        // (6 more density taps in the raymarched variant) is never observed.
+    // one sample of the recurrence (clouds:216-236); la = raymarched light or the height ratio, lb = planet-shadow factor
+    auto integrate = [&](float density, float la, float lb) {
+        // A zero-density sample contributes nothing: transmittance 1, light term 0.
         if (density > 0.0f) {
 #pragma clang fp contract(fast)
-            float light;
-            if (RM) {
-                light = light_raymarched<PRECISE>(rc, px, py, pz, hr, sx, sy, sz);
-            } else {
-                light = fmaf(p16, one_minus_alpha, hr);
-            }
-            // get_planet_shadow: smoothstep(-0.3, 0.3, dot(normalize(pos), -sun_dir))
-            const float sd = -(px * sx + py * sy + pz * sz) * hw_rcp(r);
-            const float st = sat((sd + 0.3f) * (1.0f / 0.6f));
-            const float shadow = st * st * (3.0f - 2.0f * st);
-            light *= fmaf(shadow, 0.002f - 1.0f, 1.0f);
-
+            float light = RM ? la : fmaf(p16, one_minus_alpha, la);
+            light *= lb;
             const float transmittance = hw_exp2(density * neg_scale_step_log2e);
             total_transmittance = fmaxf(total_transmittance * transmittance, 0.005f);
             total_light = fmaf(light * (density * scale_step), total_transmittance, total_light);
             one_minus_alpha *= transmittance;
         }
-        // exact: pos += ray_dir * step_len
-        px = px + ddx;
-        py = py + ddy;
-        pz = pz + ddz;
-        ++i;
+    };
+
+    const int iters = (steps + SPLIT - 1) / SPLIT;
+    for (int it = 0; it < iters; ++it) {
+        float density = 0.0f, la = 0.0f, lb = 0.0f;
+        if (SPLIT == 1 || it * SPLIT + half < steps) {
+            float r, hr;
+            cloud_height(rc, px, py, pz, r, hr);
+            density = cloud_density<true, PRECISE>(rc, px, py, pz, hr);
+            // the light value of a zero-density sample (6 more density taps in the raymarched variant) is never observed
+            if (density > 0.0f) {
+#pragma clang fp contract(fast)
+                la = RM ? light_raymarched<PRECISE>(rc, px, py, pz, hr, sx, sy, sz) : hr;
+                // get_planet_shadow: smoothstep(-0.3, 0.3, dot(normalize(pos), -sun_dir))
+                const float sd = -(px * sx + py * sy + pz * sz) * hw_rcp(r);
+                const float st = sat((sd + 0.3f) * (1.0f / 0.6f));
+                const float shadow = st * st * (3.0f - 2.0f * st);
+                lb = fmaf(shadow, 0.002f - 1.0f, 1.0f);
+            }
+        }
+        // exact: pos += ray_dir * step_len, once per step of the ray
+#pragma unroll
+        for (int k = 0; k < SPLIT; ++k) {
+            px = px + ddx; py = py + ddy; pz = pz + ddz;
+        }
+        if (SPLIT == 1) {
+            integrate(density, la, lb);
+        } else {
+            // step order for lane 0 of the pair: its own sample, then the partner's (lane 1's order is irrelevant)
+            const float d1 = swap_adjacent(density), a1 = swap_adjacent(la), b1 = swap_adjacent(lb);
+            integrate(density, la, lb);
+            integrate(d1, a1, b1);
+        }
     }
     return make_float2(total_light, 1.0f - one_minus_alpha);
 }
 
 // ---- atmosphere_fragment ---------------------------------------------------------------------------
-template <int FLAGS, int LSTEPS>
-__global__ __launch_bounds__(TILE_W *TILE_H) void atmo_render_kernel(const RenderConsts rc) {
+template <int FLAGS, int LSTEPS, int SPLIT>
+__device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int tile_x, const int tile_y) {
     constexpr bool CLOUDS = (FLAGS & KF_CLOUDS) != 0;
     constexpr bool RM = (FLAGS & KF_CLOUD_LIGHT_RM) != 0;
     constexpr bool DIRECT = (FLAGS & KF_LIGHT_DIRECT) != 0;
@@ -651,11 +683,15 @@ __global__ __launch_bounds__(TILE_W *TILE_H) void atmo_render_kernel(const Rende
     constexpr bool PRECISE = (FLAGS & KF_PRECISE) != 0;
 
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    // SPLIT = 2: lanes 2r, 2r+1 share ray r; a wave covers WAVE_W x (32 / WAVE_W) pixels, the workgroup TILE_W x TILE_H / 2
+    const int ray = SPLIT == 2 ? lane >> 1 : lane;
+    const int half = SPLIT == 2 ? lane & 1 : 0;
     constexpr int WAVES_X = TILE_W / (WAVE_W > TILE_W ? TILE_W : WAVE_W);
-    const int lx = (wave % WAVES_X) * WAVE_W + lane % WAVE_W;
-    const int ly = (wave / WAVES_X) * WAVE_H + lane / WAVE_W;
-    const int px = rc.x0 + blockIdx.x * TILE_W + lx;
-    const int py = rc.y0 + blockIdx.y * TILE_H + ly;
+    constexpr int WAVE_ROWS = WAVE_H / SPLIT;
+    const int lx = (wave % WAVES_X) * WAVE_W + ray % WAVE_W;
+    const int ly = (wave / WAVES_X) * WAVE_ROWS + ray / WAVE_W;
+    const int px = rc.x0 + tile_x * TILE_W + lx;
+    const int py = rc.y0 + tile_y * (TILE_H / SPLIT) + ly;
     if (px >= rc.x1 || py >= rc.y1) return;
     float4 *out = rc.out + (size_t)(py - rc.out_y0) * (size_t)rc.out_pitch + (px - rc.out_x0);
 
@@ -688,7 +724,7 @@ __global__ __launch_bounds__(TILE_W *TILE_H) void atmo_render_kernel(const Rende
     const float2 rs_atmo = hit_radius(sh, rc.atmosphere_radius);
 
     if (rs_atmo.x == rs_atmo.y) {  // discard: nothing reaches the blend stage
-        if (!rc.composite) *out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (!rc.composite && half == 0) *out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         return;
     }
     const float t_begin = fmaxf(rs_atmo.x, 0.0f);
@@ -705,10 +741,10 @@ __global__ __launch_bounds__(TILE_W *TILE_H) void atmo_render_kernel(const Rende
 
     float4 rgba;
     if (LITE) {
-        rgba = march_atmosphere_v1(rc, dir, t_begin, t_end);  // main:172-175
+        rgba = march_atmosphere_v1<SPLIT>(rc, dir, t_begin, t_end, half);  // main:172-175
     } else {
         const float view_step_len = ieee_div(t_end - t_begin, (float)rc.view_steps);
-        rgba = march_atmosphere<DIRECT, LSTEPS>(rc, dir, t_begin, view_step_len, jitter);
+        rgba = march_atmosphere<DIRECT, LSTEPS, SPLIT>(rc, dir, t_begin, view_step_len, jitter, half);
     }
 
     if (CLOUDS) {
@@ -724,7 +760,7 @@ __global__ __launch_bounds__(TILE_W *TILE_H) void atmo_render_kernel(const Rende
                 dir_m.x = M[0] * dir.x + M[4] * dir.y + M[8] * dir.z;
                 dir_m.y = M[1] * dir.x + M[5] * dir.y + M[9] * dir.z;
                 dir_m.z = M[2] * dir.x + M[6] * dir.y + M[10] * dir.z;
-                const float2 rr = march_clouds<RM, PRECISE>(rc, dir_m, c0, c1, jitter);
+                const float2 rr = march_clouds<RM, PRECISE, SPLIT>(rc, dir_m, c0, c1, jitter, half);
                 {
 #pragma clang fp contract(fast)
                     const float cl = rr.x, ca = rr.y;
@@ -750,6 +786,7 @@ __global__ __launch_bounds__(TILE_W *TILE_H) void atmo_render_kernel(const Rende
             }
         }
     }
+    if (SPLIT == 2 && half) return;  // lane 0 of the pair holds the ray's result
     if (rc.composite) {
         // What the engine's blend stage does with ALBEDO/ALPHA of an unshaded, blend_mix spatial material:
         // colour: SRC_ALPHA, ONE_MINUS_SRC_ALPHA; alpha: ONE, ONE_MINUS_SRC_ALPHA.
@@ -765,6 +802,112 @@ __global__ __launch_bounds__(TILE_W *TILE_H) void atmo_render_kernel(const Rende
     } else {
         *out = rgba;
     }
+}
+
+// The launch: one workgroup per TILE_W x (TILE_H / SPLIT) pixel tile.
+//
+// Tile order with cost feedback (rc.tile_order / rc.tile_cost, atmo_set_tile_feedback): the hardware dispatches
+// workgroups in blockIdx order, and at 1920x1080 the kernel time of the cloud variants is set by the critical path of
+// the few heaviest waves (all lanes in dense cloud: ~100 k VALU instructions against 11 k on average) when they happen
+// to start late.  Every wave records its duration (s_memtime) into tile_cost; before the next launch
+// atmo_tile_order_kernel sorts the tiles by that cost, heaviest first (longest-processing-time-first list scheduling),
+// and blockIdx indexes the sorted list.  Frames of an animation are coherent, so the previous frame's costs predict this
+// frame's; the picture does not depend on the order.
+template <int FLAGS, int LSTEPS, int SPLIT = 1>
+__global__ __launch_bounds__(TILE_W *TILE_H) void atmo_render_kernel(const RenderConsts rc) {
+    uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
+    if (rc.tile_order != nullptr) tile = rc.tile_order[tile];
+    const uint32_t tile_y = tile / (uint32_t)rc.tiles_x, tile_x = tile - tile_y * (uint32_t)rc.tiles_x;
+    uint64_t t0 = 0;
+    if (rc.tile_cost != nullptr) t0 = __builtin_amdgcn_s_memtime();
+    shade_pixel<FLAGS, LSTEPS, SPLIT>(rc, (int)tile_x, (int)tile_y);
+    if (rc.tile_cost != nullptr && (threadIdx.x & 63) == 0) {
+        const uint64_t dt = __builtin_amdgcn_s_memtime() - t0;
+        atomicMax(&rc.tile_cost[tile], (uint32_t)(dt > 0xffffffffull ? 0xffffffffull : dt));
+    }
+}
+
+// Stable counting sort of the tiles by the cost the previous launch recorded, heaviest class first; clears the costs
+// for the next launch.  32 classes = half octaves of the wave duration (2^8 .. 2^24 cycles); tiles of one class keep
+// their row-major order, so neighbouring tiles -- which share texture footprints in L1/L2 -- still run together.
+// One workgroup of 512 threads: every thread owns a contiguous chunk of tiles (read 16 at a time with independent
+// loads) and a private column of counters in LDS (no atomics); the 32 x 512 counters are scanned per class with wave
+// shuffles; then every thread scatters its chunk in order.  ~5 us for the 8 160 tiles of a 1920x1080 launch.
+constexpr int ORDER_THREADS = 512, ORDER_CLASSES = 32, ORDER_BATCH = 16;
+__device__ __forceinline__ uint32_t tile_cost_class(uint32_t c) {
+    if (c == 0) return ORDER_CLASSES - 1;
+    const int msb = 31 - __builtin_clz(c);
+    const int q = msb * 2 + (msb > 0 ? (int)((c >> (msb - 1)) & 1u) : 0) - 16;
+    return (uint32_t)(ORDER_CLASSES - 1 - (q < 0 ? 0 : (q > ORDER_CLASSES - 1 ? ORDER_CLASSES - 1 : q)));
+}
+
+__global__ __launch_bounds__(ORDER_THREADS) void atmo_tile_order_kernel(uint32_t *__restrict__ cost, uint32_t *__restrict__ order, int n) {
+    __shared__ uint32_t cnt[ORDER_CLASSES][ORDER_THREADS];
+    __shared__ uint32_t base[ORDER_CLASSES];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int chunk = (n + ORDER_THREADS - 1) / ORDER_THREADS;
+    const int i0 = min(t * chunk, n), i1 = min(i0 + chunk, n);
+#pragma unroll
+    for (int b = 0; b < ORDER_CLASSES; ++b) cnt[b][t] = 0;
+    for (int i = i0; i < i1; i += ORDER_BATCH) {
+        uint32_t c[ORDER_BATCH];
+#pragma unroll
+        for (int k = 0; k < ORDER_BATCH; ++k) c[k] = (i + k < i1) ? cost[i + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < ORDER_BATCH; ++k)
+            if (i + k < i1) cnt[tile_cost_class(c[k])][t] += 1;
+    }
+    __syncthreads();
+    // exclusive scan of each class's 512 counters: 8 waves x 4 classes, 8 counters per lane + a wave scan
+    constexpr int PER_LANE = ORDER_THREADS / 64, PER_WAVE = ORDER_CLASSES / (ORDER_THREADS / 64);
+    for (int b = wave * PER_WAVE; b < (wave + 1) * PER_WAVE; ++b) {
+        uint32_t local[PER_LANE], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER_LANE; ++k) {
+            local[k] = sum;
+            sum += cnt[b][lane * PER_LANE + k];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t x = __shfl_up(incl, d);
+            if (lane >= d) incl += x;
+        }
+        const uint32_t excl = incl - sum;
+#pragma unroll
+        for (int k = 0; k < PER_LANE; ++k) cnt[b][lane * PER_LANE + k] = excl + local[k];
+        if (lane == 63) base[b] = incl;
+    }
+    __syncthreads();
+    if (t < 64) {  // exclusive scan of the 32 class totals
+        const uint32_t c = t < ORDER_CLASSES ? base[t] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t x = __shfl_up(incl, d);
+            if (lane >= d) incl += x;
+        }
+        if (t < ORDER_CLASSES) base[t] = incl - c;
+    }
+    __syncthreads();
+    for (int i = i0; i < i1; i += ORDER_BATCH) {
+        uint32_t c[ORDER_BATCH];
+#pragma unroll
+        for (int k = 0; k < ORDER_BATCH; ++k) c[k] = (i + k < i1) ? cost[i + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < ORDER_BATCH; ++k)
+            if (i + k < i1) {
+                const uint32_t b = tile_cost_class(c[k]);
+                order[base[b] + cnt[b][t]] = (uint32_t)(i + k);
+                cnt[b][t] += 1;
+                cost[i + k] = 0;
+            }
+    }
+}
+
+hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(atmo_tile_order_kernel, dim3(1), dim3(ORDER_THREADS), 0, stream, cost, order, n);
+    return hipGetLastError();
 }
 
 // ---- LUT bake (optical_depth.gdshader:17-31,45-68): exact evaluation, one texel per lane ---------------
@@ -907,58 +1050,59 @@ hipError_t launch_selftest(uint32_t first_bits, uint32_t count, float c, float r
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------
-template <int FLAGS, int LSTEPS>
-static hipError_t launch_t(const RenderConsts &rc, hipStream_t stream) {
-    dim3 grid((rc.x1 - rc.x0 + TILE_W - 1) / TILE_W, (rc.y1 - rc.y0 + TILE_H - 1) / TILE_H);
-    hipLaunchKernelGGL((atmo_render_kernel<FLAGS, LSTEPS>), grid, dim3(TILE_W * TILE_H), 0, stream, rc);
+void render_grid(const RenderConsts &rc, int split, int *tiles_x, int *tiles_y) {
+    const int th = TILE_H / (split == 2 ? 2 : 1);  // pixel rows per workgroup
+    *tiles_x = (rc.x1 - rc.x0 + TILE_W - 1) / TILE_W;
+    *tiles_y = (rc.y1 - rc.y0 + th - 1) / th;
+}
+
+template <int FLAGS, int LSTEPS, int SPLIT>
+static hipError_t launch_s(const RenderConsts &rc, hipStream_t stream) {
+    int gx, gy;
+    render_grid(rc, SPLIT, &gx, &gy);
+    if (gx != rc.tiles_x) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((atmo_render_kernel<FLAGS, LSTEPS, SPLIT>), dim3(gx, gy), dim3(TILE_W * TILE_H), 0, stream, rc);
     return hipGetLastError();
+}
+
+template <int FLAGS, int LSTEPS>
+static hipError_t launch_t(const RenderConsts &rc, int split, hipStream_t stream) {
+    return split == 2 ? launch_s<FLAGS, LSTEPS, 2>(rc, stream) : launch_s<FLAGS, LSTEPS, 1>(rc, stream);
 }
 
 // direct light mode: 8 light steps (BASELINE's "32 view x 8 light") has an unrolled instantiation
 template <int FLAGS>
-static hipError_t launch_direct(const RenderConsts &rc, hipStream_t stream) {
-    return rc.light_steps == 8 ? launch_t<FLAGS, 8>(rc, stream) : launch_t<FLAGS, 0>(rc, stream);
+static hipError_t launch_direct(const RenderConsts &rc, int split, hipStream_t stream) {
+    return rc.light_steps == 8 ? launch_t<FLAGS, 8>(rc, split, stream) : launch_t<FLAGS, 0>(rc, split, stream);
 }
 
-hipError_t launch_render(int flags, const RenderConsts &rc, hipStream_t stream) {
+hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream_t stream) {
     switch (flags) {
-    case 0: return launch_t<0, 0>(rc, stream);
-    case KF_LIGHT_DIRECT: return launch_direct<KF_LIGHT_DIRECT>(rc, stream);
-    case KF_CLOUDS: return launch_t<KF_CLOUDS, 0>(rc, stream);
-    case KF_CLOUDS | KF_LIGHT_DIRECT: return launch_direct<KF_CLOUDS | KF_LIGHT_DIRECT>(rc, stream);
-    case KF_CLOUDS | KF_CLOUD_LIGHT_RM: return launch_t<KF_CLOUDS | KF_CLOUD_LIGHT_RM, 0>(rc, stream);
-    case KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT: return launch_direct<KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT>(rc, stream);
-    case KF_LITE: return launch_t<KF_LITE, 0>(rc, stream);
-    case KF_LITE | KF_CLOUDS: return launch_t<KF_LITE | KF_CLOUDS, 0>(rc, stream);
-    // precise cloud density (atmo_set_precision)
-    case KF_PRECISE | KF_CLOUDS: return launch_t<KF_PRECISE | KF_CLOUDS, 0>(rc, stream);
-    case KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT: return launch_direct<KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT>(rc, stream);
-    case KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM: return launch_t<KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM, 0>(rc, stream);
+    case 0: return launch_t<0, 0>(rc, split, stream);
+    case KF_LIGHT_DIRECT: return launch_direct<KF_LIGHT_DIRECT>(rc, split, stream);
+    case KF_CLOUDS: return launch_t<KF_CLOUDS, 0>(rc, split, stream);
+    case KF_CLOUDS | KF_LIGHT_DIRECT: return launch_direct<KF_CLOUDS | KF_LIGHT_DIRECT>(rc, split, stream);
+    case KF_CLOUDS | KF_CLOUD_LIGHT_RM: return launch_t<KF_CLOUDS | KF_CLOUD_LIGHT_RM, 0>(rc, split, stream);
+    case KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT: return launch_direct<KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT>(rc, split, stream);
+    case KF_LITE: return launch_t<KF_LITE, 0>(rc, split, stream);
+    case KF_LITE | KF_CLOUDS: return launch_t<KF_LITE | KF_CLOUDS, 0>(rc, split, stream);
+    // precise cloud density (atmo_set_precision 1, the default of the cloud variants)
+    case KF_PRECISE | KF_CLOUDS: return launch_t<KF_PRECISE | KF_CLOUDS, 0>(rc, split, stream);
+    case KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT: return launch_direct<KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT>(rc, split, stream);
+    case KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM: return launch_t<KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM, 0>(rc, split, stream);
     case KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT:
-        return launch_direct<KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT>(rc, stream);
-    case KF_PRECISE | KF_LITE | KF_CLOUDS: return launch_t<KF_PRECISE | KF_LITE | KF_CLOUDS, 0>(rc, stream);
+        return launch_direct<KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT>(rc, split, stream);
+    case KF_PRECISE | KF_LITE | KF_CLOUDS: return launch_t<KF_PRECISE | KF_LITE | KF_CLOUDS, 0>(rc, split, stream);
     default: return hipErrorInvalidValue;
     }
 }
 
-const char *render_kernel_name(int flags, int light_steps) {
-    const bool u8 = (flags & KF_LIGHT_DIRECT) && light_steps == 8;
-    switch (flags) {
-    case 0: return "atmo_render_kernel<0, 0>";
-    case KF_LIGHT_DIRECT: return u8 ? "atmo_render_kernel<4, 8>" : "atmo_render_kernel<4, 0>";
-    case KF_CLOUDS: return "atmo_render_kernel<1, 0>";
-    case KF_CLOUDS | KF_LIGHT_DIRECT: return u8 ? "atmo_render_kernel<5, 8>" : "atmo_render_kernel<5, 0>";
-    case KF_CLOUDS | KF_CLOUD_LIGHT_RM: return "atmo_render_kernel<3, 0>";
-    case KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT: return u8 ? "atmo_render_kernel<7, 8>" : "atmo_render_kernel<7, 0>";
-    case KF_LITE: return "atmo_render_kernel<8, 0>";
-    case KF_LITE | KF_CLOUDS: return "atmo_render_kernel<9, 0>";
-    case KF_PRECISE | KF_CLOUDS: return "atmo_render_kernel<17, 0>";
-    case KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT: return u8 ? "atmo_render_kernel<21, 8>" : "atmo_render_kernel<21, 0>";
-    case KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM: return "atmo_render_kernel<19, 0>";
-    case KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT: return u8 ? "atmo_render_kernel<23, 8>" : "atmo_render_kernel<23, 0>";
-    case KF_PRECISE | KF_LITE | KF_CLOUDS: return "atmo_render_kernel<25, 0>";
-    default: return "?";
-    }
+const char *render_kernel_name(int flags, int light_steps, int split) {
+    // demangled template name as rocprofv3 prints it: atmo_render_kernel<FLAGS, LSTEPS, SPLIT>
+    static thread_local char name[64];
+    const int lsteps = ((flags & KF_LIGHT_DIRECT) && light_steps == 8) ? 8 : 0;
+    snprintf(name, sizeof(name), "atmo_render_kernel<%d, %d, %d>", flags, lsteps, split == 2 ? 2 : 1);
+    return name;
 }
 
 hipError_t launch_bake(const BakeConsts &bc, hipStream_t stream) {

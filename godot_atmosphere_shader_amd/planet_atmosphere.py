@@ -214,7 +214,8 @@ class PlanetAtmosphere:
 
     def __init__(self, device: int = 0, light_mode: str = "lut", light_steps: int = 0,
                  view_steps: int | None = None, cloud_steps: int | None = None, blue_noise=None,
-                 precise_clouds: bool = True, double_precision: bool = False):
+                 precise_clouds: bool = True, double_precision: bool = False, lane_split: int = 0,
+                 tile_feedback: int = -1):
         self._lib = N.load()
         self._device = int(device)
         self._light_mode = {"lut": N.LIGHT_LUT, "direct": N.LIGHT_DIRECT}[light_mode]
@@ -223,6 +224,8 @@ class PlanetAtmosphere:
         self._cloud_steps_override = cloud_steps  # macro override of CLOUDS_MAX_RAYMARCH_STEPS
         self._precise_clouds = bool(precise_clouds)  # atmo_set_precision: bit-faithful cloud density (default); False = fast mode
         self._double_precision = bool(double_precision)  # `#define DOUBLE_PRECISION` (main:25): engine negates INV_VIEW origin
+        self._lane_split = int(lane_split)  # atmo_set_lane_split: 0 auto, 1 / 2 lanes per ray
+        self._tile_feedback = int(tile_feedback)  # atmo_set_tile_feedback: -1 by variant, 0 off, 1 on
         self._ctx = C.c_void_p()
         self._planet_radius = 1.0
         self._atmosphere_height = 0.1
@@ -259,6 +262,8 @@ class PlanetAtmosphere:
         self._ctx = ctx
         N.check(ctx, self._lib.atmo_set_precision(ctx, 1 if self._precise_clouds else 0))
         N.check(ctx, self._lib.atmo_set_host_double_precision(ctx, 1 if self._double_precision else 0))
+        N.check(ctx, self._lib.atmo_set_lane_split(ctx, self._lane_split))
+        N.check(ctx, self._lib.atmo_set_tile_feedback(ctx, self._tile_feedback))
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:

@@ -180,6 +180,27 @@ int atmo_set_precision(AtmoContext *ctx, int mode);
  */
 int atmo_set_host_double_precision(AtmoContext *ctx, int enable);
 
+/*
+ * Launch shape (no reference counterpart): lanes per view ray.  1 = one wavefront lane per ray (64 rays per wave);
+ * 2 = two adjacent lanes share a ray (32 rays per wave: each lane takes every second cloud sample / half of the view
+ * samples, results cross by DPP) -- twice the waves for the same frame; the cloud march is the same bits, the
+ * atmosphere sums agree within rounding.  It pays only for small launches dominated by a few very long waves
+ * (clouds_high_rm at 1920x1080: -11 %), so 0 (default, "auto") currently means 1.
+ */
+int atmo_set_lane_split(AtmoContext *ctx, int lanes_per_ray);
+
+/*
+ * Launch order (no reference counterpart): with feedback on, every draw records how long each pixel tile's waves ran,
+ * and while the next draw runs a small sort kernel on a side stream turns those costs into the tile order of the draw
+ * after it: heaviest tiles first (longest-processing-time-first list scheduling; two draws of delay, nothing on the
+ * critical path).  Cloud frames at 1920x1080 are bounded by the few tiles that sit entirely in dense cloud (~10x the
+ * mean wave); starting those first shortens the draw of clouds_high_rm by 27 % (14 % at 3840x2160), while frames whose
+ * tiles weigh about the same lose 1-6 % to the bookkeeping.  The picture does not depend on the order.
+ * -1 (default) = on for ATMO_VARIANT_CLOUDS_HIGH_RM only; 0 = off; 1 = on.  Launches inside a HIP graph capture never
+ * use it.  The per-grid buffers are allocated by the first launch of a grid size (synchronously).
+ */
+int atmo_set_tile_feedback(AtmoContext *ctx, int mode);
+
 /* Device time of `atmo_render` kernels measured with HIP events recorded around the launch on its own stream:
  * atmo_set_timing(ctx, k): k = 0 off, k >= 1 brackets every k-th launch (k > 1 keeps the ~5 us cost of recording two
  * events out of most steps); atmo_get_timing returns the number of bracketed launches and their total milliseconds
@@ -203,7 +224,8 @@ int atmo_host_layout_lut(const float *lut, int w, int h, float *apron_out);
 int atmo_selftest_exact_math(AtmoContext *ctx, uint32_t first_bits, uint32_t count, float divisor,
                              uint32_t *sqrt_mismatches, uint32_t *div_mismatches);
 
-/* Name of the kernel the current configuration launches (for matching rocprofv3 kernel traces). */
+/* Name of the kernel the most recent atmo_render of this context launched, "atmo_render_kernel<FLAGS, LSTEPS, SPLIT>"
+ * (before the first launch: the one-lane-per-ray form), for matching rocprofv3 kernel traces. */
 const char *atmo_kernel_name(AtmoContext *ctx);
 
 /* Last error message of this context (or of the failed atmo_create when ctx == NULL). Never NULL. */

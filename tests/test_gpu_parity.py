@@ -256,12 +256,12 @@ def test_host_mirror_behaviour():
     lut_b = node.read_optical_depth()
     assert not np.array_equal(lut_a, lut_b)
     node.custom_shader = load_shader("res://addons/zylann.atmosphere/shaders/planet_atmosphere_clouds_high_m.gdshader")
-    assert node.kernel_name == "atmo_render_kernel<19, 0>"
+    assert node.kernel_name.startswith("atmo_render_kernel<19, 0,")
     assert "shader_params/u_cloud_blend" in [p["name"] for p in node.get_property_list()]
     assert np.array_equal(node.read_optical_depth(), lut_b)  # parameters survived the shader switch
     # the v1 "lite" variants declare no optical-depth LUT: switching to one stops the baking (planet_atmosphere.gd:132-139)
     node.custom_shader = load_shader("planet_atmosphere_v1_clouds.gdshader")
-    assert node.kernel_name == "atmo_render_kernel<25, 0>"
+    assert node.kernel_name.startswith("atmo_render_kernel<25, 0,")
     names = [p["name"] for p in node.get_property_list()]
     assert "shader_params/u_day_color0" in names and "shader_params/u_scattering_strength" not in names
     assert node.get("shader_params/u_day_night_transition_scale") == 2.0
@@ -508,7 +508,7 @@ def test_native_host_matches_python_binding(tmp_path):
     r = subprocess.run([str(exe), str(tmp_path / "frame.bin"), str(tmp_path / "depth.bin"), str(tmp_path / "out.bin"),
                         "100", "8", "0.5", "32"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert "atmo_render_kernel<0, 0>" in r.stdout
+    assert "atmo_render_kernel<0, 0, 1>" in r.stdout
     got = np.fromfile(tmp_path / "out.bin", dtype=np.float32).reshape(want.shape)
     assert np.array_equal(got, want)
 
@@ -594,19 +594,19 @@ def test_precise_cloud_mode(oracle32, config_name):
     cam = S.Camera.from_pose(w, h, "P_ground")
     depth = S.depth_ground_sphere(cam)
     node = make_node(config_name, tex, params)  # precise is the default of the cloud variants
-    assert node.kernel_name in ("atmo_render_kernel<17, 0>", "atmo_render_kernel<19, 0>", "atmo_render_kernel<25, 0>")
+    assert node.kernel_name.rsplit(",", 1)[0] in ("atmo_render_kernel<17, 0", "atmo_render_kernel<19, 0", "atmo_render_kernel<25, 0")
     got = _gpu_render(node, cam, depth)
     lut = node.read_optical_depth() if _uses_lut(config_name) else None
     node.close()
     want, _ = _oracle_render(oracle32, config_name, params, tex, cam, depth, lut)
     fast = make_node(config_name, tex, params, precise_clouds=False)
-    assert fast.kernel_name in ("atmo_render_kernel<1, 0>", "atmo_render_kernel<3, 0>", "atmo_render_kernel<9, 0>")
+    assert fast.kernel_name.rsplit(",", 1)[0] in ("atmo_render_kernel<1, 0", "atmo_render_kernel<3, 0", "atmo_render_kernel<9, 0")
     got_fast = _gpu_render(fast, cam, depth)
     fast.close()
     err, err_fast = np.abs(got - want).max(), np.abs(got_fast - want).max()
     assert err <= 2.5e-5 and err <= err_fast and err_fast <= TOL
     base = make_node("no_clouds_8", tex, params, precise_clouds=True)   # no cloud kernel: the flag is ignored
-    assert base.kernel_name == "atmo_render_kernel<0, 0>"
+    assert base.kernel_name == "atmo_render_kernel<0, 0, 1>"
     base.close()
 
 
@@ -649,7 +649,7 @@ def test_parity_config2_clouds_high_1920x1080_full_frame(oracle32, pose, precise
     cam = S.Camera.from_pose(w, h, pose)
     depth = S.depth_ground_sphere(cam)
     node = make_node("clouds_high", tex, params, precise_clouds=precise)
-    assert node.kernel_name == ("atmo_render_kernel<17, 0>" if precise else "atmo_render_kernel<1, 0>")
+    assert node.kernel_name.startswith("atmo_render_kernel<17, 0," if precise else "atmo_render_kernel<1, 0,")
     got = _gpu_render(node, cam, depth)
     lut = node.read_optical_depth()
     node.close()
@@ -675,7 +675,7 @@ def test_parity_config3_clouds_high_rm_3840x2160(oracle32, pose, precise):
     cam = S.Camera.from_pose(w, h, pose)
     depth = S.depth_ground_sphere(cam)
     node = make_node("clouds_high_rm", tex, params, precise_clouds=precise)
-    assert node.kernel_name == ("atmo_render_kernel<19, 0>" if precise else "atmo_render_kernel<3, 0>")
+    assert node.kernel_name.startswith("atmo_render_kernel<19, 0," if precise else "atmo_render_kernel<3, 0,")
     got = _gpu_render(node, cam, depth)
     lut = node.read_optical_depth()
     assert np.isfinite(got).all()
@@ -842,3 +842,32 @@ def test_parity_other_planet_scales(oracle32, config_name, case):
     print(f"\n{config_name} {case['id']}: max |HIP - oracle| = {worst:.3e} (precise, default), {worst_fast:.3e} (fast)")
     assert worst <= TOL
     assert worst_fast <= 3e-4
+
+
+# ---- two lanes per ray (atmo_set_lane_split) ------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("config_name", list(CONFIGS))
+def test_lane_split_two_equals_one(oracle32, config_name):
+    """SPLIT = 2 (two adjacent lanes share a ray) against SPLIT = 1 on an odd-sized viewport with odd rects: the cloud
+    march is the same arithmetic per sample, so cloud-dominated pixels agree to the last bits of the blend; the view-ray
+    sums are regrouped (first half + exp(-V_A k) * second half), i.e. equal within rounding -- and both meet the oracle."""
+    w, h = 203, 117
+    tex, params = demo_textures(), demo_params()
+    for pose in ("P_space", "P_clouds"):
+        cam = S.Camera.from_pose(w, h, pose)
+        depth = S.depth_ground_sphere(cam)
+        one = make_node(config_name, tex, params, lane_split=1)
+        two = make_node(config_name, tex, params, lane_split=2)
+        a = _gpu_render(one, cam, depth)
+        b = _gpu_render(two, cam, depth)
+        assert one.kernel_name.endswith(", 1>") and two.kernel_name.endswith(", 2>")
+        assert np.array_equal(np.all(a == 0.0, axis=-1), np.all(b == 0.0, axis=-1))
+        assert np.abs(a - b).max() <= 2e-5
+        lut = one.read_optical_depth() if _uses_lut(config_name) else None
+        want, _ = _oracle_render(oracle32, config_name, params, tex, cam, depth, lut)
+        assert np.abs(b - want).max() <= TOL
+        # rect renders (odd offsets and sizes) are crops of the full frame, bit for bit, in the split form too
+        rect = (7, 5, 150, 98)
+        assert np.array_equal(_gpu_render(two, cam, depth, rect=rect), b[5:98, 7:150])
+        one.close()
+        two.close()
