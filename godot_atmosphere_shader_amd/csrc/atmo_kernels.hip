@@ -63,6 +63,23 @@ constexpr int TILE_H = ATMO_TILE_H;
 #define ATMO_CUBE_EXACT 0
 #endif
 
+// Direct-light kernel experiments (profiles/round2/ab_direct_kernel.txt):
+// ATMO_TRANS_CLUSTER 1 (shipped): the 7 light-sample square roots (and the 3 exps) are issued back to back from one asm
+//   block, so a transcendental "poisons" the pairing of the following fast ops once per cluster instead of once per
+//   sample (tools/valu_issue.hip: exp x4 + fma x28 clustered 3.36 cycles/instruction, spread 3.69); 2: also pairs the
+//   sample-radius and chord roots (slower: lengthens the dependency chain in front of the light block)
+// ATMO_LIGHT_PK 1: light samples evaluated as packed pairs (v_pk_fma_f32 / v_pk_mul_f32): no gain, a packed op issues
+//   in 4.2 cycles against 2 x 2.2 for the pair it replaces
+// ATMO_CHORD_MAX 1 (shipped): chord length clamped with v_max instead of v_cmp + v_cndmask
+#ifndef ATMO_TRANS_CLUSTER
+#define ATMO_TRANS_CLUSTER 1
+#endif
+#ifndef ATMO_LIGHT_PK
+#define ATMO_LIGHT_PK 0
+#endif
+#ifndef ATMO_CHORD_MAX
+#define ATMO_CHORD_MAX 1
+#endif
 // 1: texture gathers as buffer loads (SRSRC + 32-bit offset) instead of flat 64-bit addresses
 #ifndef ATMO_BUFFER_LOADS
 #define ATMO_BUFFER_LOADS 1
@@ -380,7 +397,18 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
         const float bdot = ox * sx + oy * sy + oz * sz;
         // LUT mode needs 1/r for the cosine; the direct light march only needs r
         const float inv_r = DIRECT ? 0.0f : hw_rsq(r2);
+#if ATMO_TRANS_CLUSTER >= 2
+        // the sample radius and the sun-chord root issued as one pair (DIRECT only)
+        float r, sq_pre = 0.0f;
+        if (DIRECT) {
+            const float hh_pre = fmaxf(ratm2 - (r2 - bdot * bdot), 0.0f);
+            asm volatile("v_sqrt_f32 %0, %2\n\tv_sqrt_f32 %1, %3\n\ts_nop 0" : "=&v"(r), "=&v"(sq_pre) : "v"(r2), "v"(hh_pre));
+        } else {
+            r = r2 * inv_r;
+        }
+#else
         const float r = DIRECT ? hw_sqrt(r2) : r2 * inv_r;
+#endif
         const float y = sat(fmaf(r, ninv_h, c1));  // 1 - height_ratio
         const float y3 = y * y * y;
 
@@ -389,11 +417,63 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
             // chord from the sample to the outer sphere along the sun direction, then a left Riemann sum.
             // x1 - max(x0, 0) with x0 = -b - sq, x1 = sq - b  ==  min(x1 - x0, x1) = min(2 sq, sq - b)
             const float hh = ratm2 - (r2 - bdot * bdot);
+#if ATMO_TRANS_CLUSTER >= 2
+            const float sq = sq_pre;
+#else
             const float sq = hw_sqrt(fmaxf(hh, 0.0f));
+#endif
+#if ATMO_CHORD_MAX
+            // inside the outer sphere the forward exit distance is >= 0; hh < 0 (rounding at the shell) gives sq = 0 and
+            // min(0, -b), which the max folds to the reference's 0
+            const float ray_len = fmaxf(fminf(sq + sq, sq - bdot), 0.0f);
+#else
             const float ray_len = (hh < 0.0f) ? 0.0f : fminf(sq + sq, sq - bdot);
+#endif
             const float lstep = ray_len * inv_light_steps;
             float acc = y3;  // sample 0 sits on the view sample itself
-            if (LSTEPS > 0) {
+            if (LSTEPS == 8 && (ATMO_TRANS_CLUSTER || ATMO_LIGHT_PK)) {
+                const float lb = lstep * (bdot + bdot), l2 = lstep * lstep;
+                float q[8], rr[8];
+#if ATMO_LIGHT_PK
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const f2 l2v = {l2, l2}, lbv = {lb, lb}, r2v = {r2, r2};
+                const f2 j01 = {0.0f, 1.0f}, j23 = {2.0f, 3.0f}, j45 = {4.0f, 5.0f}, j67 = {6.0f, 7.0f};
+                const f2 s01 = {0.0f, 1.0f}, s23 = {4.0f, 9.0f}, s45 = {16.0f, 25.0f}, s67 = {36.0f, 49.0f};
+                auto quad = [&](f2 jj, f2 ss) { return __builtin_elementwise_fma(ss, l2v, __builtin_elementwise_fma(jj, lbv, r2v)); };
+                const f2 q01 = quad(j01, s01), q23 = quad(j23, s23), q45 = quad(j45, s45), q67 = quad(j67, s67);
+                q[0] = q01.x; q[1] = q01.y; q[2] = q23.x; q[3] = q23.y; q[4] = q45.x; q[5] = q45.y; q[6] = q67.x; q[7] = q67.y;
+#else
+#pragma unroll
+                for (int j = 1; j < 8; ++j) q[j] = fmaf((float)(j * j), l2, fmaf((float)j, lb, r2));
+#endif
+#if ATMO_TRANS_CLUSTER
+                asm volatile("v_sqrt_f32 %0, %7\n\tv_sqrt_f32 %1, %8\n\tv_sqrt_f32 %2, %9\n\tv_sqrt_f32 %3, %10\n\t"
+                             "v_sqrt_f32 %4, %11\n\tv_sqrt_f32 %5, %12\n\tv_sqrt_f32 %6, %13\n\ts_nop 0"
+                             : "=&v"(rr[1]), "=&v"(rr[2]), "=&v"(rr[3]), "=&v"(rr[4]), "=&v"(rr[5]), "=&v"(rr[6]), "=&v"(rr[7])
+                             : "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]));
+#else
+#pragma unroll
+                for (int j = 1; j < 8; ++j) rr[j] = hw_sqrt(q[j]);
+#endif
+#if ATMO_LIGHT_PK
+                const f2 nh = {ninv_h, ninv_h}, c1v = {c1, c1}, zero = {0.0f, 0.0f}, one = {1.0f, 1.0f};
+                auto dens = [&](f2 r) {
+                    f2 y = __builtin_elementwise_fma(r, nh, c1v);
+                    y = __builtin_elementwise_min(__builtin_elementwise_max(y, zero), one);
+                    return y * y * y;
+                };
+                const f2 d23 = dens(f2{rr[2], rr[3]}), d45 = dens(f2{rr[4], rr[5]}), d67 = dens(f2{rr[6], rr[7]});
+                const float y1 = sat(fmaf(rr[1], ninv_h, c1));
+                const f2 sum = d23 + d45 + d67;
+                acc = fmaf(y1 * y1, y1, acc) + (sum.x + sum.y);
+#else
+#pragma unroll
+                for (int j = 1; j < 8; ++j) {
+                    const float yy = sat(fmaf(rr[j], ninv_h, c1));
+                    acc = fmaf(yy * yy, yy, acc);
+                }
+#endif
+            } else if (LSTEPS > 0) {
                 // |o + j*l*sun|^2 = r2 + j*(l*2b) + j^2*(l*l), |sun| = 1: two FMAs per sample
                 const float lb = lstep * (bdot + bdot), l2 = lstep * lstep;
 #pragma unroll
@@ -423,9 +503,20 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
         const float d = y3 * dstep;
         view_od += d;
         const float od = sun_od + view_od;
+#if ATMO_TRANS_CLUSTER
+        {
+            const float ar = od * kr, ag = od * kg, ab = od * kb;
+            float er, eg, eb;
+            asm volatile("v_exp_f32 %0, %3\n\tv_exp_f32 %1, %4\n\tv_exp_f32 %2, %5\n\ts_nop 0" : "=&v"(er), "=&v"(eg), "=&v"(eb) : "v"(ar), "v"(ag), "v"(ab));
+            lr = fmaf(d, er, lr);
+            lg = fmaf(d, eg, lg);
+            lb = fmaf(d, eb, lb);
+        }
+#else
         lr = fmaf(d, hw_exp2(od * kr), lr);
         lg = fmaf(d, hw_exp2(od * kg), lg);
         lb = fmaf(d, hw_exp2(od * kb), lb);
+#endif
 
         ox += sdx; oy += sdy; oz += sdz;
     }
