@@ -10,9 +10,11 @@ A "step" is one pass of the hot path over one synthetic frame: BASELINE.json con
 scene, pose P_space, analytic ground-sphere depth buffer, all inputs resident in HBM before the timed
 region.  With N > 1 every rank shades its own viewport (weak scaling, BASELINE configs[4] shape: one
 viewport per GPU on an orbit of camera poses).  The path has no exchange step, so frames stay resident in
-each GPU's HBM (like the inputs) and the timed region ends with ONE RCCL gather of every rank's last frame
-to rank 0 (--gather final, default); --gather every gathers each frame (two in flight, overlapped with the
-next render; root ingress over xGMI then sets the step time), --gather none skips the collective.
+each GPU's HBM (like the inputs); `value` includes an RCCL gather of EVERY frame to rank 0 (--gather every,
+default: two frames in flight, overlapped with the next render; root ingress over xGMI then sets the step
+time) and config.mrays_per_s_no_gather is the same loop without the collective (SURVEY.md 8e asks for both);
+--gather final gathers only the last frame, --gather none skips the collective.  At N > 1 the headline run is
+followed by BASELINE configs[4] (one 3840x2160 clouds_high_rm viewport per GPU) under extra.
 Rank 0 prints ONE JSON line.
 
 Other workloads (--workload): lut32 (reference-exact LUT light, 32 view steps), shipped8 (the shipped
@@ -33,36 +35,96 @@ if ROOT not in sys.path:
 BYTES_PER_RAY = 20          # 16 B RGBA32F store + 4 B depth load
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 TIMING_EVERY = 4            # HIP events bracket every 4th kernel launch of the timed region (recording costs ~5 us)
-# Measured VALU issue ceilings of MI355X under load (tools/valu_peak.hip, profiles/round1/valu_peak_mi355x.jsonl),
-# wave-instructions per second chip-wide: plain f32 FMA/MUL/ADD and transcendental (exp/sqrt/rsq/rcp).
-VALU_FMA_WINST_PER_S = 8.68e11
-VALU_TRANS_WINST_PER_S = 3.02e11
-# rocprofv3 PMC results for the same command line (tools/profile.sh), keyed by (workload, width, height)
-PMC_FILES = {
-    ("direct32x8", 1920, 1080): "profiles/round1/pmc_final_direct32x8_1920x1080.json",
-    ("lut32", 1920, 1080): "profiles/round1/pmc_final_lut32_1920x1080.json",
-    ("clouds_high", 1920, 1080): "profiles/round1/pmc_final_clouds_high_1920x1080.json",
-    ("clouds_high_rm", 1920, 1080): "profiles/round1/pmc_final_clouds_high_rm_1920x1080.json",
-    ("clouds_high_rm", 3840, 2160): "profiles/round1/pmc_final_clouds_high_rm_3840x2160.json",
-}
+N_SIMD = 1024               # 256 CUs x 4 SIMDs
+SPEC_CLOCK_GHZ = 2.4
+# VALU issue costs, shader cycles per wave64 instruction on one SIMD.
+#   "spec": cdna_hip_programming.md / MI355X_MICROARCH.md -- v_fma_f32 2 cycles (SIMD-32), transcendentals quarter rate.
+#   "measured": tools/valu_issue.hip (s_memtime cycles, 8 waves per SIMD), profiles/round2/valu_issue*_mi355x.jsonl:
+#      fast class 2.2 (v_fma/mul/add_f32 on VGPR/constant operands, mov, and/or/xor, lshr, add_u32), slow class 4.1 (any
+#      SGPR operand, max/min/med3, cvt, floor/fract, cmp, cndmask, lshl, 3-operand integer ops, cube, DPP, v_pk_*_f32),
+#      transcendental 8.1, and the ~3 fast ops issued after a transcendental do not pair (+2 cycles each).  Slow ops run on
+#      one 16-lane pipe while another wave's fast ops use the second: a mix costs max(4.1 S, 2.2 (S + F)).
+ISSUE_SPEC = {"valu": 2.0, "trans": 8.0}
+ISSUE_MEASURED = {"fast": 2.2, "slow": 4.1, "trans": 8.1, "poison_ops_per_trans": 3, "poison_extra": 2.0}
+PROFILE_DIR = "profiles/round2"
 
 
 def pmc_summary(workload, w, h):
-    """HBM traffic and VALU instruction counts per launch from the committed rocprofv3 PMC passes (collected in
-    their own runs, tools/profile.sh); None when this workload/size has not been profiled."""
-    path = PMC_FILES.get((workload, w, h))
-    if not path or not os.path.exists(os.path.join(ROOT, path)):
+    """rocprofv3 PMC results for the same bench command line (tools/profile.sh -> tools/summarize_pmc.py; collected in their
+    own runs, never beside tracing), committed under profiles/round2/pmc_<workload>_<W>x<H>.json.  None when this
+    workload/size has not been profiled."""
+    path = f"{PROFILE_DIR}/pmc_{workload}_{w}x{h}.json"
+    if not os.path.exists(os.path.join(ROOT, path)):
         return None
     with open(os.path.join(ROOT, path)) as f:
         d = json.load(f)
     c = {k: v["mean_per_launch"] for k, v in d.get("pmc_per_launch", {}).items()}
-    out = {"source": path}
+    out = {"source": path, "counters": c, "profiled_kernel_ns": d.get("kernel_stats", {}).get("avg_ns")}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         out["hbm_bytes"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-    if "SQ_INSTS_VALU" in c:
-        out["valu_winst"] = c["SQ_INSTS_VALU"]
-        out["trans_winst"] = c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
     return out
+
+
+def valu_roofline(pmc, kernel_avg_ms):
+    """The resource that actually binds: VALU instruction issue.  Dynamic instruction counts per launch from the PMC
+    passes (SQ_INSTS_VALU and its class counters, calibrated on single-opcode kernels: tools/calibrate_counters.sh),
+    priced twice: at the guide's rates ("spec") and with the measured issue model.  Returns None without counters."""
+    if pmc is None or "SQ_INSTS_VALU" not in pmc["counters"] or not kernel_avg_ms:
+        return None
+    c = pmc["counters"]
+    n, t = c["SQ_INSTS_VALU"], c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+    # fast class upper bound: every f32 FMA/ADD/MUL (the counters cannot see SGPR operands) + the half of INT32 that is
+    # add/sub; everything else that is not transcendental is slow class (cvt, cmp, cndmask, max/min, floor, cube, shifts ...)
+    have_classes = "SQ_INSTS_VALU_FMA_F32" in c
+    fast = (c["SQ_INSTS_VALU_FMA_F32"] + c["SQ_INSTS_VALU_ADD_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + 0.5 * c.get("SQ_INSTS_VALU_INT32", 0.0)) if have_classes else (n - t)
+    fast = min(fast, n - t)
+    slow = n - t - fast
+    m = ISSUE_MEASURED
+    cyc_spec = ISSUE_SPEC["valu"] * (n - t) + ISSUE_SPEC["trans"] * t
+    poison = m["poison_extra"] * min(m["poison_ops_per_trans"] * t, fast)
+    cyc_meas = m["trans"] * t + poison + max(m["slow"] * slow, m["fast"] * (slow + fast))
+    clock = SPEC_CLOCK_GHZ
+    if c.get("GRBM_GUI_ACTIVE") and pmc.get("profiled_kernel_ns"):
+        clock = c["GRBM_GUI_ACTIVE"] / 8.0 / pmc["profiled_kernel_ns"]  # sustained shader clock of the profiled run (8 XCDs)
+    floor_spec_ms = cyc_spec / (N_SIMD * SPEC_CLOCK_GHZ * 1e9) * 1e3
+    floor_meas_ms = cyc_meas / (N_SIMD * clock * 1e9) * 1e3
+    return {
+        "bound": "valu-issue",
+        "valu_wave_insts_per_launch": n,
+        "class_wave_insts_per_launch": {"fast_upper_bound": fast, "slow": slow, "transcendental": t} if have_classes else None,
+        "achieved_winst_per_s": n / (kernel_avg_ms * 1e-3),
+        "cycles_per_winst_per_simd_achieved": kernel_avg_ms * 1e-3 * N_SIMD * clock * 1e9 / n,
+        "issue_floor_spec_ms": floor_spec_ms,
+        "issue_floor_measured_ms": floor_meas_ms,
+        "frac_vs_spec": floor_spec_ms / kernel_avg_ms,
+        "frac_vs_measured": floor_meas_ms / kernel_avg_ms,
+        "sustained_clock_ghz": clock,
+        "issue_costs": {"spec": ISSUE_SPEC, "measured": ISSUE_MEASURED,
+                        "source": "tools/valu_issue.hip -> profiles/round2/valu_issue_mi355x.jsonl, valu_issue_set2_mi355x.jsonl; "
+                                  "class counters calibrated in profiles/round2/counter_calibration.txt"},
+        "note": "frac_vs_spec prices every non-transcendental op at 2 cycles (unreachable: half of the ISA issues in 4); "
+                "frac_vs_measured uses the per-class costs this chip sustains; the rest is occupancy (too few waves per SIMD "
+                "to pair instructions at 1920x1080, see tools/concurrency_probe.py) and lane divergence",
+    }
+
+
+def hbm_roofline(kernel_avg_ms, launches, launch_rays, pmc):
+    achieved = (BYTES_PER_RAY * launch_rays / (kernel_avg_ms * 1e-3) / 1e9) if kernel_avg_ms else None
+    return {
+        "bound": "hbm",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": None if achieved is None else achieved / HBM_PEAK_GBS,
+        "traffic": None if pmc is None else pmc.get("hbm_bytes"),
+        "traffic_source": None if pmc is None else pmc["source"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bytes per launch)",
+        "kernel_avg_ms": kernel_avg_ms or None,
+        "kernel_launches_timed": launches,
+        "kernel_timing": f"HIP events around every {TIMING_EVERY}th launch of the timed region, on the launch stream",
+        "algorithmic_bytes_per_launch": BYTES_PER_RAY * launch_rays,
+        "note": "path is VALU-issue-bound, not HBM-bound (20 B/ray); see valu_roofline and DESIGN.md",
+    }
+
 
 WORKLOADS = {
     # name: (godot_atmosphere_shader_amd.demo.CONFIGS key, description)
@@ -94,17 +156,18 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--pose", default="P_space")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", default="final", choices=["final", "every", "none"],
-                    help="N>1: 'final' = one RCCL gather of every rank's last frame to rank 0 inside the timed region "
-                         "(default: the path has no exchange step, frames stay resident like the inputs); "
-                         "'every' = gather every frame, two in flight, overlapped with the next render; 'none' = no collective")
+    ap.add_argument("--gather", default="every", choices=["final", "every", "none"],
+                    help="N>1: 'every' (default) = RCCL gather of EVERY frame to rank 0, two in flight, overlapped with the "
+                         "next render (root ingress over xGMI then sets the step time); 'final' = one gather of every rank's "
+                         "last frame inside the timed region; 'none' = no collective.  The no-gather rate is measured in a "
+                         "second loop and reported as config.mrays_per_s_no_gather either way (SURVEY.md 8e asks for both).")
     ap.add_argument("--shard", default="viewports", choices=["viewports", "bands"],
                     help="N>1: 'viewports' = one full viewport per GPU (weak scaling, default); 'bands' = ONE viewport cut "
                          "into hit-balanced row bands, one per GPU, gathered in place into the frame on rank 0 (strong scaling)")
-    ap.add_argument("--also", default="lut32,shipped8,clouds_high,clouds_high_rm,noise_cubemap",
-                    help="comma-separated extra workloads timed at N=1 after the headline and reported under 'extra' "
-                         "(SURVEY.md 8d asks for the reference-exact LUT mode and the shipped 8-step shader next to the "
-                         "32x8 headline); '' to skip")
+    ap.add_argument("--also", default="lut32,shipped8,clouds_high,clouds_high_rm,direct32x8@3840x2160,clouds_high_rm@3840x2160,noise_cubemap",
+                    help="comma-separated extra workloads (name or name@WxH) timed at N=1 after the headline and reported under "
+                         "'extra', each with its own roofline blocks: the reference-exact LUT mode and the shipped 8-step shader "
+                         "(SURVEY.md 8d), BASELINE configs[2] (clouds_high 1080p) and configs[3] (clouds_high_rm 3840x2160); '' to skip")
     return ap.parse_args()
 
 
@@ -274,6 +337,49 @@ def timed_loop_distributed(torch, dist, render_into, h, w, device, steps, warmup
     return float(tmax.item()), launches, kernel_ms
 
 
+def cloud_row_cost(np, S, cam, cloudy):
+    """Per-row cost estimate for band balancing: pixels whose ray hits the atmosphere shell count 1; for the cloud
+    variants a pixel whose ray also crosses the cloud shell (between the ground sphere and the cloud-top sphere: the
+    gate of render_clouds, clouds:263-278) counts CLOUD_WEIGHT more (64 cloud steps against 8 view steps)."""
+    d = cam.pixel_view_dirs()
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    c = (cam.view @ np.array([0.0, 0.0, 0.0, 1.0]))[:3]
+    bq = d @ c
+    q2 = c @ c - bq * bq
+    R, H = S.DEMO_PLANET_RADIUS, S.DEMO_ATMOSPHERE_HEIGHT
+    hit = ((R + H) ** 2 - q2 >= 0)
+    cost = hit.astype(np.float64)
+    if cloudy:
+        top = R + S.DEMO_SHADER_PARAMS["u_cloud_top"] * H
+        cost += CLOUD_WEIGHT * (top ** 2 - q2 >= 0)
+    return cost.sum(axis=1) + 0.02 * cam.width  # + a small per-row cost for the miss pixels
+
+
+CLOUD_WEIGHT = 8.0
+
+
+def run_workload(torch, S, name, w, h, pose, steps, warmup, textures, params, local_rank, with_frame_stats=True):
+    """One single-GPU workload: returns the result dictionary of an `extra` entry (rate, kernel time, both rooflines)."""
+    import numpy as np  # noqa: F401
+    from godot_atmosphere_shader_amd.demo import make_node
+
+    config_name, desc = WORKLOADS[name]
+    cam = S.Camera.from_pose(w, h, pose)
+    depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
+    node = make_node(config_name, textures, params, device=local_rank, **node_kwargs(name))
+    dt, launches, kernel_ms, out = time_workload(torch, node, cam, depth, steps, warmup)
+    kernel_avg_ms = kernel_ms / launches if launches else 0.0
+    pmc = pmc_summary(name, w, h) if pose == "P_space" else None
+    res = {"workload": f"{desc}; {w}x{h}; demo scene, pose {pose}", "Mrays/s": w * h * steps / dt / 1e6,
+           "ms_per_step": dt / steps * 1e3, "steps": steps, "kernel_avg_ms": kernel_avg_ms or None, "kernel": node.kernel_name,
+           "roofline": hbm_roofline(kernel_avg_ms, launches, w * h, pmc), "valu_roofline": valu_roofline(pmc, kernel_avg_ms)}
+    if with_frame_stats:
+        res["hit_fraction"] = float((out.abs().sum(dim=-1) > 0).float().mean().item())
+    node.close()
+    del out, depth
+    return res
+
+
 def main():
     args = parse_args()
     import numpy as np
@@ -297,35 +403,32 @@ def main():
     if world > 1 or force_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    multi = world > 1 or force_dist
 
     w, h = args.width, args.height
     config_name, desc = WORKLOADS[args.workload]
     textures = demo_textures()
     params = demo_params()
-    strong = args.shard == "bands" and (world > 1 or os.environ.get("ATMO_BENCH_FORCE_DIST") == "1")
+    strong = args.shard == "bands" and multi
     pose = args.pose if (world == 1 or rank == 0 or strong) else S.orbit_pose(rank, world)
     cam = S.Camera.from_pose(w, h, pose)
     depth_np = S.depth_ground_sphere(cam)
     depth = torch.from_numpy(depth_np).cuda()
     node = make_node(config_name, textures, params, device=local_rank, **node_kwargs(args.workload))
     rays = w * h
+    device = torch.device("cuda", local_rank)
 
     # ---- timed region ---------------------------------------------------------------------------------
-    if world == 1 and not force_dist:
-        dt, launches, kernel_ms, out = time_workload(torch, node, cam, depth, args.steps, args.warmup)
-        dt_max = dt
+    bands = None
+    no_gather_rate = None
+    if not multi:
+        dt_max, launches, kernel_ms, out = time_workload(torch, node, cam, depth, args.steps, args.warmup)
         gather_mode = "none (single GPU)"
     else:
-        bands = None
         if strong:
-            # one frame, row bands balanced by the number of shell-hitting pixels per row (analytic ray/sphere test)
+            # ONE frame in row bands balanced by the estimated work per row (shell hits, cloud-shell hits weighted)
             from godot_atmosphere_shader_amd.sharding import balanced_row_bands, band_rect
-            d = cam.pixel_view_dirs()
-            d /= np.linalg.norm(d, axis=-1, keepdims=True)
-            c = (cam.view @ np.array([0.0, 0.0, 0.0, 1.0]))[:3]
-            bq = d @ c
-            hit_rows = ((S.DEMO_PLANET_RADIUS + S.DEMO_ATMOSPHERE_HEIGHT) ** 2 - (c @ c - bq * bq) >= 0).sum(axis=1)
-            bands = balanced_row_bands(hit_rows + 0.02 * w, world)  # + a small per-row cost for the miss pixels
+            bands = balanced_row_bands(cloud_row_cost(np, S, cam, "cloud" in config_name), world)
             frame = node.prepare_frame(cam, rect=band_rect(w, bands[rank]))
         else:
             frame = node.prepare_frame(cam)
@@ -337,24 +440,32 @@ def main():
 
         node_timing = (lambda: node.set_timing(True, every=TIMING_EVERY), node.get_timing)
         dt_max, launches, kernel_ms = timed_loop_distributed(
-            torch, dist, render_into, h, w, torch.device("cuda", local_rank), args.steps, args.warmup, args.gather, node_timing,
-            bands=bands)
+            torch, dist, render_into, h, w, device, args.steps, args.warmup, args.gather, node_timing, bands=bands)
         node.set_timing(False)
         gather_mode = {"none": "no collective",
                        "final": "one RCCL gather of each rank's last frame to rank 0, inside the timed region",
                        "every": "RCCL gather of every frame to rank 0, 2 frames in flight, inside the timed region"}[args.gather]
+        if args.gather != "none":
+            # the rate WITHOUT the gather next to the rate with it (same loop, no collective)
+            dt_ng, _, _ = timed_loop_distributed(torch, dist, render_into, h, w, device, args.steps, max(2, args.warmup // 4),
+                                                 "none", None, bands=bands)
+            no_gather_rate = (1 if strong else world) * rays * args.steps / dt_ng / 1e6
 
+    result = None
     if rank == 0:
         value = (1 if strong else world) * rays * args.steps / dt_max / 1e6
-        pmc = None if strong else pmc_summary(args.workload, w, h)
-        kernel_avg_ms = kernel_ms / max(launches, 1)
+        if no_gather_rate is None:
+            no_gather_rate = value
+        pmc = None if (strong or args.pose != "P_space") else pmc_summary(args.workload, w, h)
+        kernel_avg_ms = kernel_ms / launches if launches else 0.0
         launch_rays = rays if not strong else w * (bands[0][1] - bands[0][0])  # rank 0's kernel shades its band only
-        achieved_gbs = BYTES_PER_RAY * launch_rays / (kernel_avg_ms * 1e-3) / 1e9
-        frame = node.render(cam, depth)
+        frame_img = node.render(cam, depth)
         torch.cuda.synchronize()
-        hit_fraction = float((frame.abs().sum(dim=-1) > 0).float().mean().item())
+        hit_fraction = float((frame_img.abs().sum(dim=-1) > 0).float().mean().item())
+        del frame_img
         result = {
-            "metric": "Mrays/s at 1920x1080, 32 view x 8 light steps; % HBM roofline",
+            "metric": f"Mrays/s, {args.workload} at {w}x{h}" + ("; 32 view x 8 light steps" if args.workload == "direct32x8" else "")
+                      + "; % HBM roofline",
             "value": value,
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -368,66 +479,85 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{desc}; {w}x{h}; demo scene, pose {args.pose}"
-                            + ("" if world == 1 else f" on rank 0, orbit poses on ranks 1..{world - 1}; one viewport per GPU"),
-                "width": w, "height": h, "rays_per_step_per_gpu": rays,
+                            + ("" if world == 1 or strong else f" on rank 0, orbit poses on ranks 1..{world - 1}; one viewport per GPU"),
+                "width": w, "height": h, "rays_per_step_per_gpu": rays if not strong else None,
                 "hit_fraction": hit_fraction,
                 "mrays_per_s_hit_only": value * hit_fraction,
                 "gather": gather_mode,
-                "shard": ("one viewport in hit-balanced row bands: " + str(bands)) if strong else "one viewport per GPU",
+                "mrays_per_s_no_gather": no_gather_rate,
+                "shard": ("one viewport in work-balanced row bands: " + str(bands)) if strong else "one viewport per GPU",
                 "kernel": node.kernel_name,
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved_gbs,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": None if pmc is None else pmc.get("hbm_bytes"),
-                "traffic_source": None if pmc is None else pmc["source"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bytes per launch)",
-                "kernel_avg_ms": kernel_avg_ms,
-                "kernel_launches_timed": launches,
-                "kernel_timing": f"HIP events around every {TIMING_EVERY}th launch of the timed region, on the launch stream",
-                "algorithmic_bytes_per_launch": BYTES_PER_RAY * launch_rays,
-                "note": "path is VALU/transcendental-bound, not HBM-bound (20 B/ray); see DESIGN.md",
-            },
+            "roofline": hbm_roofline(kernel_avg_ms, launches, launch_rays, pmc),
         }
-        if pmc is not None and "valu_winst" in pmc:
-            # the resource that actually binds: VALU instruction issue, priced against the measured ceilings
-            n_all, n_tr = pmc["valu_winst"], pmc["trans_winst"]
-            t_floor = (n_all - n_tr) / VALU_FMA_WINST_PER_S + n_tr / VALU_TRANS_WINST_PER_S
-            result["valu_roofline"] = {
-                "bound": "valu-issue",
-                "valu_wave_insts_per_launch": n_all,
-                "transcendental_wave_insts_per_launch": n_tr,
-                "achieved_winst_per_s": n_all / (kernel_avg_ms * 1e-3),
-                "issue_floor_ms": t_floor * 1e3,
-                "frac": t_floor * 1e3 / kernel_avg_ms,
-                "peaks": {"fma_winst_per_s": VALU_FMA_WINST_PER_S, "trans_winst_per_s": VALU_TRANS_WINST_PER_S,
-                          "source": "tools/valu_peak.hip, profiles/round1/valu_peak_mi355x.jsonl"},
-            }
-        if world == 1 and args.also:
-            extra = {}
-            for name in [x for x in args.also.split(",") if x]:
-                if name == "noise_cubemap":
-                    extra[name] = bench_noise_cubemap()
-                    continue
-                cfg2, desc2 = WORKLOADS[name]
-                node2 = make_node(cfg2, textures, params, device=local_rank, **node_kwargs(name))
-                dt2, n2, ms2, _ = time_workload(torch, node2, cam, depth, max(10, args.steps // 4), max(3, args.warmup // 4))
-                extra[name] = {"workload": desc2, "Mrays/s": rays * max(10, args.steps // 4) / dt2 / 1e6,
-                               "kernel_avg_ms": ms2 / max(n2, 1), "kernel": node2.kernel_name}
-                node2.close()
-            result["extra"] = extra
-        if world == 1 and not args.no_cpu_baseline:
+        vr = valu_roofline(pmc, kernel_avg_ms)
+        if vr is not None:
+            result["valu_roofline"] = vr
+    node.close()
+
+    # ---- extras ----------------------------------------------------------------------------------------
+    if not multi and args.also and rank == 0:
+        extra = {}
+        ex_steps, ex_warm = max(10, args.steps // 4), max(3, args.warmup // 4)
+        for item in [x for x in args.also.split(",") if x]:
+            if item == "noise_cubemap":
+                extra[item] = bench_noise_cubemap()
+                continue
+            name, _, size = item.partition("@")
+            ew, eh = (int(v) for v in size.split("x")) if size else (w, h)
+            extra[item] = run_workload(torch, S, name, ew, eh, args.pose, ex_steps, ex_warm, textures, params, local_rank)
+        result["extra"] = extra
+    if multi and not strong and args.workload == "direct32x8" and os.environ.get("ATMO_BENCH_NO_CONFIG4") != "1":
+        # BASELINE.json configs[4]: independent 3840x2160 clouds_high_rm viewports, one per GPU, gathered to rank 0 over xGMI
+        c4 = bench_config4(torch, dist, S, textures, params, local_rank, rank, world, max(5, args.steps // 8), 2)
+        if rank == 0:
+            result.setdefault("extra", {})["config4_clouds_high_rm_3840x2160"] = c4
+
+    if rank == 0:
+        if not multi and not args.no_cpu_baseline:
             from godot_atmosphere_shader_amd.demo import CONFIGS
             ocfg = CONFIGS[config_name][1]
-            lut = node.read_optical_depth() if not (ocfg.get("lite") or ocfg.get("light_steps")) else None
+            lut = None
+            if not (ocfg.get("lite") or ocfg.get("light_steps")):
+                n2 = make_node(config_name, textures, params, device=local_rank)
+                lut = n2.read_optical_depth()
+                n2.close()
             result["cpu_baseline"] = cpu_baseline(config_name, params, textures, cam, depth_np, lut)
         print(json.dumps(result), flush=True)
-    node.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_config4(torch, dist, S, textures, params, local_rank, rank, world, steps, warmup):
+    """BASELINE.json configs[4]: `world` independent 3840x2160 planet_atmosphere_clouds_high_rm viewports (orbit poses), one
+    per GPU, every frame gathered to rank 0 (132.7 MB per rank per frame over xGMI); weak scaling, with and without the gather."""
+    from godot_atmosphere_shader_amd.demo import make_node
+
+    w, h = 3840, 2160
+    pose = "P_space" if rank == 0 else S.orbit_pose(rank, world)
+    cam = S.Camera.from_pose(w, h, pose)
+    depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
+    node = make_node("clouds_high_rm", textures, params, device=local_rank)
+    frame = node.prepare_frame(cam)
+    stream = torch.cuda.current_stream().cuda_stream
+    device = torch.device("cuda", local_rank)
+
+    def render_into(buf):
+        node.render_prepared(frame, depth.data_ptr(), buf.data_ptr(), stream)
+
+    out = {}
+    for mode in ("every", "none"):
+        timing = (lambda: node.set_timing(True, every=TIMING_EVERY), node.get_timing)
+        dt, launches, kernel_ms = timed_loop_distributed(torch, dist, render_into, h, w, device, steps, warmup, mode, timing)
+        node.set_timing(False)
+        out["Mrays/s_gather_every_frame" if mode == "every" else "Mrays/s_no_gather"] = world * w * h * steps / dt / 1e6
+        out["ms_per_step_" + mode] = dt / steps * 1e3
+        out["kernel_avg_ms_rank0"] = kernel_ms / launches if launches else None
+    out.update(workload=f"planet_atmosphere_clouds_high_rm, 3840x2160, one viewport per GPU x {world}", steps=steps, n_gpus=world,
+               kernel=node.kernel_name, scaling="weak")
+    node.close()
+    return out
 
 
 if __name__ == "__main__":

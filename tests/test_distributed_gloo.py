@@ -151,3 +151,83 @@ def test_bench_distributed_timed_loop_world_size_2(tmp_path, mode):
     mp.spawn(_bench_worker, args=(world, port, mode, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert (tmp_path / f"ok_bench_{mode}_{r}").exists()
+
+
+def _bench_worker4(rank, world, port, mode, tmpdir):
+    """World size 4: an EMPTY band (more ranks than rows would give one too) and the band mode with gather="final"."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from godot_atmosphere_shader_amd.sharding import row_bands
+
+        w = 5
+        if mode == "empty_band":
+            h, bands, gather = 3, row_bands(3, world), "every"      # [(0,0),(0,1),(1,2),(2,3)]: rank 0's band is empty
+            assert bands[0] == (0, 0)
+        elif mode == "bands_final":
+            h, bands, gather = 9, [(0, 1), (1, 5), (5, 5), (5, 9)], "final"   # unequal, one empty in the middle
+        else:
+            h, bands, gather = 4, None, "every"                       # four viewports
+        calls = {"n": 0}
+
+        def render_into(buf):
+            calls["n"] += 1
+            if buf.numel():
+                buf.fill_(float(100 * rank + calls["n"]))
+
+        steps, warmup = 3, 1
+        dt, launches, kernel_ms = bench.timed_loop_distributed(
+            torch, dist, render_into, h, w, torch.device("cpu"), steps, warmup, gather, None, bands=bands)
+        assert dt > 0 and calls["n"] == steps + warmup
+        res = bench.timed_loop_distributed.last_gathered
+        if rank == 0:
+            last = steps + warmup
+            if bands is None:
+                assert res.shape == (world, h, w, 4)
+                for r in range(world):
+                    assert torch.all(res[r] == float(100 * r + last))
+            else:
+                assert res.shape == (h, w, 4)
+                for r, (y0, y1) in enumerate(bands):
+                    assert torch.all(res[y0:y1] == float(100 * r + last)), (r, y0, y1)
+        else:
+            assert res is None
+        with open(os.path.join(tmpdir, f"ok4_{mode}_{rank}"), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["viewports", "empty_band", "bands_final"])
+def test_bench_distributed_timed_loop_world_size_4(tmp_path, mode):
+    world = 4
+    port = _free_port()
+    mp.spawn(_bench_worker4, args=(world, port, mode, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert (tmp_path / f"ok4_{mode}_{r}").exists()
+
+
+def test_cloud_weighted_row_cost_balances_cloud_variants():
+    """bench.py --shard bands: rows that cross the cloud shell weigh CLOUD_WEIGHT more for the cloud variants, so the
+    bands of a cloud frame are cut by estimated work, not by shell hits alone."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from godot_atmosphere_shader_amd import scene as S
+    from godot_atmosphere_shader_amd.sharding import balanced_row_bands
+
+    cam = S.Camera.from_pose(192, 108, "P_space")
+    plain = bench.cloud_row_cost(np, S, cam, False)
+    cloudy = bench.cloud_row_cost(np, S, cam, True)
+    assert plain.shape == (108,) and np.all(cloudy >= plain)
+    mid = 54
+    assert 5 * plain[mid] < cloudy[mid] <= (1 + bench.CLOUD_WEIGHT) * plain[mid]   # the disc rows carry the cloud weight
+    far = S.Camera(192, 108, eye=(0.0, 0.0, 900.0), target=(0.0, 0.0, 0.0), far=2000.0)  # small disc: sky rows above and below
+    c_far = bench.cloud_row_cost(np, S, far, True)
+    assert c_far[0] == pytest.approx(0.02 * 192) and c_far[54] > 50 * c_far[0]
+    for cost in (plain, cloudy, c_far):
+        bands = balanced_row_bands(cost, 4)
+        assert bands[0][0] == 0 and bands[-1][1] == 108
+        sums = [cost[a:b].sum() for a, b in bands]
+        assert max(sums) / (sum(sums) / 4) < 1.25

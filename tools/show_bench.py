@@ -1,0 +1,14 @@
+#!/usr/bin/env python3
+"""Prints the headline and the extras of a bench.py JSON line: tools/show_bench.py file.json"""
+import json, sys
+d = json.loads(open(sys.argv[1]).readline())
+vr = d.get("valu_roofline") or {}
+print(f"{d['metric']}: {d['value']:.0f} {d['unit']}  step {d['ms_per_step']:.4f} ms  kernel {d['roofline']['kernel_avg_ms']}  {d['config']['kernel']}"
+      f"  hbm frac {d['roofline']['frac']}  valu frac spec/measured {vr.get('frac_vs_spec')} / {vr.get('frac_vs_measured')}")
+for k, v in (d.get("extra") or {}).items():
+    if "Mrays/s" in v:
+        r = v.get("valu_roofline") or {}
+        print(f"  {k:28s} {v['Mrays/s']:9.0f} Mrays/s  kernel {v.get('kernel_avg_ms')}  {v.get('kernel')}  valu frac {r.get('frac_vs_spec')} / {r.get('frac_vs_measured')}")
+    else:
+        print(f"  {k:28s} {v}")
+print("  cpu_baseline", d.get("cpu_baseline"))
