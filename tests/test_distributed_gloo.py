@@ -225,7 +225,7 @@ def test_cloud_weighted_row_cost_balances_cloud_variants():
     assert 5 * plain[mid] < cloudy[mid] <= (1 + bench.CLOUD_WEIGHT) * plain[mid]   # the disc rows carry the cloud weight
     far = S.Camera(192, 108, eye=(0.0, 0.0, 900.0), target=(0.0, 0.0, 0.0), far=2000.0)  # small disc: sky rows above and below
     c_far = bench.cloud_row_cost(np, S, far, True)
-    assert c_far[0] == pytest.approx(0.02 * 192) and c_far[54] > 50 * c_far[0]
+    assert c_far[0] == pytest.approx(0.02 * 192) and c_far[54] > 20 * c_far[0]
     for cost in (plain, cloudy, c_far):
         bands = balanced_row_bands(cost, 4)
         assert bands[0][0] == 0 and bands[-1][1] == 108
