@@ -20,7 +20,7 @@ ABI_VERSION = 2
 # every symbol include/atmo.h declares
 EXPORTED_SYMBOLS = (
     "atmo_abi_version", "atmo_device_count", "atmo_create", "atmo_destroy", "atmo_set_param_f32",
-    "atmo_get_param_f32", "atmo_set_texture", "atmo_generate_noise_cubemap", "atmo_bake_optical_depth", "atmo_read_optical_depth",
+    "atmo_get_param_f32", "atmo_set_texture", "atmo_get_texture_size", "atmo_set_sampler_lod", "atmo_host_cubemap_mip", "atmo_read_texture_layout", "atmo_generate_noise_cubemap", "atmo_bake_optical_depth", "atmo_read_optical_depth",
     "atmo_render", "atmo_render_composite", "atmo_set_precision", "atmo_set_host_double_precision", "atmo_set_lane_split", "atmo_set_tile_feedback", "atmo_set_timing", "atmo_get_timing", "atmo_selftest_exact_math", "atmo_host_layout_cubemap",
     "atmo_host_layout_shape", "atmo_host_layout_lut", "atmo_kernel_name",
     "atmo_last_error_string",
@@ -77,7 +77,11 @@ def load() -> C.CDLL:
         "atmo_destroy": (ip, [vp]),
         "atmo_set_param_f32": (ip, [vp, cp, fp, ip]),
         "atmo_get_param_f32": (ip, [vp, cp, fp, ip]),
-        "atmo_set_texture": (ip, [vp, cp, ip, ip, ip, ip, vp, ip]),
+        "atmo_set_texture": (ip, [vp, cp, ip, ip, ip, ip, ip, vp, ip, vp]),
+        "atmo_get_texture_size": (ip, [vp, cp, C.POINTER(ip), C.POINTER(ip), C.POINTER(ip), C.POINTER(ip)]),
+        "atmo_set_sampler_lod": (ip, [vp, ip]),
+        "atmo_read_texture_layout": (ip, [vp, cp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]),
+        "atmo_host_cubemap_mip": (ip, [vp, ip, vp]),
         "atmo_generate_noise_cubemap": (ip, [vp, ip, C.c_uint32, C.c_float, ip, C.c_float, fp, ip, vp, C.POINTER(C.c_double)]),
         "atmo_bake_optical_depth": (ip, [vp, vp]),
         "atmo_read_optical_depth": (ip, [vp, vp, vp, ip, vp]),

@@ -7,6 +7,7 @@
 // HIP device every compute entry point fails with ATMO_E_NO_DEVICE / ATMO_E_HIP.
 #include "../../include/atmo.h"
 #include "atmo_device.h"
+#include "atmo_layout.h"
 
 #include <cmath>
 #include <cstdio>
@@ -92,6 +93,16 @@ struct AtmoContext {
     Params p;
     DeviceBuffer lut, blue, shape, cube;
     int lut_w = 0, lut_h = 0, shape_n = 0, cube_n = 0;
+    int cube_levels = 0;                 // mip levels bound (footprint arrays packed level after level in `cube`)
+    DeviceBuffer cube_level_off;         // element offset of every level's footprint array (uint32 x 16, device)
+    uint32_t cube_level_off_host[16] = {0};
+    int sampler_lod = 0;                 // atmo_set_sampler_lod: 0 = LOD 0, 1 = implicit LOD from 2x2 pixel quads
+    DeviceBuffer staging;                // raw texels on their way into a re-layout kernel (grow-only)
+    hipStream_t staging_stream = nullptr;
+    bool staging_used = false;
+    hipEvent_t tex_event = nullptr;      // recorded after the last texture update on tex_stream
+    hipStream_t tex_stream = nullptr;
+    bool tex_pending = false;
     int host_double_precision = 0;  // DOUBLE_PRECISION (main:25,118-125)
     int lane_split = 0;             // 0 = choose per launch by size, 1 = one lane per ray, 2 = two lanes per ray
     int last_split = 1;             // what the most recent launch used (atmo_kernel_name)
@@ -144,108 +155,28 @@ void dev_free(DeviceBuffer &b) {
     b.bytes = 0;
 }
 
-// ---- cubemap apron -----------------------------------------------------------------------------------
-// The kernel samples each face as an (n+2)^2 image whose border row/column holds the texels that lie
-// across the cube edge (seamless filtering) and whose corners hold the mean of the three faces' corner
-// texels.  Faces +X,-X,+Y,-Y,+Z,-Z; Vulkan face table (same as noise_cubemap.gd:110-128).
-struct FaceBasis { int major[3], s[3], t[3]; };
-const FaceBasis kFaces[6] = {
-    {{1, 0, 0}, {0, 0, -1}, {0, -1, 0}}, {{-1, 0, 0}, {0, 0, 1}, {0, -1, 0}},
-    {{0, 1, 0}, {1, 0, 0}, {0, 0, 1}},   {{0, -1, 0}, {1, 0, 0}, {0, 0, -1}},
-    {{0, 0, 1}, {1, 0, 0}, {0, -1, 0}},  {{0, 0, -1}, {-1, 0, 0}, {0, -1, 0}},
-};
-
-// Integer cube-surface coordinates: texel centre (i,j) of face f sits at 2*i+1-n, 2*j+1-n in the face
-// plane and at n on the major axis (units of half texels).  Stepping one texel off the face keeps the
-// in-plane coordinate at the edge (+-n) and moves the major-axis coordinate in by one texel (n-1 ... in
-// half-texel units: n - 1), which is a texel centre of the neighbouring face.
-uint8_t cube_fold(const uint8_t *faces, int n, int f, int i, int j) {
-    const FaceBasis &fb = kFaces[f];
-    int sc = 2 * i + 1 - n, tc = 2 * j + 1 - n, ma = n;
-    if (i < 0) { sc = -n; ma = n - 1; } else if (i >= n) { sc = n; ma = n - 1; }
-    if (j < 0) { tc = -n; ma = n - 1; } else if (j >= n) { tc = n; ma = n - 1; }
-    int p[3];
-    for (int a = 0; a < 3; ++a) p[a] = fb.major[a] * ma + fb.s[a] * sc + fb.t[a] * tc;
-    // which face is this point on?  exactly one coordinate has magnitude n
-    int f2 = -1;
-    for (int g = 0; g < 6 && f2 < 0; ++g) {
-        const FaceBasis &gb = kFaces[g];
-        int m = gb.major[0] * p[0] + gb.major[1] * p[1] + gb.major[2] * p[2];
-        if (m == n) f2 = g;
-    }
-    const FaceBasis &gb = kFaces[f2];
-    int s2 = gb.s[0] * p[0] + gb.s[1] * p[1] + gb.s[2] * p[2];
-    int t2 = gb.t[0] * p[0] + gb.t[1] * p[1] + gb.t[2] * p[2];
-    int i2 = (s2 + n - 1) / 2, j2 = (t2 + n - 1) / 2;
-    if (i2 < 0) i2 = 0; if (i2 > n - 1) i2 = n - 1;
-    if (j2 < 0) j2 = 0; if (j2 > n - 1) j2 = n - 1;
-    return faces[((size_t)f2 * n + j2) * n + i2];
-}
-
-void build_cube_apron(const uint8_t *faces, int n, std::vector<uint8_t> &out) {
-    const int st = n + 2;
-    out.assign((size_t)6 * st * st, 0);
-    for (int f = 0; f < 6; ++f)
-        for (int j = -1; j <= n; ++j)
-            for (int i = -1; i <= n; ++i) {
-                const bool oi = (i < 0 || i >= n), oj = (j < 0 || j >= n);
-                int v;
-                if (!oi && !oj) {
-                    v = faces[((size_t)f * n + j) * n + i];
-                } else if (oi && oj) {
-                    const int ci = i < 0 ? 0 : n - 1, cj = j < 0 ? 0 : n - 1;
-                    const int a = faces[((size_t)f * n + cj) * n + ci];
-                    const int b = cube_fold(faces, n, f, i, cj);
-                    const int c = cube_fold(faces, n, f, ci, j);
-                    v = (a + b + c + 1) / 3;
-                } else {
-                    v = cube_fold(faces, n, f, i, j);
-                }
-                out[((size_t)f * st + (j + 1)) * st + (i + 1)] = (uint8_t)v;
-            }
-}
-
-// ---- device texture layouts (see atmo_kernels.hip "samplers") ---------------------------------------------
-
-// 6 x (n+1)^2 words: word (i,j) of a face = padded texels (i,j), (i+1,j), (i,j+1), (i+1,j+1) in bytes 0..3
-void build_cube_footprints(const std::vector<uint8_t> &padded, int n, std::vector<uint32_t> &out) {
-    const int ps = n + 2, fs = n + 1;
+// ---- host-side statement of the device texture layouts (atmo_host_layout_*: the CPU checker) ----------------------
+// The same per-element functions (atmo_layout.h) the re-layout kernels evaluate on the GPU.
+void build_cube_footprints(const uint8_t *faces, int n, std::vector<uint32_t> &out) {
+    const int fs = n + 1;
     out.assign((size_t)6 * fs * fs, 0u);
     for (int f = 0; f < 6; ++f)
         for (int j = 0; j < fs; ++j)
-            for (int i = 0; i < fs; ++i) {
-                const uint8_t *p = &padded[((size_t)f * ps + j) * ps + i];
-                out[((size_t)f * fs + j) * fs + i] =
-                    (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[ps] << 16) | ((uint32_t)p[ps + 1] << 24);
-            }
+            for (int i = 0; i < fs; ++i) out[((size_t)f * fs + j) * fs + i] = atmo::cube_footprint_word(faces, n, f, i, j);
 }
 
-// n^3 words: word (i,j,k) = T(i,j,k), T(i+1,j,k), T(i,j+1,k), T(i+1,j+1,k) with repeat wrap
 void build_shape_footprints(const uint8_t *t, int n, std::vector<uint32_t> &out) {
     out.assign((size_t)n * n * n, 0u);
     for (int k = 0; k < n; ++k)
-        for (int j = 0; j < n; ++j) {
-            const int j1 = (j + 1) % n;
-            const uint8_t *r0 = t + ((size_t)k * n + j) * n, *r1 = t + ((size_t)k * n + j1) * n;
-            for (int i = 0; i < n; ++i) {
-                const int i1 = (i + 1) % n;
-                out[((size_t)k * n + j) * n + i] =
-                    (uint32_t)r0[i] | ((uint32_t)r0[i1] << 8) | ((uint32_t)r1[i] << 16) | ((uint32_t)r1[i1] << 24);
-            }
-        }
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i) out[((size_t)k * n + j) * n + i] = atmo::shape_footprint_word(t, n, i, j, k);
 }
 
-// (h+2) x (w+2) floats with a clamp-to-edge apron
 void build_lut_apron(const float *lut, int w, int h, std::vector<float> &out) {
     const int st = w + 2;
     out.assign((size_t)st * (h + 2), 0.0f);
-    for (int j = -1; j <= h; ++j) {
-        const int cj = j < 0 ? 0 : (j >= h ? h - 1 : j);
-        for (int i = -1; i <= w; ++i) {
-            const int ci = i < 0 ? 0 : (i >= w ? w - 1 : i);
-            out[(size_t)(j + 1) * st + (i + 1)] = lut[(size_t)cj * w + ci];
-        }
-    }
+    for (int j = 0; j < h + 2; ++j)
+        for (int i = 0; i < st; ++i) out[(size_t)j * st + i] = atmo::lut_apron_value(lut, w, h, i, j);
 }
 
 // ---- per-frame constants, evaluated like a scalar fp32 run of the shader would ----------------------------
@@ -351,6 +282,8 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
     rc.blue = (const uint8_t *)ctx->blue.ptr;
     rc.shape = (const uint32_t *)ctx->shape.ptr; rc.shape_n = ctx->shape_n;
     rc.cube = (const uint32_t *)ctx->cube.ptr; rc.cube_n = ctx->cube_n;
+    rc.cube_levels = ctx->cube_levels;
+    rc.cube_level_off = (const uint32_t *)ctx->cube_level_off.ptr;
     rc.depth = depth;
     rc.out = (float4 *)rgba;
     rc.out_pitch = f->x1 - f->x0;
@@ -464,6 +397,9 @@ int atmo_destroy(AtmoContext *ctx) {
     dev_free(ctx->blue);
     dev_free(ctx->shape);
     dev_free(ctx->cube);
+    dev_free(ctx->cube_level_off);
+    dev_free(ctx->staging);
+    if (ctx->tex_event) (void)hipEventDestroy(ctx->tex_event);
     if (ctx->fb_stream) {
         (void)hipStreamSynchronize(ctx->fb_stream);
         (void)hipStreamDestroy(ctx->fb_stream);
@@ -502,80 +438,173 @@ int atmo_get_param_f32(AtmoContext *ctx, const char *name, float *v, int n) {
     return ATMO_OK;
 }
 
-int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h, int d, const void *data, int memory) {
+// Raw texels of a texture update, on the device: the caller's buffer itself (ATMO_MEM_DEVICE) or the context's staging
+// buffer filled by an asynchronous copy on `s` (ATMO_MEM_HOST).  The staging buffer is reused by the next update, which
+// is safe on one stream; an update arriving on another stream first waits for the previous one.
+static int stage_texels(AtmoContext *ctx, const void *data, size_t bytes, int memory, hipStream_t s, size_t extra_bytes, uint8_t **out) {
+    if (memory == ATMO_MEM_DEVICE && extra_bytes == 0) { *out = (uint8_t *)const_cast<void *>(data); return ATMO_OK; }
+    if (ctx->staging_used && ctx->staging_stream != s) HIP_TRY(ctx, hipStreamSynchronize(ctx->staging_stream));
+    if (ctx->staging.bytes < bytes + extra_bytes) {
+        if (ctx->staging_used) HIP_TRY(ctx, hipStreamSynchronize(ctx->staging_stream));
+        const int rc = dev_alloc(ctx, ctx->staging, bytes + extra_bytes);
+        if (rc != ATMO_OK) return rc;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->staging.ptr, data, bytes, memory == ATMO_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+    ctx->staging_stream = s;
+    ctx->staging_used = true;
+    *out = (uint8_t *)ctx->staging.ptr;
+    return ATMO_OK;
+}
+
+// same-size updates overwrite the bound copy in place (stream-ordered); a size change frees it, which waits for the device
+static int tex_alloc(AtmoContext *ctx, DeviceBuffer &b, size_t bytes) { return dev_alloc(ctx, b, bytes); }
+
+static int tex_updated(AtmoContext *ctx, hipStream_t s) {
+    if (!ctx->tex_event) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->tex_event, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(ctx->tex_event, s));
+    ctx->tex_stream = s;
+    ctx->tex_pending = true;
+    return ATMO_OK;
+}
+
+int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h, int d, int mips, const void *data, int memory,
+                     void *stream) {
     if (!ctx) return ATMO_E_ARG;
     if (!name) return fail(ctx, ATMO_E_NAME, "atmo_set_texture: name is null");
     if (memory != ATMO_MEM_HOST && memory != ATMO_MEM_DEVICE) return fail(ctx, ATMO_E_ARG, "atmo_set_texture: bad memory kind");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
     const hipMemcpyKind ck = memory == ATMO_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-    // Texture updates are rare (bake, scene load): serialise with any in-flight render that reads the old copy.
-    HIP_TRY(ctx, hipDeviceSynchronize());
+    const bool is_cube = std::strcmp(name, "u_cloud_coverage_cubemap") == 0;
+    if (!is_cube && data && mips != 0 && mips != 1) return fail(ctx, ATMO_E_ARG, "atmo_set_texture: only the cubemap takes mip levels");
 
     if (std::strcmp(name, "u_optical_depth_texture") == 0) {
         if (!data) { dev_free(ctx->lut); ctx->lut_w = ctx->lut_h = 0; return ATMO_OK; }
         if (kind != ATMO_TEX_2D_R32F) return fail(ctx, ATMO_E_ARG, "u_optical_depth_texture must be ATMO_TEX_2D_R32F");
         if (w < 1 || h < 1 || w > 8192 || h > 8192) return fail(ctx, ATMO_E_ARG, "u_optical_depth_texture: bad size");
-        std::vector<float> host((size_t)w * h), padded;
-        if (memory == ATMO_MEM_HOST) std::memcpy(host.data(), data, host.size() * sizeof(float));
-        else HIP_TRY(ctx, hipMemcpy(host.data(), data, host.size() * sizeof(float), hipMemcpyDeviceToHost));
-        build_lut_apron(host.data(), w, h, padded);
-        int rc = dev_alloc(ctx, ctx->lut, padded.size() * sizeof(float));
+        uint8_t *raw = nullptr;
+        int rc = stage_texels(ctx, data, (size_t)w * h * sizeof(float), memory, s, 0, &raw);
+        if (rc == ATMO_OK) rc = tex_alloc(ctx, ctx->lut, (size_t)(w + 2) * (h + 2) * sizeof(float));
         if (rc != ATMO_OK) return rc;
-        HIP_TRY(ctx, hipMemcpy(ctx->lut.ptr, padded.data(), ctx->lut.bytes, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, atmo::launch_layout_lut((const float *)raw, w, h, (float *)ctx->lut.ptr, s));
         ctx->lut_w = w; ctx->lut_h = h;
-        return ATMO_OK;
+        return tex_updated(ctx, s);
     }
     if (std::strcmp(name, "u_blue_noise_texture") == 0) {
-        if (!data) { HIP_TRY(ctx, hipMemset(ctx->blue.ptr, 0, 256 * 256)); return ATMO_OK; }
+        if (!data) { HIP_TRY(ctx, hipMemsetAsync(ctx->blue.ptr, 0, 256 * 256, s)); return tex_updated(ctx, s); }
         if (kind != ATMO_TEX_2D_R8) return fail(ctx, ATMO_E_ARG, "u_blue_noise_texture must be ATMO_TEX_2D_R8");
         if (w != 256 || h != 256) return fail(ctx, ATMO_E_ARG, "u_blue_noise_texture must be 256x256 (indexed & 0xff, main:169)");
-        HIP_TRY(ctx, hipMemcpy(ctx->blue.ptr, data, 256 * 256, ck));
-        return ATMO_OK;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->blue.ptr, data, 256 * 256, ck, s));
+        return tex_updated(ctx, s);
     }
     if (std::strcmp(name, "u_cloud_shape_texture") == 0) {
         if (!data) { dev_free(ctx->shape); ctx->shape_n = 0; return ATMO_OK; }
         if (kind != ATMO_TEX_3D_R8) return fail(ctx, ATMO_E_ARG, "u_cloud_shape_texture must be ATMO_TEX_3D_R8");
         if (w < 1 || w > 512 || h != w || d != w) return fail(ctx, ATMO_E_ARG, "u_cloud_shape_texture must be n x n x n, n <= 512");
-        std::vector<uint8_t> host((size_t)w * w * w);
-        if (memory == ATMO_MEM_HOST) std::memcpy(host.data(), data, host.size());
-        else HIP_TRY(ctx, hipMemcpy(host.data(), data, host.size(), hipMemcpyDeviceToHost));
-        std::vector<uint32_t> fp;
-        build_shape_footprints(host.data(), w, fp);
-        int rc = dev_alloc(ctx, ctx->shape, fp.size() * sizeof(uint32_t));
+        uint8_t *raw = nullptr;
+        int rc = stage_texels(ctx, data, (size_t)w * w * w, memory, s, 0, &raw);
+        if (rc == ATMO_OK) rc = tex_alloc(ctx, ctx->shape, (size_t)w * w * w * sizeof(uint32_t));
         if (rc != ATMO_OK) return rc;
-        HIP_TRY(ctx, hipMemcpy(ctx->shape.ptr, fp.data(), ctx->shape.bytes, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, atmo::launch_layout_shape(raw, w, (uint32_t *)ctx->shape.ptr, s));
         ctx->shape_n = w;
-        return ATMO_OK;
+        return tex_updated(ctx, s);
     }
-    if (std::strcmp(name, "u_cloud_coverage_cubemap") == 0) {
-        if (!data) { dev_free(ctx->cube); ctx->cube_n = 0; return ATMO_OK; }
+    if (is_cube) {
+        if (!data) { dev_free(ctx->cube); ctx->cube_n = 0; ctx->cube_levels = 0; return ATMO_OK; }
         if (kind != ATMO_TEX_CUBE_R8) return fail(ctx, ATMO_E_ARG, "u_cloud_coverage_cubemap must be ATMO_TEX_CUBE_R8");
         if (w < 1 || w > 4096 || h != w || d != 6) return fail(ctx, ATMO_E_ARG, "u_cloud_coverage_cubemap must be n x n x 6 faces");
-        const size_t face_bytes = (size_t)w * w;
-        std::vector<uint8_t> host(6 * face_bytes);
-        if (memory == ATMO_MEM_HOST) std::memcpy(host.data(), data, host.size());
-        else HIP_TRY(ctx, hipMemcpy(host.data(), data, host.size(), hipMemcpyDeviceToHost));
-        std::vector<uint8_t> padded;
-        build_cube_apron(host.data(), w, padded);
-        std::vector<uint32_t> fp;
-        build_cube_footprints(padded, w, fp);
-        int rc = dev_alloc(ctx, ctx->cube, fp.size() * sizeof(uint32_t));
+        const int full = atmo::cube_full_mip_count(w);
+        if (mips < 0 || mips > full) return fail(ctx, ATMO_E_ARG, "u_cloud_coverage_cubemap: mips must be 0 (generate the chain), 1 (level 0 only) .. log2(n)+1");
+        const int given = mips == 0 ? 1 : mips;      // levels present in `data`, packed level after level
+        const int levels = mips == 0 ? full : mips;  // levels bound afterwards
+        size_t given_bytes = 0, chain_bytes = 0, fp_words = 0;
+        for (int l = 0; l < levels; ++l) {
+            if (l < given) given_bytes += atmo::cube_level_texels(w, l);
+            chain_bytes += atmo::cube_level_texels(w, l);
+            ctx->cube_level_off_host[l] = (uint32_t)fp_words;
+            fp_words += atmo::cube_level_footprints(w, l);
+        }
+        // the texel chain lives in the staging buffer: given levels copied in, missing ones generated behind them
+        uint8_t *raw = nullptr;
+        int rc = stage_texels(ctx, data, given_bytes, memory, s, chain_bytes - given_bytes + 1, &raw);
+        if (rc == ATMO_OK) rc = tex_alloc(ctx, ctx->cube, fp_words * sizeof(uint32_t));
+        if (rc == ATMO_OK) rc = dev_alloc(ctx, ctx->cube_level_off, sizeof(ctx->cube_level_off_host));
         if (rc != ATMO_OK) return rc;
-        HIP_TRY(ctx, hipMemcpy(ctx->cube.ptr, fp.data(), ctx->cube.bytes, hipMemcpyHostToDevice));
+        size_t off = 0;
+        for (int l = 0; l < levels; ++l) {
+            const int nl = w >> l;
+            if (l + 1 < levels && l + 1 >= given)
+                HIP_TRY(ctx, atmo::launch_cube_mip(raw + off, nl, raw + off + atmo::cube_level_texels(w, l), s));
+            HIP_TRY(ctx, atmo::launch_layout_cube(raw + off, nl, (uint32_t *)ctx->cube.ptr + ctx->cube_level_off_host[l], s));
+            off += atmo::cube_level_texels(w, l);
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->cube_level_off.ptr, ctx->cube_level_off_host, sizeof(ctx->cube_level_off_host), hipMemcpyHostToDevice, s));
         ctx->cube_n = w;
-        return ATMO_OK;
+        ctx->cube_levels = levels;
+        return tex_updated(ctx, s);
     }
     return fail(ctx, ATMO_E_NAME, std::string("atmo_set_texture: unknown texture uniform '") + name + "'");
+}
+
+int atmo_get_texture_size(AtmoContext *ctx, const char *name, int *w, int *h, int *d, int *mips) {
+    if (!ctx) return ATMO_E_ARG;
+    if (!name) return fail(ctx, ATMO_E_NAME, "atmo_get_texture_size: name is null");
+    int W = 0, H = 0, D = 0, M = 0;
+    if (std::strcmp(name, "u_optical_depth_texture") == 0) { W = ctx->lut_w; H = ctx->lut_h; D = W ? 1 : 0; M = W ? 1 : 0; }
+    else if (std::strcmp(name, "u_blue_noise_texture") == 0) { W = H = 256; D = 1; M = 1; }
+    else if (std::strcmp(name, "u_cloud_shape_texture") == 0) { W = H = D = ctx->shape_n; M = W ? 1 : 0; }
+    else if (std::strcmp(name, "u_cloud_coverage_cubemap") == 0) { W = H = ctx->cube_n; D = W ? 6 : 0; M = ctx->cube_levels; }
+    else return fail(ctx, ATMO_E_NAME, std::string("atmo_get_texture_size: unknown texture uniform '") + name + "'");
+    if (w) *w = W;
+    if (h) *h = H;
+    if (d) *d = D;
+    if (mips) *mips = M;
+    return ATMO_OK;
+}
+
+int atmo_read_texture_layout(AtmoContext *ctx, const char *name, void *out_host, size_t capacity_bytes, size_t *bytes_out, void *stream) {
+    if (!ctx) return ATMO_E_ARG;
+    if (!name) return fail(ctx, ATMO_E_NAME, "atmo_read_texture_layout: name is null");
+    const DeviceBuffer *b = nullptr;
+    if (std::strcmp(name, "u_optical_depth_texture") == 0) b = &ctx->lut;
+    else if (std::strcmp(name, "u_blue_noise_texture") == 0) b = &ctx->blue;
+    else if (std::strcmp(name, "u_cloud_shape_texture") == 0) b = &ctx->shape;
+    else if (std::strcmp(name, "u_cloud_coverage_cubemap") == 0) b = &ctx->cube;
+    else return fail(ctx, ATMO_E_NAME, std::string("atmo_read_texture_layout: unknown texture uniform '") + name + "'");
+    if (bytes_out) *bytes_out = b->bytes;
+    if (!out_host) return ATMO_OK;
+    if (capacity_bytes < b->bytes) return fail(ctx, ATMO_E_ARG, "atmo_read_texture_layout: buffer too small");
+    if (!b->ptr) return ATMO_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (ctx->tex_pending && ctx->tex_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->tex_event, 0));
+    HIP_TRY(ctx, hipMemcpyAsync(out_host, b->ptr, b->bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return ATMO_OK;
+}
+
+int atmo_set_sampler_lod(AtmoContext *ctx, int mode) {
+    if (!ctx) return ATMO_E_ARG;
+    if (mode != 0 && mode != 1) return fail(ctx, ATMO_E_ARG, "atmo_set_sampler_lod: 0 (LOD 0) or 1 (implicit LOD from 2x2 pixel quads)");
+    ctx->sampler_lod = mode;
+    return ATMO_OK;
 }
 
 // ---- host-only layout helpers (no device needed): what atmo_set_texture uploads -----------------------------------
 int atmo_host_layout_cubemap(const uint8_t *faces, int n, uint32_t *footprints_out) {
     if (!faces || !footprints_out || n < 1 || n > 4096) return ATMO_E_ARG;
-    std::vector<uint8_t> padded;
-    build_cube_apron(faces, n, padded);
     std::vector<uint32_t> fp;
-    build_cube_footprints(padded, n, fp);
+    build_cube_footprints(faces, n, fp);
     std::memcpy(footprints_out, fp.data(), fp.size() * sizeof(uint32_t));
+    return ATMO_OK;
+}
+
+int atmo_host_cubemap_mip(const uint8_t *level, int n, uint8_t *next_out) {
+    if (!level || !next_out || n < 2 || n > 4096) return ATMO_E_ARG;
+    const int m = n >> 1;
+    for (int f = 0; f < 6; ++f)
+        for (int j = 0; j < m; ++j)
+            for (int i = 0; i < m; ++i) next_out[((size_t)f * m + j) * m + i] = atmo::cube_mip_texel(level, n, f, i, j);
     return ATMO_OK;
 }
 
@@ -627,7 +656,8 @@ int atmo_generate_noise_cubemap(AtmoContext *ctx, int resolution, uint32_t seed,
         if (e != hipSuccess) rc = hip_fail(ctx, e, "hipMemcpy");
     }
     if (rc == ATMO_OK && bind)
-        rc = atmo_set_texture(ctx, "u_cloud_coverage_cubemap", ATMO_TEX_CUBE_R8, resolution, resolution, 6, dev, ATMO_MEM_DEVICE);
+        rc = atmo_set_texture(ctx, "u_cloud_coverage_cubemap", ATMO_TEX_CUBE_R8, resolution, resolution, 6, /*mips: generate the chain*/ 0,
+                              dev, ATMO_MEM_DEVICE, nullptr);  // stays on the device: mip + re-layout kernels, no host round trip
     (void)hipFree(dev);
     return rc;
 }
@@ -637,8 +667,7 @@ int atmo_bake_optical_depth(AtmoContext *ctx, void *stream) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int w = 256, h = 256;  // optical_depth_baker.gd:24
     if (ctx->lut_w != w || ctx->lut_h != h) {
-        HIP_TRY(ctx, hipDeviceSynchronize());
-        int rc = dev_alloc(ctx, ctx->lut, (size_t)(w + 2) * (h + 2) * sizeof(float));
+        int rc = dev_alloc(ctx, ctx->lut, (size_t)(w + 2) * (h + 2) * sizeof(float));  // a size change waits for the device (hipFree)
         if (rc != ATMO_OK) return rc;
         ctx->lut_w = w; ctx->lut_h = h;
     }
@@ -650,20 +679,22 @@ int atmo_bake_optical_depth(AtmoContext *ctx, void *stream) {
     bc.steps = 64;  // optical_depth.gdshader:18
     bc.out = (float *)ctx->lut.ptr;
     HIP_TRY(ctx, atmo::launch_bake(bc, (hipStream_t)stream));
-    return ATMO_OK;
+    return tex_updated(ctx, (hipStream_t)stream);  // draws and read-backs on other streams wait for this bake
 }
 
 int atmo_read_optical_depth(AtmoContext *ctx, float *lut_host, uint8_t *rgba8_host, int capacity_texels, void *stream) {
     if (!ctx) return ATMO_E_ARG;
     if (!ctx->lut.ptr) return fail(ctx, ATMO_E_STATE, "atmo_read_optical_depth: no LUT bound");
     const int n = ctx->lut_w * ctx->lut_h;
-    if (capacity_texels < n) return fail(ctx, ATMO_E_ARG, "atmo_read_optical_depth: buffer too small");
+    if (capacity_texels < n) return fail(ctx, ATMO_E_ARG, "atmo_read_optical_depth: buffer too small (atmo_get_texture_size gives w x h)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    hipStream_t s = (hipStream_t)stream;
+    if (ctx->tex_pending && ctx->tex_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->tex_event, 0));  // a bake on another stream
     std::vector<float> tmp, padded((size_t)(ctx->lut_w + 2) * (ctx->lut_h + 2));
     float *dst = lut_host;
     if (!dst) { tmp.resize(n); dst = tmp.data(); }
-    HIP_TRY(ctx, hipMemcpy(padded.data(), ctx->lut.ptr, padded.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpyAsync(padded.data(), ctx->lut.ptr, padded.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
     for (int j = 0; j < ctx->lut_h; ++j)  // strip the apron
         std::memcpy(dst + (size_t)j * ctx->lut_w, &padded[(size_t)(j + 1) * (ctx->lut_w + 2) + 1], (size_t)ctx->lut_w * sizeof(float));
     if (rgba8_host) {
@@ -722,6 +753,7 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         rc.composite = 1;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (ctx->tex_pending && ctx->tex_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->tex_event, 0));  // texture updated on another stream
     const int split = choose_split(ctx, frame);
     int gx = 0, gy = 0;
     atmo::render_grid(rc, split, &gx, &gy);

@@ -57,6 +57,8 @@ struct RenderConsts {
     int32_t shape_n;
     const uint32_t *cube;    // u_cloud_coverage_cubemap: 6 x (n+1)^2 footprint words of the seamless-apron faces; null => 1.0
     int32_t cube_n;
+    int32_t cube_levels;             // mip levels bound; level l = (cube_n >> l)-sided faces, footprints at cube + cube_level_off[l]
+    const uint32_t *cube_level_off;  // device array of 16 element offsets
     // --- per-pixel streams
     const float *depth;      // h rows of w
     float4 *out;             // plain: (y1-y0) rows of (x1-x0); composite: the h x w scene colour buffer, blended in place
@@ -90,6 +92,10 @@ enum KernelFlags : int { KF_CLOUDS = 1, KF_CLOUD_LIGHT_RM = 2, KF_LIGHT_DIRECT =
 hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream_t stream);
 hipError_t launch_bake(const BakeConsts &bc, hipStream_t stream);
 hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int n, hipStream_t stream);
+hipError_t launch_layout_lut(const float *lut, int w, int h, float *out, hipStream_t stream);
+hipError_t launch_layout_shape(const uint8_t *t, int n, uint32_t *out, hipStream_t stream);
+hipError_t launch_layout_cube(const uint8_t *faces, int n, uint32_t *out, hipStream_t stream);
+hipError_t launch_cube_mip(const uint8_t *level, int n, uint8_t *next, hipStream_t stream);
 void render_grid(const RenderConsts &rc, int split, int *tiles_x, int *tiles_y);
 hipError_t launch_noise_cubemap(const NoiseCubemapConsts &nc, hipStream_t stream);
 const char *render_kernel_name(int flags, int light_steps, int split);

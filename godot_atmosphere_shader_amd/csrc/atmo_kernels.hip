@@ -25,6 +25,7 @@
 //   include/cloud_funcs.gdshaderinc:249-324             render_clouds            -> atmo_render_kernel tail
 //   optical_depth.gdshader:17-31,45-68                  LUT bake                 -> atmo_bake_kernel
 #include "atmo_device.h"
+#include "atmo_layout.h"
 
 #include <cstdio>
 
@@ -998,6 +999,49 @@ __global__ __launch_bounds__(ORDER_THREADS) void atmo_tile_order_kernel(uint32_t
 
 hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int n, hipStream_t stream) {
     hipLaunchKernelGGL(atmo_tile_order_kernel, dim3(1), dim3(ORDER_THREADS), 0, stream, cost, order, n);
+    return hipGetLastError();
+}
+
+// ---- texture re-layout on the device (atmo_set_texture), stream-ordered; element definitions in atmo_layout.h ------------
+__global__ __launch_bounds__(256) void atmo_layout_lut_kernel(const float *__restrict__ lut, int w, int h, float *__restrict__ out) {
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i < w + 2 && j < h + 2) out[(size_t)j * (w + 2) + i] = lut_apron_value(lut, w, h, i, j);
+}
+
+__global__ __launch_bounds__(256) void atmo_layout_shape_kernel(const uint8_t *__restrict__ t, int n, uint32_t *__restrict__ out) {
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), j = blockIdx.y * 4 + (threadIdx.x >> 6), k = blockIdx.z;
+    if (i < n && j < n) out[((size_t)k * n + j) * n + i] = shape_footprint_word(t, n, i, j, k);
+}
+
+// one mip level: faces = 6 x n^2 texels of that level, out = its 6 x (n+1)^2 footprint words
+__global__ __launch_bounds__(256) void atmo_layout_cube_kernel(const uint8_t *__restrict__ faces, int n, uint32_t *__restrict__ out) {
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), j = blockIdx.y * 4 + (threadIdx.x >> 6), f = blockIdx.z;
+    if (i <= n && j <= n) out[((size_t)f * (n + 1) + j) * (n + 1) + i] = cube_footprint_word(faces, n, f, i, j);
+}
+
+// next = 2x2 box of level (n per side) -> n/2 per side; Image.generate_mipmaps on L8 (noise_cubemap.gd:135)
+__global__ __launch_bounds__(256) void atmo_cube_mip_kernel(const uint8_t *__restrict__ level, int n, uint8_t *__restrict__ next) {
+    const int m = n >> 1;
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), j = blockIdx.y * 4 + (threadIdx.x >> 6), f = blockIdx.z;
+    if (i < m && j < m) next[((size_t)f * m + j) * m + i] = cube_mip_texel(level, n, f, i, j);
+}
+
+hipError_t launch_layout_lut(const float *lut, int w, int h, float *out, hipStream_t stream) {
+    hipLaunchKernelGGL(atmo_layout_lut_kernel, dim3((w + 2 + 63) / 64, (h + 2 + 3) / 4), dim3(256), 0, stream, lut, w, h, out);
+    return hipGetLastError();
+}
+hipError_t launch_layout_shape(const uint8_t *t, int n, uint32_t *out, hipStream_t stream) {
+    hipLaunchKernelGGL(atmo_layout_shape_kernel, dim3((n + 63) / 64, (n + 3) / 4, n), dim3(256), 0, stream, t, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_layout_cube(const uint8_t *faces, int n, uint32_t *out, hipStream_t stream) {
+    hipLaunchKernelGGL(atmo_layout_cube_kernel, dim3((n + 1 + 63) / 64, (n + 1 + 3) / 4, 6), dim3(256), 0, stream, faces, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_cube_mip(const uint8_t *level, int n, uint8_t *next, hipStream_t stream) {
+    const int m = n >> 1;
+    if (m < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(atmo_cube_mip_kernel, dim3((m + 63) / 64, (m + 3) / 4, 6), dim3(256), 0, stream, level, n, next);
     return hipGetLastError();
 }
 

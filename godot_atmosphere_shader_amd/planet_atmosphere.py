@@ -215,7 +215,7 @@ class PlanetAtmosphere:
     def __init__(self, device: int = 0, light_mode: str = "lut", light_steps: int = 0,
                  view_steps: int | None = None, cloud_steps: int | None = None, blue_noise=None,
                  precise_clouds: bool = True, double_precision: bool = False, lane_split: int = 0,
-                 tile_feedback: int = -1):
+                 tile_feedback: int = -1, cubemap_lod: bool = False):
         self._lib = N.load()
         self._device = int(device)
         self._light_mode = {"lut": N.LIGHT_LUT, "direct": N.LIGHT_DIRECT}[light_mode]
@@ -226,6 +226,7 @@ class PlanetAtmosphere:
         self._double_precision = bool(double_precision)  # `#define DOUBLE_PRECISION` (main:25): engine negates INV_VIEW origin
         self._lane_split = int(lane_split)  # atmo_set_lane_split: 0 auto, 1 / 2 lanes per ray
         self._tile_feedback = int(tile_feedback)  # atmo_set_tile_feedback: -1 by variant, 0 off, 1 on
+        self._cubemap_lod = bool(cubemap_lod)  # atmo_set_sampler_lod: implicit LOD of the coverage cubemap (2x2 quad derivatives)
         self._ctx = C.c_void_p()
         self._planet_radius = 1.0
         self._atmosphere_height = 0.1
@@ -264,6 +265,7 @@ class PlanetAtmosphere:
         N.check(ctx, self._lib.atmo_set_host_double_precision(ctx, 1 if self._double_precision else 0))
         N.check(ctx, self._lib.atmo_set_lane_split(ctx, self._lane_split))
         N.check(ctx, self._lib.atmo_set_tile_feedback(ctx, self._tile_feedback))
+        N.check(ctx, self._lib.atmo_set_sampler_lod(ctx, 1 if self._cubemap_lod else 0))
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
@@ -401,9 +403,10 @@ class PlanetAtmosphere:
         if hasattr(value, "get_images"):  # a NoiseCubemap resource
             value = value.get_images()
         if value is None:
-            rc = self._lib.atmo_set_texture(self._ctx, name.encode(), kind, 0, 0, 0, None, N.MEM_HOST)
+            rc = self._lib.atmo_set_texture(self._ctx, name.encode(), kind, 0, 0, 0, 0, None, N.MEM_HOST, None)
             N.check(self._ctx, rc)
             return
+        mips = 1
         if name == "u_optical_depth_texture":
             a = np.ascontiguousarray(value, dtype=np.float32)
             h, w = a.shape
@@ -416,9 +419,18 @@ class PlanetAtmosphere:
             a = np.ascontiguousarray(value, dtype=np.uint8)
             d, h, w = a.shape
         else:
-            a = np.ascontiguousarray(value, dtype=np.uint8)
-            d, h, w = a.shape
-        rc = self._lib.atmo_set_texture(self._ctx, name.encode(), kind, w, h, d, a.ctypes.data_as(C.c_void_p), N.MEM_HOST)
+            # a cubemap is (6, n, n) = level 0 (its mip chain is generated on the device, as Image.generate_mipmaps
+            # does in noise_cubemap.gd:135), or a list of levels [(6, n, n), (6, n/2, n/2), ...] given explicitly
+            if isinstance(value, (list, tuple)):
+                levels = [np.ascontiguousarray(v, dtype=np.uint8) for v in value]
+                d, h, w = levels[0].shape
+                mips = len(levels)
+                a = np.concatenate([lv.reshape(-1) for lv in levels])
+            else:
+                a = np.ascontiguousarray(value, dtype=np.uint8)
+                d, h, w = a.shape
+                mips = 0
+        rc = self._lib.atmo_set_texture(self._ctx, name.encode(), kind, w, h, d, mips, a.ctypes.data_as(C.c_void_p), N.MEM_HOST, None)
         N.check(self._ctx, rc)
 
     # Object.get / Object.set with the "shader_params/<name>" convention (planet_atmosphere.gd:200-218)
@@ -470,11 +482,13 @@ class PlanetAtmosphere:
         """The baked LUT as the reference's baker would hand it to ImageTexture (FORMAT_RF), optionally with the
         RGBA8 packing of optical_depth.gdshader:33-43."""
         self._bake_if_needed(stream)
-        lut = np.empty((256, 256), dtype=np.float32)
-        rgba8 = np.empty((256, 256, 4), dtype=np.uint8) if with_rgba8 else None
+        w, h = C.c_int(0), C.c_int(0)
+        N.check(self._ctx, self._lib.atmo_get_texture_size(self._ctx, b"u_optical_depth_texture", C.byref(w), C.byref(h), None, None))
+        lut = np.empty((h.value, w.value), dtype=np.float32)
+        rgba8 = np.empty((h.value, w.value, 4), dtype=np.uint8) if with_rgba8 else None
         rc = self._lib.atmo_read_optical_depth(
             self._ctx, lut.ctypes.data_as(C.c_void_p),
-            rgba8.ctypes.data_as(C.c_void_p) if with_rgba8 else None, 256 * 256, C.c_void_p(stream or 0))
+            rgba8.ctypes.data_as(C.c_void_p) if with_rgba8 else None, w.value * h.value, C.c_void_p(stream or 0))
         N.check(self._ctx, rc)
         return (lut, rgba8) if with_rgba8 else lut
 

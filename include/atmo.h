@@ -61,7 +61,7 @@ enum AtmoTextureKind {
     ATMO_TEX_2D_R32F = 0,  /* u_optical_depth_texture (what optical_depth_baker.gd:75-80 uploads) */
     ATMO_TEX_2D_R8 = 1,    /* u_blue_noise_texture, 256x256 */
     ATMO_TEX_3D_R8 = 2,    /* u_cloud_shape_texture, n^3, x fastest */
-    ATMO_TEX_CUBE_R8 = 3   /* u_cloud_coverage_cubemap, 6 faces +X,-X,+Y,-Y,+Z,-Z of n^2, level 0 */
+    ATMO_TEX_CUBE_R8 = 3   /* u_cloud_coverage_cubemap, 6 faces +X,-X,+Y,-Y,+Z,-Z of n^2 per mip level */
 };
 
 enum AtmoMemory { ATMO_MEM_HOST = 0, ATMO_MEM_DEVICE = 1 };
@@ -114,9 +114,31 @@ int atmo_get_param_f32(AtmoContext *ctx, const char *name, float *v, int n);
  * (planet_atmosphere.gd:156), u_blue_noise_texture (:107), u_cloud_shape_texture and
  * u_cloud_coverage_cubemap (user-set).  The data is copied; `memory` says where `data` lives.
  * data == NULL unsets the texture (cubemap => constant 1.0).  2-D: w x h; 3-D: w=h=d=n; cube: w=h=n, d=6.
+ * mips (cubemap only; 0 or 1 for the others): number of mip levels in `data`, packed level after level (level l = 6 faces
+ * of (n >> l)^2 texels); 1 = level 0 only; 0 = level 0 given, the rest of the chain generated on the device with the 2x2
+ * box filter Image.generate_mipmaps applies to L8 (noise_cubemap.gd:107,135).  Levels above 0 are only read in the
+ * implicit-LOD sampler mode (atmo_set_sampler_lod).
+ * The copy and the re-layout into the kernels' footprint layouts are enqueued on `stream` (hipStream_t, NULL = default
+ * stream) and draws of this context on other streams wait for them; nothing waits on the host except a copy from
+ * pageable host memory and the re-allocation when a texture changes size.  Updates of one context must not overlap
+ * draws that are still reading the previous copy on ANOTHER stream (same-stream order is enough).
  */
-int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h, int d,
-                     const void *data, int memory);
+int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h, int d, int mips,
+                     const void *data, int memory, void *stream);
+
+/* Size of the texture bound to a texture uniform (0 when unset): 2-D w x h (d = 1), 3-D n^3, cube n x n x 6 and its mips. */
+int atmo_get_texture_size(AtmoContext *ctx, const char *name, int *w, int *h, int *d, int *mips);
+
+/*
+ * Replaces: the implicit level-of-detail of `texture(u_cloud_coverage_cubemap, dir)` (cloud_funcs.gdshaderinc:15,45: a
+ * samplerCube with the default linear-mipmap filter).  0 (default) = level 0 only (the stated convention of round 1);
+ * 1 = implicit LOD: every 2x2 pixel quad differences the cube directions of its rays at the same march step (what the
+ * fragment pipeline's derivatives are), transforms them to the selected face (Vulkan 1.3 cube-map derivative
+ * transformation), lambda = log2(max(rho_x, rho_y)) clamped to the bound levels, and the sample is the linear mix of
+ * the seamless bilinear samples of the two nearest levels.  Needs a mip chain (atmo_set_texture mips != 1); exact rule
+ * in oracle/atmo_oracle.h.  The quad exchange of ray parameters uses DPP quad_perm moves.
+ */
+int atmo_set_sampler_lod(AtmoContext *ctx, int mode);
 
 /*
  * Replaces: OpticalDepthBaker (optical_depth_baker.gd:37-85) + shaders/optical_depth.gdshader:45-68:
@@ -217,6 +239,13 @@ int atmo_get_timing(AtmoContext *ctx, int *launches, double *total_ms);
 int atmo_host_layout_cubemap(const uint8_t *faces, int n, uint32_t *footprints_out);
 int atmo_host_layout_shape(const uint8_t *texels, int n, uint32_t *footprints_out);
 int atmo_host_layout_lut(const float *lut, int w, int h, float *apron_out);
+/* next mip level (n/2 per side, 6 faces) of a 6 x n^2 level: the 2x2 box (a + b + c + d + 2) >> 2 */
+int atmo_host_cubemap_mip(const uint8_t *level, int n, uint8_t *next_out);
+
+/* Diagnostics (no reference counterpart): copies the DEVICE layout of a bound texture (what the re-layout kernels of
+ * atmo_set_texture wrote: LUT apron / shape footprints / cubemap footprints of all bound levels / blue-noise bytes) to
+ * host memory, so it can be compared with atmo_host_layout_*.  out_host == NULL only reports the size in *bytes_out. */
+int atmo_read_texture_layout(AtmoContext *ctx, const char *name, void *out_host, size_t capacity_bytes, size_t *bytes_out, void *stream);
 
 /* Diagnostics (no reference counterpart): on the device, compares the kernels' cheap correctly-rounded sqrt and
  * divide-by-uniform helpers with the compiler's IEEE expansions over `count` consecutive float bit patterns

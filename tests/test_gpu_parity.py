@@ -213,9 +213,9 @@ def test_c_abi_error_codes():
     assert lib.atmo_set_param_f32(ctx, b"u_density", one, 1) == N.ATMO_OK
     back = (C.c_float * 1)(0.0)
     assert lib.atmo_get_param_f32(ctx, b"u_density", back, 1) == N.ATMO_OK and back[0] == 1.0
-    assert lib.atmo_set_texture(ctx, b"u_bogus_texture", N.TEX_2D_R8, 1, 1, 1, None, N.MEM_HOST) == N.ATMO_E_NAME
+    assert lib.atmo_set_texture(ctx, b"u_bogus_texture", N.TEX_2D_R8, 1, 1, 1, 1, None, N.MEM_HOST, None) == N.ATMO_E_NAME
     bn = np.zeros((128, 128), dtype=np.uint8)
-    assert lib.atmo_set_texture(ctx, b"u_blue_noise_texture", N.TEX_2D_R8, 128, 128, 1, bn.ctypes.data_as(C.c_void_p), N.MEM_HOST) == N.ATMO_E_ARG
+    assert lib.atmo_set_texture(ctx, b"u_blue_noise_texture", N.TEX_2D_R8, 128, 128, 1, 1, bn.ctypes.data_as(C.c_void_p), N.MEM_HOST, None) == N.ATMO_E_ARG
     f = N.AtmoFrame()
     f.viewport_w, f.viewport_h, f.x1, f.y1 = 16, 16, 16, 16
     depth = torch.zeros((16, 16), device="cuda")
@@ -461,13 +461,13 @@ def test_textures_from_device_memory(oracle32):
            dict(lut=lut, blue=tex["blue_noise"], shape=tex["shape"], cube=tex["cubemap"]).items()}
     # unset everything first so a stale copy cannot make the test pass
     for name, kind in ((b"u_cloud_shape_texture", N.TEX_3D_R8), (b"u_cloud_coverage_cubemap", N.TEX_CUBE_R8), (b"u_optical_depth_texture", N.TEX_2D_R32F)):
-        assert lib.atmo_set_texture(ctx, name, kind, 0, 0, 0, None, N.MEM_HOST) == N.ATMO_OK
+        assert lib.atmo_set_texture(ctx, name, kind, 0, 0, 0, 0, None, N.MEM_HOST, None) == N.ATMO_OK
     node._bake_pending = False
     f = N.AtmoFrame()
-    assert lib.atmo_set_texture(ctx, b"u_optical_depth_texture", N.TEX_2D_R32F, 256, 256, 1, C.c_void_p(dev["lut"].data_ptr()), N.MEM_DEVICE) == N.ATMO_OK
-    assert lib.atmo_set_texture(ctx, b"u_blue_noise_texture", N.TEX_2D_R8, 256, 256, 1, C.c_void_p(dev["blue"].data_ptr()), N.MEM_DEVICE) == N.ATMO_OK
-    assert lib.atmo_set_texture(ctx, b"u_cloud_shape_texture", N.TEX_3D_R8, 32, 32, 32, C.c_void_p(dev["shape"].data_ptr()), N.MEM_DEVICE) == N.ATMO_OK
-    assert lib.atmo_set_texture(ctx, b"u_cloud_coverage_cubemap", N.TEX_CUBE_R8, 64, 64, 6, C.c_void_p(dev["cube"].data_ptr()), N.MEM_DEVICE) == N.ATMO_OK
+    assert lib.atmo_set_texture(ctx, b"u_optical_depth_texture", N.TEX_2D_R32F, 256, 256, 1, 1, C.c_void_p(dev["lut"].data_ptr()), N.MEM_DEVICE, None) == N.ATMO_OK
+    assert lib.atmo_set_texture(ctx, b"u_blue_noise_texture", N.TEX_2D_R8, 256, 256, 1, 1, C.c_void_p(dev["blue"].data_ptr()), N.MEM_DEVICE, None) == N.ATMO_OK
+    assert lib.atmo_set_texture(ctx, b"u_cloud_shape_texture", N.TEX_3D_R8, 32, 32, 32, 1, C.c_void_p(dev["shape"].data_ptr()), N.MEM_DEVICE, None) == N.ATMO_OK
+    assert lib.atmo_set_texture(ctx, b"u_cloud_coverage_cubemap", N.TEX_CUBE_R8, 64, 64, 6, 1, C.c_void_p(dev["cube"].data_ptr()), N.MEM_DEVICE, None) == N.ATMO_OK
     got = _gpu_render(node, cam, depth_np)
     node.close()
     assert np.array_equal(got, ref)
@@ -929,3 +929,70 @@ def test_tile_feedback_default_policy_and_graph_capture():
     assert torch.equal(out, want)
     node.close()
     ref.close()
+
+
+# ---- texture re-layout on the device -----------------------------------------------------------------------------------
+
+def test_device_texture_layouts_equal_the_host_layouts():
+    """atmo_set_texture re-lays textures out with kernels, stream-ordered (no host loops, no device-wide sync): the
+    device buffers equal the host statement of the same layouts (atmo_host_layout_*) bit for bit -- LUT apron, shape
+    footprints (odd and power-of-two sizes), cubemap footprints of every level of a device-generated mip chain and of an
+    explicitly given chain; host and device sources; on a side stream."""
+    from godot_atmosphere_shader_amd import _native as N
+
+    lib = N.load()
+    ctx = C.c_void_p()
+    assert lib.atmo_create(0, N.VARIANT_CLOUDS_HIGH, 0, 0, N.LIGHT_LUT, 0, C.byref(ctx)) == N.ATMO_OK
+    rng = np.random.default_rng(5)
+    side = torch.cuda.Stream()
+    sptr = C.c_void_p(side.cuda_stream)
+
+    def read_layout(name, dtype):
+        nbytes = C.c_size_t(0)
+        assert lib.atmo_read_texture_layout(ctx, name, None, 0, C.byref(nbytes), None) == N.ATMO_OK
+        out = np.empty(nbytes.value // np.dtype(dtype).itemsize, dtype=dtype)
+        assert lib.atmo_read_texture_layout(ctx, name, out.ctypes.data_as(C.c_void_p), nbytes.value, None, sptr) == N.ATMO_OK
+        return out
+
+    for (w, h) in ((256, 256), (37, 19)):
+        lut = rng.random((h, w), dtype=np.float32)
+        want = np.zeros((h + 2, w + 2), dtype=np.float32)
+        assert lib.atmo_host_layout_lut(lut.ctypes.data_as(C.c_void_p), w, h, want.ctypes.data_as(C.c_void_p)) == N.ATMO_OK
+        assert lib.atmo_set_texture(ctx, b"u_optical_depth_texture", N.TEX_2D_R32F, w, h, 1, 1, lut.ctypes.data_as(C.c_void_p), N.MEM_HOST, sptr) == N.ATMO_OK
+        assert np.array_equal(read_layout(b"u_optical_depth_texture", np.float32).reshape(h + 2, w + 2), want)
+    for n in (64, 24, 5):
+        tex = rng.integers(0, 256, (n, n, n), dtype=np.uint8)
+        want = np.zeros((n, n, n), dtype=np.uint32)
+        assert lib.atmo_host_layout_shape(tex.ctypes.data_as(C.c_void_p), n, want.ctypes.data_as(C.c_void_p)) == N.ATMO_OK
+        dev = torch.from_numpy(tex).cuda()
+        assert lib.atmo_set_texture(ctx, b"u_cloud_shape_texture", N.TEX_3D_R8, n, n, n, 1, C.c_void_p(dev.data_ptr()), N.MEM_DEVICE, sptr) == N.ATMO_OK
+        assert np.array_equal(read_layout(b"u_cloud_shape_texture", np.uint32).reshape(n, n, n), want)
+    for n, mips in ((64, 0), (16, 0), (12, 0), (32, 3), (8, 1)):
+        cube = rng.integers(0, 256, (6, n, n), dtype=np.uint8)
+        levels = [cube]
+        full = int(np.log2(n)) + 1 if n & (n - 1) == 0 else len(bin(n)) - 2
+        for _ in range((full if mips == 0 else mips) - 1):
+            prev = levels[-1]
+            m = prev.shape[1] // 2
+            nxt = np.zeros((6, m, m), dtype=np.uint8)
+            assert lib.atmo_host_cubemap_mip(prev.ctypes.data_as(C.c_void_p), prev.shape[1], nxt.ctypes.data_as(C.c_void_p)) == N.ATMO_OK
+            box = (prev[:, 0:2 * m:2, 0:2 * m:2].astype(np.int32) + prev[:, 0:2 * m:2, 1:2 * m:2] + prev[:, 1:2 * m:2, 0:2 * m:2] + prev[:, 1:2 * m:2, 1:2 * m:2] + 2) >> 2
+            assert np.array_equal(nxt, box.astype(np.uint8))  # (a + b + c + d + 2) >> 2
+            levels.append(nxt)
+        want = []
+        for lv in levels:
+            m = lv.shape[1]
+            fp = np.zeros((6, m + 1, m + 1), dtype=np.uint32)
+            assert lib.atmo_host_layout_cubemap(np.ascontiguousarray(lv).ctypes.data_as(C.c_void_p), m, fp.ctypes.data_as(C.c_void_p)) == N.ATMO_OK
+            want.append(fp.reshape(-1))
+        given = np.concatenate([lv.reshape(-1) for lv in (levels if mips > 1 else levels[:1])])
+        assert lib.atmo_set_texture(ctx, b"u_cloud_coverage_cubemap", N.TEX_CUBE_R8, n, n, 6, mips, given.ctypes.data_as(C.c_void_p), N.MEM_HOST, sptr) == N.ATMO_OK
+        wq, hq, dq, mq = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        assert lib.atmo_get_texture_size(ctx, b"u_cloud_coverage_cubemap", C.byref(wq), C.byref(hq), C.byref(dq), C.byref(mq)) == N.ATMO_OK
+        assert (wq.value, hq.value, dq.value, mq.value) == (n, n, 6, len(levels))
+        assert np.array_equal(read_layout(b"u_cloud_coverage_cubemap", np.uint32), np.concatenate(want))
+    # argument checks
+    assert lib.atmo_set_texture(ctx, b"u_cloud_coverage_cubemap", N.TEX_CUBE_R8, 8, 8, 6, 9, cube.ctypes.data_as(C.c_void_p), N.MEM_HOST, None) == N.ATMO_E_ARG
+    assert lib.atmo_set_texture(ctx, b"u_cloud_shape_texture", N.TEX_3D_R8, 8, 8, 8, 2, cube.ctypes.data_as(C.c_void_p), N.MEM_HOST, None) == N.ATMO_E_ARG
+    assert lib.atmo_set_sampler_lod(ctx, 2) == N.ATMO_E_ARG
+    lib.atmo_destroy(ctx)
