@@ -103,9 +103,13 @@ struct AtmoContext {
     hipEvent_t tex_event = nullptr;      // recorded after the last texture update on tex_stream
     hipStream_t tex_stream = nullptr;
     bool tex_pending = false;
+    unsigned tex_version = 0;            // bumped by every texture update
+    hipStream_t tex_waited_stream = nullptr;  // the last other stream that was ordered behind tex_event ...
+    unsigned tex_waited_version = 0;          // ... and for which update (one wait per stream and update, not per launch)
     int host_double_precision = 0;  // DOUBLE_PRECISION (main:25,118-125)
     int lane_split = 0;             // 0 = choose per launch by size, 1 = one lane per ray, 2 = two lanes per ray
     int last_split = 1;             // what the most recent launch used (atmo_kernel_name)
+    int last_flags = -1;
     // tile order with cost feedback (atmo_set_tile_feedback): -1 = by variant (clouds_high_rm on), 0 off, 1 on
     int tile_feedback = -1;
     DeviceBuffer tile_cost[2], tile_order[2];          // double-buffered: draw N uses [N & 1]
@@ -305,8 +309,15 @@ int choose_split(const AtmoContext *ctx, const AtmoFrame *f) {
     return ctx->lane_split == 2 ? 2 : 1;
 }
 
-void drain_timing(AtmoContext *ctx) {
+// Reads back finished timing pairs.  only_completed: keep the pairs whose second event has not happened yet
+// (used to bound `pending` without blocking); otherwise wait for every pair.
+void drain_timing(AtmoContext *ctx, bool only_completed = false) {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> keep;
     for (auto &pr : ctx->pending) {
+        if (only_completed && hipEventQuery(pr.second) == hipErrorNotReady) {
+            keep.push_back(pr);
+            continue;
+        }
         if (hipEventSynchronize(pr.second) == hipSuccess) {
             float ms = 0.0f;
             if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
@@ -317,7 +328,7 @@ void drain_timing(AtmoContext *ctx) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
     }
-    ctx->pending.clear();
+    ctx->pending.swap(keep);
 }
 
 }  // namespace
@@ -464,6 +475,18 @@ static int tex_updated(AtmoContext *ctx, hipStream_t s) {
     HIP_TRY(ctx, hipEventRecord(ctx->tex_event, s));
     ctx->tex_stream = s;
     ctx->tex_pending = true;
+    ctx->tex_version += 1;
+    return ATMO_OK;
+}
+
+// Orders stream `s` behind the last texture update when that happened on another stream.  Once per (stream, update):
+// a wait in front of EVERY launch puts a barrier packet between back-to-back draws (+6 us per draw measured).
+static int tex_order(AtmoContext *ctx, hipStream_t s) {
+    if (!ctx->tex_pending || ctx->tex_stream == s) return ATMO_OK;
+    if (ctx->tex_waited_stream == s && ctx->tex_waited_version == ctx->tex_version) return ATMO_OK;
+    HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->tex_event, 0));
+    ctx->tex_waited_stream = s;
+    ctx->tex_waited_version = ctx->tex_version;
     return ATMO_OK;
 }
 
@@ -577,7 +600,7 @@ int atmo_read_texture_layout(AtmoContext *ctx, const char *name, void *out_host,
     if (!b->ptr) return ATMO_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
-    if (ctx->tex_pending && ctx->tex_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->tex_event, 0));
+    { const int rc0 = tex_order(ctx, s); if (rc0 != ATMO_OK) return rc0; }
     HIP_TRY(ctx, hipMemcpyAsync(out_host, b->ptr, b->bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     return ATMO_OK;
@@ -689,7 +712,7 @@ int atmo_read_optical_depth(AtmoContext *ctx, float *lut_host, uint8_t *rgba8_ho
     if (capacity_texels < n) return fail(ctx, ATMO_E_ARG, "atmo_read_optical_depth: buffer too small (atmo_get_texture_size gives w x h)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
-    if (ctx->tex_pending && ctx->tex_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->tex_event, 0));  // a bake on another stream
+    { const int rc0 = tex_order(ctx, s); if (rc0 != ATMO_OK) return rc0; }  // a bake on another stream
     std::vector<float> tmp, padded((size_t)(ctx->lut_w + 2) * (ctx->lut_h + 2));
     float *dst = lut_host;
     if (!dst) { tmp.resize(n); dst = tmp.data(); }
@@ -753,8 +776,16 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         rc.composite = 1;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (ctx->tex_pending && ctx->tex_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->tex_event, 0));  // texture updated on another stream
-    const int split = choose_split(ctx, frame);
+    { const int rc0 = tex_order(ctx, s); if (rc0 != ATMO_OK) return rc0; }  // texture updated on another stream
+    int split = choose_split(ctx, frame);
+    int flags = ctx->flags;
+    if (ctx->sampler_lod && (flags & atmo::KF_CLOUDS) && ctx->cube.ptr && ctx->cube_levels > 1) {
+        // implicit cubemap LOD: needs a mip chain; available for the precise cloud kernels with the reference's LUT light
+        if (!(flags & atmo::KF_PRECISE) || (flags & atmo::KF_LIGHT_DIRECT))
+            return fail(ctx, ATMO_E_STATE, "atmo_render: the implicit cubemap LOD (atmo_set_sampler_lod 1) needs the precise cloud mode and the LUT light mode");
+        flags |= atmo::KF_CUBE_LOD;
+        split = 1;
+    }
     int gx = 0, gy = 0;
     atmo::render_grid(rc, split, &gx, &gy);
     rc.tiles_x = gx;
@@ -795,15 +826,24 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         }
         rc.tile_cost = (uint32_t *)ctx->tile_cost[fbk].ptr;
     }
-    // kernel timing brackets the draw kernel alone (the tile-order kernel in front of it shows in the step time)
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool timed = ctx->timing > 0 && (ctx->launch_counter++ % ctx->timing) == 0;
+    // kernel timing brackets the draw kernel alone (the tile-order kernel runs beside the previous draw).  The event pair
+    // is owned by a guard until it is handed to ctx->pending, so no error path leaks it.
+    struct EventPair {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~EventPair() {
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } ev;
+    const bool timed = ctx->timing > 0 && (ctx->launch_counter % ctx->timing) == 0;
     if (timed) {
-        HIP_TRY(ctx, hipEventCreate(&e0));
-        HIP_TRY(ctx, hipEventCreate(&e1));
-        HIP_TRY(ctx, hipEventRecord(e0, s));
+        if (ctx->pending.size() >= 64) drain_timing(ctx, /*only_completed=*/true);  // a long loop with timing left on stays bounded
+        HIP_TRY(ctx, hipEventCreate(&ev.e0));
+        HIP_TRY(ctx, hipEventCreate(&ev.e1));
+        HIP_TRY(ctx, hipEventRecord(ev.e0, s));
     }
-    HIP_TRY(ctx, atmo::launch_render(ctx->flags, split, rc, s));
+    HIP_TRY(ctx, atmo::launch_render(flags, split, rc, s));
+    ctx->last_flags = flags;
     if (fbk >= 0) {
         // While this draw runs, sort the tiles for the NEXT draw on the side stream, from the costs the PREVIOUS draw
         // left in the other buffer (the sort also clears them for the next draw to write).
@@ -820,9 +860,11 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         ctx->fb_n += 1;
     }
     ctx->last_split = split;
+    ctx->launch_counter += 1;  // counted only once the launch was accepted
     if (timed) {
-        HIP_TRY(ctx, hipEventRecord(e1, s));
-        ctx->pending.emplace_back(e0, e1);
+        HIP_TRY(ctx, hipEventRecord(ev.e1, s));
+        ctx->pending.emplace_back(ev.e0, ev.e1);
+        ev.e0 = ev.e1 = nullptr;  // ownership moved
     }
     return ATMO_OK;
 }
@@ -895,7 +937,7 @@ int atmo_selftest_exact_math(AtmoContext *ctx, uint32_t first_bits, uint32_t cou
 
 const char *atmo_kernel_name(AtmoContext *ctx) {
     if (!ctx) return "";
-    return atmo::render_kernel_name(ctx->flags, ctx->light_steps, ctx->last_split);
+    return atmo::render_kernel_name(ctx->last_flags >= 0 ? ctx->last_flags : ctx->flags, ctx->light_steps, ctx->last_split);
 }
 
 const char *atmo_last_error_string(AtmoContext *ctx) {

@@ -18,6 +18,7 @@ typedef double REAL;
 #define SFX(name) name##_f64
 #define R_SQRT sqrt
 #define R_EXP exp
+#define R_LOG2 log2
 #define R_FLOOR floor
 #define R_FABS fabs
 #else
@@ -25,6 +26,7 @@ typedef float REAL;
 #define SFX(name) name##_f32
 #define R_SQRT sqrtf
 #define R_EXP expf
+#define R_LOG2 log2f
 #define R_FLOOR floorf
 #define R_FABS fabsf
 #endif
@@ -228,14 +230,25 @@ static int cube_select_d(const double *d, double *sc, double *tc, double *ma) {
     *sc = d[2]; *tc = -d[1]; return 1;
 }
 
-static int cube_texel_raw(const OracleTextures *t, int f, int i, int j) {
-    const int n = t->cube_n;
-    return t->cubemap[(f * n + j) * n + i];
+/* one mip level of the cubemap: 6 faces of n^2 texels */
+typedef struct { const uint8_t *faces; int n; } CubeLevel;
+
+static CubeLevel cube_level(const OracleTextures *t, int level) {
+    CubeLevel L;
+    size_t off = 0;
+    for (int l = 0; l < level; ++l) { size_t m = (size_t)(t->cube_n >> l); off += 6 * m * m; }
+    L.faces = t->cubemap + off;
+    L.n = t->cube_n >> level;
+    return L;
+}
+
+static int cube_texel_raw(CubeLevel L, int f, int i, int j) {
+    return L.faces[(f * L.n + j) * L.n + i];
 }
 
 /* Texel across ONE edge: fold (i,j) (exactly one of them is -1 or n) over that edge. */
-static int cube_texel_fold(const OracleTextures *t, int f, int i, int j) {
-    const int n = t->cube_n;
+static int cube_texel_fold(CubeLevel t, int f, int i, int j) {
+    const int n = t.n;
     int ci = clampi(i, 0, n - 1), cj = clampi(j, 0, n - 1);
     /* face-plane coordinates of the clamped texel centre, pushed onto the edge in the folded axis */
     double sc = (i < 0) ? -1.0 : (i >= n) ? 1.0 : (2.0 * (ci + 0.5) / n - 1.0);
@@ -249,8 +262,8 @@ static int cube_texel_fold(const OracleTextures *t, int f, int i, int j) {
 }
 
 /* Seamless texel fetch, (i,j) in [-1, n]; returns byte value (corner: mean of 3 rounded to nearest). */
-static int cube_texel(const OracleTextures *t, int f, int i, int j) {
-    const int n = t->cube_n;
+static int cube_texel(CubeLevel t, int f, int i, int j) {
+    const int n = t.n;
     int oi = (i < 0 || i >= n), oj = (j < 0 || j >= n);
     if (!oi && !oj) return cube_texel_raw(t, f, i, j);
     if (oi && oj) {
@@ -263,34 +276,101 @@ static int cube_texel(const OracleTextures *t, int f, int i, int j) {
     return cube_texel_fold(t, f, i, j);
 }
 
-/* texture(samplerCube, dir).r on an R8 cubemap, LOD 0, bilinear, seamless */
-static REAL sample_cube(const OracleTextures *t, vec3 dir) {
-    if (t->cubemap == NULL) return K(1.0);
-    const int n = t->cube_n;
+/* Vulkan face selection of `dir` (z wins ties over y over x): face, sc, tc, ma = |major component| */
+static int cube_select(vec3 dir, REAL *sc, REAL *tc, REAL *ma) {
     REAL ax = R_FABS(dir.x), ay = R_FABS(dir.y), az = R_FABS(dir.z);
-    REAL sc, tc, ma;
-    int f;
     if (az >= ax && az >= ay) {
-        ma = az;
-        if (dir.z >= K(0.0)) { f = 4; sc = dir.x; tc = -dir.y; } else { f = 5; sc = -dir.x; tc = -dir.y; }
-    } else if (ay >= ax) {
-        ma = ay;
-        if (dir.y >= K(0.0)) { f = 2; sc = dir.x; tc = dir.z; } else { f = 3; sc = dir.x; tc = -dir.z; }
-    } else {
-        ma = ax;
-        if (dir.x >= K(0.0)) { f = 0; sc = -dir.z; tc = -dir.y; } else { f = 1; sc = dir.z; tc = -dir.y; }
+        *ma = az;
+        if (dir.z >= K(0.0)) { *sc = dir.x; *tc = -dir.y; return 4; }
+        *sc = -dir.x; *tc = -dir.y; return 5;
     }
-    REAL s = K(0.5) * (sc / ma + K(1.0));
-    REAL tt = K(0.5) * (tc / ma + K(1.0));
+    if (ay >= ax) {
+        *ma = ay;
+        if (dir.y >= K(0.0)) { *sc = dir.x; *tc = dir.z; return 2; }
+        *sc = dir.x; *tc = -dir.z; return 3;
+    }
+    *ma = ax;
+    if (dir.x >= K(0.0)) { *sc = -dir.z; *tc = -dir.y; return 0; }
+    *sc = dir.z; *tc = -dir.y; return 1;
+}
+
+/* (sc, tc, signed major) of an arbitrary vector in the frame of face f: the linear maps cube_select applies on that face */
+static void cube_face_frame(int f, vec3 v, REAL *sc, REAL *tc, REAL *ma) {
+    switch (f) {
+    case 0: *sc = -v.z; *tc = -v.y; *ma = v.x; break;
+    case 1: *sc = v.z;  *tc = -v.y; *ma = -v.x; break;
+    case 2: *sc = v.x;  *tc = v.z;  *ma = v.y; break;
+    case 3: *sc = v.x;  *tc = -v.z; *ma = -v.y; break;
+    case 4: *sc = v.x;  *tc = -v.y; *ma = v.z; break;
+    default: *sc = -v.x; *tc = -v.y; *ma = -v.z; break;
+    }
+}
+
+/* bilinear, seamless sample of one level at face coordinates (s, tt) in [0,1] */
+static REAL cube_bilinear(CubeLevel L, int f, REAL s, REAL tt) {
+    const int n = L.n;
     REAL x = s * K(n) - K(0.5), y = tt * K(n) - K(0.5);
     REAL xf = R_FLOOR(x), yf = R_FLOOR(y);
     REAL fx = x - xf, fy = y - yf;
     int i0 = clampi((int)xf, -1, n - 1), j0 = clampi((int)yf, -1, n - 1);
-    REAL t00 = K(cube_texel(t, f, i0, j0)) / K(255.0);
-    REAL t10 = K(cube_texel(t, f, i0 + 1, j0)) / K(255.0);
-    REAL t01 = K(cube_texel(t, f, i0, j0 + 1)) / K(255.0);
-    REAL t11 = K(cube_texel(t, f, i0 + 1, j0 + 1)) / K(255.0);
+    REAL t00 = K(cube_texel(L, f, i0, j0)) / K(255.0);
+    REAL t10 = K(cube_texel(L, f, i0 + 1, j0)) / K(255.0);
+    REAL t01 = K(cube_texel(L, f, i0, j0 + 1)) / K(255.0);
+    REAL t11 = K(cube_texel(L, f, i0 + 1, j0 + 1)) / K(255.0);
     return r_mix(r_mix(t00, t10, fx), r_mix(t01, t11, fx), fy);
+}
+
+/* texture(samplerCube, dir).r on an R8 cubemap, LOD 0, bilinear, seamless */
+static REAL sample_cube(const OracleTextures *t, vec3 dir) {
+    if (t->cubemap == NULL) return K(1.0);
+    REAL sc, tc, ma;
+    int f = cube_select(dir, &sc, &tc, &ma);
+    REAL s = K(0.5) * (sc / ma + K(1.0));
+    REAL tt = K(0.5) * (tc / ma + K(1.0));
+    return cube_bilinear(cube_level(t, 0), f, s, tt);
+}
+
+/*
+ * texture(samplerCube, dir).r with the IMPLICIT level of detail of a linear-mipmap sampler (cloud_funcs.gdshaderinc:15,45;
+ * engine behaviour, stated convention of this build -- OracleConfig.cube_lod = 1):
+ *   - derivatives are finite differences inside the 2x2 pixel quad: dir_x / dir_y are the cube directions the horizontal
+ *     / vertical quad neighbour passes to the SAME texture() call (same march step, same light tap); a neighbour that
+ *     does not reach the call (outside the viewport, discarded, cloud gates false) contributes a zero derivative;
+ *   - they are transformed to the face selected by `dir` (Vulkan 1.3, "Cube Map Derivative Transformation"), written in
+ *     the cancellation-free exact form  s' - s = 0.5 (dsc ma - sc dma) / (ma ma'),  d* = neighbour - self in the face frame;
+ *   - rho_x^2 = n^2 (ds_x^2 + dt_x^2), likewise y; lambda = 0.5 log2(max(rho_x^2, rho_y^2)) clamped to [0, levels - 1];
+ *   - the result is mix(level floor(lambda), level floor(lambda) + 1, fract(lambda)), each level sampled bilinear + seamless.
+ */
+static REAL sample_cube_lod(const OracleTextures *t, vec3 dir, const vec3 *nb_dir, const int *nb_valid) {
+    if (t->cubemap == NULL) return K(1.0);
+    const int levels = t->cube_mips > 0 ? t->cube_mips : 1;
+    REAL sc, tc, ma;
+    int f = cube_select(dir, &sc, &tc, &ma);
+    REAL s = K(0.5) * (sc / ma + K(1.0));
+    REAL tt = K(0.5) * (tc / ma + K(1.0));
+    REAL rho2 = K(0.0);
+    for (int a = 0; a < 2; ++a) {
+        if (!nb_valid[a]) continue;
+        vec3 dv = v3_sub(nb_dir[a], dir);
+        REAL dsc, dtc, dma;
+        cube_face_frame(f, dv, &dsc, &dtc, &dma);
+        REAL ma2 = ma + dma;
+        if (!(ma2 > K(0.0))) continue; /* neighbour direction beyond the face's half space: no usable derivative */
+        REAL inv = K(0.5) / (ma * ma2);
+        REAL ds = (dsc * ma - sc * dma) * inv;
+        REAL dt = (dtc * ma - tc * dma) * inv;
+        REAL r2 = (ds * ds + dt * dt) * (K(t->cube_n) * K(t->cube_n));
+        rho2 = r_max(rho2, r2);
+    }
+    REAL lambda = rho2 > K(0.0) ? K(0.5) * R_LOG2(rho2) : K(0.0);
+    lambda = r_clamp(lambda, K(0.0), K(levels - 1));
+    REAL lf = R_FLOOR(lambda);
+    int lo = (int)lf, hi = lo + 1 < levels ? lo + 1 : lo;
+    REAL fr = lambda - lf;
+    REAL v0 = cube_bilinear(cube_level(t, lo), f, s, tt);
+    if (hi == lo || fr == K(0.0)) return v0;
+    REAL v1 = cube_bilinear(cube_level(t, hi), f, s, tt);
+    return r_mix(v0, v1, fr);
 }
 
 /* ---- atmosphere (v2) ------------------------------------------------------------------- */
@@ -429,7 +509,10 @@ typedef struct { REAL bottom_height, top_height, density_scale, ground_height; }
 static REAL height_curve(REAL x) { return K(1.0) - pow2(K(2.0) * x - K(1.0)); }
 
 /* ref: I/cloud_funcs.gdshaderinc:31-68 with CLOUDS_ALWAYS_LOW_QUALITY forced (main:49) => detail = 0.5 */
-static REAL get_density(const Ctx *c, vec3 pos_world, const CloudSettings *s) {
+/* The 2x2-quad neighbours of the shaded pixel for the implicit cubemap LOD: their sample position at the current call */
+typedef struct { int valid[2]; vec3 pos[2]; } QuadNb;
+
+static REAL get_density(const Ctx *c, vec3 pos_world, const CloudSettings *s, const QuadNb *nb) {
     REAL height = v3_length(pos_world) - s->bottom_height;
     REAL height_ratio = height / (s->top_height - s->bottom_height);
     REAL hc = r_max(height_curve(height_ratio), K(0.0));
@@ -437,7 +520,17 @@ static REAL get_density(const Ctx *c, vec3 pos_world, const CloudSettings *s) {
     /* mat2 * vec2, column-major: (m0*x + m2*z, m1*x + m3*z) */
     REAL cx = c->cov_rot[0] * pos_world.x + c->cov_rot[2] * pos_world.z;
     REAL cy = c->cov_rot[1] * pos_world.x + c->cov_rot[3] * pos_world.z;
-    REAL coverage = sample_cube(&c->tex, v3(cx, pos_world.y, cy));
+    REAL coverage;
+    if (nb != NULL && c->cfg.cube_lod) {
+        vec3 nd[2];
+        for (int a = 0; a < 2; ++a) {
+            vec3 q = nb->pos[a];
+            nd[a] = v3(c->cov_rot[0] * q.x + c->cov_rot[2] * q.z, q.y, c->cov_rot[1] * q.x + c->cov_rot[3] * q.z);
+        }
+        coverage = sample_cube_lod(&c->tex, v3(cx, pos_world.y, cy), nd, nb->valid);
+    } else {
+        coverage = sample_cube(&c->tex, v3(cx, pos_world.y, cy));
+    }
     coverage = coverage - K(0.25) * height_ratio + c->cloud_coverage_bias;
 
     REAL shape = r_mix(K(0.5), sample_shape(&c->tex, v3_scale(pos_world, c->cloud_shape_scale)), c->cloud_shape_factor);
@@ -468,7 +561,7 @@ static REAL get_light_cheap(vec3 pos_world, vec3 ray_dir, vec3 sun_dir, REAL alp
 }
 
 /* ref: I/cloud_funcs.gdshaderinc:104-151 */
-static REAL get_light_raymarched(const Ctx *c, vec3 pos0, vec3 sun_dir, const CloudSettings *s) {
+static REAL get_light_raymarched(const Ctx *c, vec3 pos0, vec3 sun_dir, const CloudSettings *s, const QuadNb *nb) {
     const int steps = 6;
     REAL reach = (s->top_height - s->bottom_height) * K(0.15);
     REAL pos0_height = v3_length(pos0) - s->bottom_height;
@@ -478,7 +571,13 @@ static REAL get_light_raymarched(const Ctx *c, vec3 pos0, vec3 sun_dir, const Cl
     REAL alpha = K(0.0);
     for (int i = 0; i < steps; ++i) {
         vec3 pos = v3_add(pos0, v3_scale(sun_dir, K(i) * step_len));
-        REAL density = get_density(c, pos, s); /* both alpha0 branches identical (detail forced low) */
+        QuadNb tap, *tp = NULL;
+        if (nb != NULL) { /* the quad neighbours evaluate the same tap from their own pos0 */
+            tap = *nb;
+            for (int a = 0; a < 2; ++a) tap.pos[a] = v3_add(nb->pos[a], v3_scale(sun_dir, K(i) * step_len));
+            tp = &tap;
+        }
+        REAL density = get_density(c, pos, s, tp); /* both alpha0 branches identical (detail forced low) */
         density *= step_len * s->density_scale;
         REAL transmittance = R_EXP(-density);
         alpha += (K(1.0) - transmittance) * (K(1.0) - alpha);
@@ -489,8 +588,8 @@ static REAL get_light_raymarched(const Ctx *c, vec3 pos0, vec3 sun_dir, const Cl
 }
 
 /* ref: I/cloud_funcs.gdshaderinc:153-167 */
-static REAL get_light(const Ctx *c, vec3 pos, vec3 ray_dir, vec3 sun_dir, REAL alpha, const CloudSettings *s) {
-    REAL light = c->cfg.cloud_light_rm ? get_light_raymarched(c, pos, sun_dir, s)
+static REAL get_light(const Ctx *c, vec3 pos, vec3 ray_dir, vec3 sun_dir, REAL alpha, const CloudSettings *s, const QuadNb *nb) {
+    REAL light = c->cfg.cloud_light_rm ? get_light_raymarched(c, pos, sun_dir, s, nb)
                                        : get_light_cheap(pos, ray_dir, sun_dir, alpha, s);
     REAL shadow_amount = get_planet_shadow(pos, sun_dir);
     light = light * r_mix(K(1.0), K(0.002), shadow_amount);
@@ -498,8 +597,28 @@ static REAL get_light(const Ctx *c, vec3 pos, vec3 ray_dir, vec3 sun_dir, REAL a
 }
 
 /* ref: I/cloud_funcs.gdshaderinc:175-247 */
+/* where a pixel's cloud march starts and how it advances (model space); valid = 0 when the pixel does not march */
+typedef struct { int valid; vec3 pos0, dd; } MarchRay;
+
+static MarchRay cloud_march_ray(const Ctx *c, vec3 ray_origin, vec3 ray_dir, REAL t_begin, REAL t_end, REAL jitter,
+                                const CloudSettings *s) {
+    /* the first lines of raymarch_cloud (clouds:186-213), for a quad neighbour */
+    const int steps = c->cfg.cloud_steps;
+    REAL march_distance_space = K(0.5) * R_SQRT(K(1.0) - pow2(s->ground_height / s->top_height)) * s->bottom_height;
+    REAL march_distance_ground = K(3.0) * march_distance_space;
+    REAL max_d = r_mix(march_distance_ground, march_distance_space,
+                       r_smoothstep(s->bottom_height, s->top_height * K(1.05), v3_length(ray_origin)));
+    t_end = t_begin + r_min(t_end - t_begin, max_d);
+    REAL step_len = (t_end - t_begin) * (K(1.0) / K(steps));
+    MarchRay m;
+    m.valid = 1;
+    m.pos0 = v3_add(v3_add(ray_origin, v3_scale(ray_dir, jitter * step_len)), v3_scale(ray_dir, t_begin));
+    m.dd = v3_scale(ray_dir, step_len);
+    return m;
+}
+
 static vec2 raymarch_cloud(const Ctx *c, vec3 ray_origin, vec3 ray_dir, REAL t_begin, REAL t_end,
-                           REAL jitter, vec3 sun_dir, const CloudSettings *s) {
+                           REAL jitter, vec3 sun_dir, const CloudSettings *s, const MarchRay *nbray) {
     const int steps = c->cfg.cloud_steps;
     REAL march_distance_space = K(0.5) * R_SQRT(K(1.0) - pow2(s->ground_height / s->top_height)) * s->bottom_height;
     REAL march_distance_ground = K(3.0) * march_distance_space;
@@ -517,9 +636,14 @@ static vec2 raymarch_cloud(const Ctx *c, vec3 ray_origin, vec3 ray_dir, REAL t_b
     /* ray_origin + jitter * step_len * ray_dir + ray_dir * t_begin */
     vec3 pos = v3_add(v3_add(ray_origin, v3_scale(ray_dir, jitter * step_len)), v3_scale(ray_dir, t_begin));
 
+    QuadNb nb, *nbp = NULL;
+    if (nbray != NULL && c->cfg.cube_lod) {
+        for (int a = 0; a < 2; ++a) { nb.valid[a] = nbray[a].valid; nb.pos[a] = nbray[a].pos0; }
+        nbp = &nb;
+    }
     for (int i = 0; i < steps; ++i) {
-        REAL light = get_light(c, pos, ray_dir, sun_dir, alpha, s);
-        REAL density = get_density(c, pos, s);
+        REAL light = get_light(c, pos, ray_dir, sun_dir, alpha, s, nbp);
+        REAL density = get_density(c, pos, s, nbp);
         density *= s->density_scale;
         REAL transmittance = R_EXP(-density * step_len);
         total_transmittance *= transmittance;
@@ -527,15 +651,20 @@ static vec2 raymarch_cloud(const Ctx *c, vec3 ray_origin, vec3 ray_dir, REAL t_b
         total_light += light * density * step_len * total_transmittance;
         alpha += (K(1.0) - transmittance) * (K(1.0) - alpha);
         pos = v3_add(pos, v3_scale(ray_dir, step_len));
+        if (nbp != NULL)
+            for (int a = 0; a < 2; ++a) nb.pos[a] = v3_add(nb.pos[a], nbray[a].dd);
     }
     vec2 r = {total_light, alpha};
     return r;
 }
 
 /* ref: I/cloud_funcs.gdshaderinc:249-324 */
-static void render_clouds(const Ctx *c, vec3 *out_albedo, REAL *out_alpha, vec3 planet_center_vs,
-                          vec3 ray_origin, vec3 ray_dir, REAL linear_depth, const REAL *inv_view,
-                          vec3 sun_dir, REAL jitter) {
+/* The part of render_clouds (clouds:249-301) in front of the march: shell hits, the gate, the transform to model space.
+ * Returns 0 when the pixel does not march. */
+typedef struct { vec3 origin, dir, sun; vec2 cloud_rs; CloudSettings cs; } CloudRay;
+
+static int cloud_gate(const Ctx *c, vec3 planet_center_vs, vec3 ray_origin, vec3 ray_dir, REAL linear_depth,
+                      const REAL *inv_view, vec3 sun_dir, CloudRay *out) {
     REAL clouds_bottom = c->planet_radius + c->cloud_bottom * c->atmosphere_height;
     REAL clouds_top = c->planet_radius + c->cloud_top * c->atmosphere_height;
     vec2 rs_top = ray_sphere(planet_center_vs, clouds_top, ray_origin, ray_dir);
@@ -551,34 +680,48 @@ static void render_clouds(const Ctx *c, vec3 *out_albedo, REAL *out_alpha, vec3 
             vec4 d4 = {ray_dir.x, ray_dir.y, ray_dir.z, K(0.0)};
             vec4 s4 = {sun_dir.x, sun_dir.y, sun_dir.z, K(0.0)};
             vec4 ow = m4_mul_v4(m, o4), dw = m4_mul_v4(m, d4), sw = m4_mul_v4(m, s4);
-
-            CloudSettings cs;
-            cs.bottom_height = clouds_bottom;
-            cs.top_height = clouds_top;
-            cs.density_scale = c->cloud_density_scale;
-            cs.ground_height = c->planet_radius;
-
-            vec2 rr = raymarch_cloud(c, v3(ow.x, ow.y, ow.z), v3(dw.x, dw.y, dw.z), cloud_rs.x, cloud_rs.y,
-                                     jitter, v3(sw.x, sw.y, sw.z), &cs);
-            REAL cl = rr.x, ca = rr.y;
-            vec4 self = {out_albedo->x, out_albedo->y, out_albedo->z, *out_alpha};
-            vec4 over = {cl, cl, cl, ca};
-            vec4 ab = blend_colors(self, over);
-            vec4 add = {out_albedo->x + cl * ca, out_albedo->y + cl * ca, out_albedo->z + cl * ca,
-                        r_max(*out_alpha, ca)};
-            out_albedo->x = r_mix(ab.x, add.x, c->cloud_blend);
-            out_albedo->y = r_mix(ab.y, add.y, c->cloud_blend);
-            out_albedo->z = r_mix(ab.z, add.z, c->cloud_blend);
-            *out_alpha = r_mix(ab.w, add.w, c->cloud_blend);
+            out->origin = v3(ow.x, ow.y, ow.z);
+            out->dir = v3(dw.x, dw.y, dw.z);
+            out->sun = v3(sw.x, sw.y, sw.z);
+            out->cloud_rs = cloud_rs;
+            out->cs.bottom_height = clouds_bottom;
+            out->cs.top_height = clouds_top;
+            out->cs.density_scale = c->cloud_density_scale;
+            out->cs.ground_height = c->planet_radius;
+            return 1;
         }
+    }
+    return 0;
+}
+
+/* ref: I/cloud_funcs.gdshaderinc:249-324 */
+static void render_clouds(const Ctx *c, vec3 *out_albedo, REAL *out_alpha, vec3 planet_center_vs,
+                          vec3 ray_origin, vec3 ray_dir, REAL linear_depth, const REAL *inv_view,
+                          vec3 sun_dir, REAL jitter, const MarchRay *nbray) {
+    CloudRay cr;
+    if (cloud_gate(c, planet_center_vs, ray_origin, ray_dir, linear_depth, inv_view, sun_dir, &cr)) {
+        vec2 rr = raymarch_cloud(c, cr.origin, cr.dir, cr.cloud_rs.x, cr.cloud_rs.y, jitter, cr.sun, &cr.cs, nbray);
+        REAL cl = rr.x, ca = rr.y;
+        vec4 self = {out_albedo->x, out_albedo->y, out_albedo->z, *out_alpha};
+        vec4 over = {cl, cl, cl, ca};
+        vec4 ab = blend_colors(self, over);
+        vec4 add = {out_albedo->x + cl * ca, out_albedo->y + cl * ca, out_albedo->z + cl * ca,
+                    r_max(*out_alpha, ca)};
+        out_albedo->x = r_mix(ab.x, add.x, c->cloud_blend);
+        out_albedo->y = r_mix(ab.y, add.y, c->cloud_blend);
+        out_albedo->z = r_mix(ab.z, add.z, c->cloud_blend);
+        *out_alpha = r_mix(ab.w, add.w, c->cloud_blend);
     }
 }
 
 /* ---- fragment driver ------------------------------------------------------------------- */
 
-/* ref: I/planet_atmosphere_main.gdshaderinc:106-197.  Returns 1 if the fragment is kept, 0 on discard. */
-static int atmosphere_fragment(const Ctx *c, const OracleFrame *f, const REAL *inv_p, const REAL *inv_v,
-                               int px, int py, REAL nonlinear_depth, REAL *rgba) {
+/* The per-pixel set-up of atmosphere_fragment (main:128-169): everything in front of compute_atmosphere. */
+typedef struct { int hit; vec3 ray_origin, ray_dir, center, sun_dir; REAL t_begin, t_end, linear_depth, jitter; } FragSetup;
+
+static FragSetup fragment_setup(const Ctx *c, const OracleFrame *f, const REAL *inv_p, const REAL *inv_v,
+                                int px, int py, REAL nonlinear_depth) {
+    FragSetup o;
     REAL vw = K(f->viewport_w), vh = K(f->viewport_h);
     REAL uvx = (K(px) + K(0.5)) / vw, uvy = (K(py) + K(0.5)) / vh;
     vec4 ndc = {uvx * K(2.0) - K(1.0), uvy * K(2.0) - K(1.0), nonlinear_depth, K(1.0)};
@@ -590,39 +733,69 @@ static int atmosphere_fragment(const Ctx *c, const OracleFrame *f, const REAL *i
     vec3 cam_pos_world = v3(cam4.x, cam4.y, cam4.z);
     REAL linear_depth = v3_length(v3_sub(cam_pos_world, pos_world));
 
-    vec3 ray_origin = v3(K(0.0), K(0.0), K(0.0));
-    vec3 ray_dir = v3_normalize(v3_sub(v3(view_coords.x, view_coords.y, view_coords.z), ray_origin));
-
-    vec3 center = v3(f->planet_center_viewspace[0], f->planet_center_viewspace[1], f->planet_center_viewspace[2]);
+    o.ray_origin = v3(K(0.0), K(0.0), K(0.0));
+    o.ray_dir = v3_normalize(v3_sub(v3(view_coords.x, view_coords.y, view_coords.z), o.ray_origin));
+    o.center = v3(f->planet_center_viewspace[0], f->planet_center_viewspace[1], f->planet_center_viewspace[2]);
     vec3 sun_c = v3(f->sun_center_viewspace[0], f->sun_center_viewspace[1], f->sun_center_viewspace[2]);
 
     REAL atmosphere_radius = c->planet_radius + c->atmosphere_height;
-    vec2 rs_atmo = ray_sphere(center, atmosphere_radius, ray_origin, ray_dir);
-
-    if (rs_atmo.x != rs_atmo.y) {
-        REAL t_begin = r_max(rs_atmo.x, K(0.0));
-        REAL t_end = r_max(rs_atmo.y, K(0.0));
-        vec2 rs_ground = ray_sphere(center, c->planet_radius, ray_origin, ray_dir);
+    vec2 rs_atmo = ray_sphere(o.center, atmosphere_radius, o.ray_origin, o.ray_dir);
+    o.hit = rs_atmo.x != rs_atmo.y;
+    o.t_begin = o.t_end = o.jitter = K(0.0);
+    o.linear_depth = linear_depth;
+    o.sun_dir = v3(K(0.0), K(0.0), K(0.0));
+    if (o.hit) {
+        o.t_begin = r_max(rs_atmo.x, K(0.0));
+        o.t_end = r_max(rs_atmo.y, K(0.0));
+        vec2 rs_ground = ray_sphere(o.center, c->planet_radius, o.ray_origin, o.ray_dir);
         REAL gd = K(10000000.0);
         if (rs_ground.x != rs_ground.y) gd = rs_ground.x;
-        linear_depth = r_mix(linear_depth, gd, c->sphere_depth_factor);
-        t_end = r_min(t_end, linear_depth);
-
-        vec3 sun_dir = v3_normalize(v3_sub(sun_c, center));
-
+        o.linear_depth = r_mix(linear_depth, gd, c->sphere_depth_factor);
+        o.t_end = r_min(o.t_end, o.linear_depth);
+        o.sun_dir = v3_normalize(v3_sub(sun_c, o.center));
         REAL jx = vw * uvx, jy = vh * uvy;
         int ji = ((int)jx) & 0xff, jj = ((int)jy) & 0xff;
-        REAL jitter = K(c->tex.blue_noise[jj * 256 + ji]) / K(255.0);
+        o.jitter = K(c->tex.blue_noise[jj * 256 + ji]) / K(255.0);
+    }
+    return o;
+}
 
+/* Where the cloud march of pixel (px, py) starts and how it advances: what a 2x2-quad neighbour contributes to the
+ * implicit cubemap LOD (sample_cube_lod).  valid = 0: outside the viewport, discarded, or the cloud gates are false. */
+static MarchRay pixel_march_ray(const Ctx *c, const OracleFrame *f, const REAL *inv_p, const REAL *inv_v,
+                                int px, int py, const float *depth) {
+    MarchRay m;
+    memset(&m, 0, sizeof(m));
+    if (px < 0 || py < 0 || px >= f->viewport_w || py >= f->viewport_h) return m;
+    FragSetup fs = fragment_setup(c, f, inv_p, inv_v, px, py, K(depth[(size_t)py * f->viewport_w + px]));
+    if (!fs.hit) return m;
+    CloudRay cr;
+    if (!cloud_gate(c, fs.center, fs.ray_origin, fs.ray_dir, fs.linear_depth, inv_v, fs.sun_dir, &cr)) return m;
+    return cloud_march_ray(c, cr.origin, cr.dir, cr.cloud_rs.x, cr.cloud_rs.y, fs.jitter, &cr.cs);
+}
+
+/* ref: I/planet_atmosphere_main.gdshaderinc:106-197.  Returns 1 if the fragment is kept, 0 on discard. */
+static int atmosphere_fragment(const Ctx *c, const OracleFrame *f, const REAL *inv_p, const REAL *inv_v,
+                               int px, int py, const float *depth, REAL *rgba) {
+    FragSetup fs = fragment_setup(c, f, inv_p, inv_v, px, py, K(depth[(size_t)py * f->viewport_w + px]));
+    if (fs.hit) {
         /* main:172-179 */
         vec4 atmosphere = c->cfg.lite
-            ? compute_atmosphere_v1(c, ray_origin, ray_dir, center, t_begin, t_end, sun_dir)
-            : compute_atmosphere_v2(c, ray_origin, ray_dir, center, t_begin, t_end, sun_dir, jitter);
+            ? compute_atmosphere_v1(c, fs.ray_origin, fs.ray_dir, fs.center, fs.t_begin, fs.t_end, fs.sun_dir)
+            : compute_atmosphere_v2(c, fs.ray_origin, fs.ray_dir, fs.center, fs.t_begin, fs.t_end, fs.sun_dir, fs.jitter);
         vec3 albedo = v3(atmosphere.x, atmosphere.y, atmosphere.z);
         REAL alpha = atmosphere.w;
 
-        if (c->cfg.cloud_steps > 0)
-            render_clouds(c, &albedo, &alpha, center, ray_origin, ray_dir, linear_depth, inv_v, sun_dir, jitter);
+        if (c->cfg.cloud_steps > 0) {
+            MarchRay nb[2], *nbp = NULL;
+            if (c->cfg.cube_lod && c->tex.cubemap != NULL && c->tex.cube_mips > 1) {
+                /* the quad partners: (px ^ 1, py) and (px, py ^ 1), absolute viewport coordinates */
+                nb[0] = pixel_march_ray(c, f, inv_p, inv_v, px ^ 1, py, depth);
+                nb[1] = pixel_march_ray(c, f, inv_p, inv_v, px, py ^ 1, depth);
+                nbp = nb;
+            }
+            render_clouds(c, &albedo, &alpha, fs.center, fs.ray_origin, fs.ray_dir, fs.linear_depth, inv_v, fs.sun_dir, fs.jitter, nbp);
+        }
 
         rgba[0] = albedo.x; rgba[1] = albedo.y; rgba[2] = albedo.z; rgba[3] = alpha;
         return 1;
@@ -646,7 +819,6 @@ typedef struct {
 
 static void *render_rows(void *arg) {
     Job *j = (Job *)arg;
-    const int w = j->frame->viewport_w;
     const int rw = j->x1 - j->x0;
     long hits = 0;
     for (;;) {
@@ -654,7 +826,7 @@ static void *render_rows(void *arg) {
         if (y >= j->y1) break;
         for (int x = j->x0; x < j->x1; ++x) {
             REAL *o = j->out + ((size_t)(y - j->y0) * rw + (x - j->x0)) * 4;
-            hits += atmosphere_fragment(j->ctx, j->frame, j->inv_p, j->inv_v, x, y, K(j->depth[(size_t)y * w + x]), o);
+            hits += atmosphere_fragment(j->ctx, j->frame, j->inv_p, j->inv_v, x, y, j->depth, o);
         }
     }
     j->hits = hits;
@@ -862,10 +1034,14 @@ void SFX(oracle_blend_colors)(const REAL *self4, const REAL *over4, REAL *out4) 
 REAL SFX(oracle_sample_lut)(const OracleTextures *t, REAL u, REAL v) { return sample_lut(t, u, v); }
 REAL SFX(oracle_sample_shape)(const OracleTextures *t, const REAL *p) { return sample_shape(t, v3(p[0], p[1], p[2])); }
 REAL SFX(oracle_sample_cube)(const OracleTextures *t, const REAL *d) { return sample_cube(t, v3(d[0], d[1], d[2])); }
-int SFX(oracle_cube_texel)(const OracleTextures *t, int f, int i, int j) { return cube_texel(t, f, i, j); }
+REAL SFX(oracle_sample_cube_lod)(const OracleTextures *t, const REAL *d, const REAL *nb6, const int *valid2) {
+    vec3 nb[2] = {v3(nb6[0], nb6[1], nb6[2]), v3(nb6[3], nb6[4], nb6[5])};
+    return sample_cube_lod(t, v3(d[0], d[1], d[2]), nb, valid2);
+}
+int SFX(oracle_cube_texel)(const OracleTextures *t, int f, int i, int j) { return cube_texel(cube_level(t, 0), f, i, j); }
 
 REAL SFX(oracle_get_cloud_density)(const OracleParams *p, const OracleTextures *t, const REAL *pos_model) {
-    OracleConfig cfg = {8, 8, 0, 0, 0, 0};
+    OracleConfig cfg = {8, 8, 0, 0, 0, 0, 0};
     Ctx c;
     ctx_init(&c, p, t, &cfg);
     CloudSettings cs;
@@ -873,7 +1049,7 @@ REAL SFX(oracle_get_cloud_density)(const OracleParams *p, const OracleTextures *
     cs.top_height = c.planet_radius + c.cloud_top * c.atmosphere_height;
     cs.density_scale = c.cloud_density_scale;
     cs.ground_height = c.planet_radius;
-    return get_density(&c, v3(pos_model[0], pos_model[1], pos_model[2]), &cs);
+    return get_density(&c, v3(pos_model[0], pos_model[1], pos_model[2]), &cs, NULL);
 }
 
 #ifndef ORACLE_F64

@@ -30,7 +30,9 @@
  *     value = mix(mix(t00,t10,fx), mix(t01,t11,fx), fy), mix(a,b,t)=a*(1-t)+b*t.
  *   - blue noise: texelFetch nearest, index & 255, value = byte/255.
  *   - 3-D shape: trilinear, repeat wrap, value = byte/255, mix order x then y then z.
- *   - cubemap: Vulkan face selection, LOD 0 only, bilinear with seamless edges (the texel across
+ *   - cubemap: Vulkan face selection, LOD 0 by default (OracleConfig.cube_lod = 1: implicit LOD of a linear-mipmap
+ *     sampler from finite differences inside the 2x2 pixel quad, rule stated at sample_cube_lod; mips = 2x2 box,
+ *     (a+b+c+d+2)>>2), bilinear with seamless edges (the texel across
  *     an edge is the one reached by folding over that edge; a corner texel is the mean of the three
  *     faces' corner texels), value = byte/255.  Unset cubemap => 1.0 ("cover uniformly", README.md:46).
  *   - pow(dp,16) with dp<=0 => 0 (GLSL-undefined; hardware returns 0 after max(NaN,0)); dp>0 => four squarings.
@@ -81,8 +83,10 @@ typedef struct OracleTextures {
     const uint8_t *blue_noise;    /* u_blue_noise_texture: 256x256 R8 */
     const uint8_t *shape;         /* u_cloud_shape_texture: shape_n^3 R8, x fastest, then y, then z */
     int32_t shape_n;
-    const uint8_t *cubemap;       /* u_cloud_coverage_cubemap: 6 faces (+X,-X,+Y,-Y,+Z,-Z) of cube_n^2 R8; NULL => unset */
+    const uint8_t *cubemap;       /* u_cloud_coverage_cubemap: 6 faces (+X,-X,+Y,-Y,+Z,-Z) of cube_n^2 R8; NULL => unset;
+                                     with cube_mips > 1 the mip levels follow, level l = 6 faces of (cube_n >> l)^2 */
     int32_t cube_n;
+    int32_t cube_mips;            /* levels present in `cubemap` (0 or 1 => level 0 only) */
 } OracleTextures;
 
 /* Per-frame inputs: the arguments of atmosphere_fragment (main:106-117) that are not per pixel. */
@@ -102,6 +106,8 @@ typedef struct OracleConfig {
     int32_t cloud_light_rm;  /* 1 => CLOUDS_RAYMARCHED_LIGHTING */
     int32_t light_steps;     /* 0 => baked LUT (reference); >0 => inline sun-ray march of that many steps */
     int32_t lite;            /* 1 => ATMOSPHERE_LITE: compute_atmosphere of atmosphere_funcs_v1.gdshaderinc */
+    int32_t cube_lod;        /* 0 => cubemap LOD 0 (stated convention of round 1); 1 => implicit LOD from 2x2 pixel quads, see
+                                sample_cube_lod in atmo_oracle.c (needs OracleTextures.cube_mips > 1) */
     int32_t double_precision;/* 1 => DOUBLE_PRECISION (main:25,118-125): the engine hands INV_VIEW_MATRIX with its origin negated */
 } OracleConfig;
 

@@ -55,6 +55,7 @@ class OracleTextures(C.Structure):
         ("shape_n", C.c_int32),
         ("cubemap", C.c_void_p),
         ("cube_n", C.c_int32),
+        ("cube_mips", C.c_int32),
     ]
 
 
@@ -77,6 +78,7 @@ class OracleConfig(C.Structure):
         ("cloud_light_rm", C.c_int32),
         ("light_steps", C.c_int32),
         ("lite", C.c_int32),
+        ("cube_lod", C.c_int32),
         ("double_precision", C.c_int32),
     ]
 
@@ -233,10 +235,19 @@ class Oracle:
             t.shape_n = sh.shape[0]
         cm = textures.get("cubemap")
         if cm is not None:
-            cm = np.ascontiguousarray(cm, dtype=np.uint8)
-            assert cm.ndim == 3 and cm.shape[0] == 6 and cm.shape[1] == cm.shape[2]
-            t.cubemap = ptr(cm)
-            t.cube_n = cm.shape[1]
+            if isinstance(cm, (list, tuple)):  # a mip chain: [(6, n, n), (6, n/2, n/2), ...]
+                levels = [np.ascontiguousarray(v, dtype=np.uint8) for v in cm]
+                assert all(lv.ndim == 3 and lv.shape[0] == 6 and lv.shape[1] == lv.shape[2] for lv in levels)
+                assert all(levels[i + 1].shape[1] == levels[i].shape[1] // 2 for i in range(len(levels) - 1))
+                t.cubemap = ptr(np.concatenate([lv.reshape(-1) for lv in levels]))
+                t.cube_n = levels[0].shape[1]
+                t.cube_mips = len(levels)
+            else:
+                cm = np.ascontiguousarray(cm, dtype=np.uint8)
+                assert cm.ndim == 3 and cm.shape[0] == 6 and cm.shape[1] == cm.shape[2]
+                t.cubemap = ptr(cm)
+                t.cube_n = cm.shape[1]
+                t.cube_mips = 1
         return t, keep
 
     @staticmethod
@@ -257,7 +268,7 @@ class Oracle:
     def make_config(config: dict) -> OracleConfig:
         return OracleConfig(int(config["view_steps"]), int(config.get("cloud_steps", 0)),
                             int(config.get("cloud_light_rm", 0)), int(config.get("light_steps", 0)),
-                            int(config.get("lite", 0)), int(config.get("double_precision", 0)))
+                            int(config.get("lite", 0)), int(config.get("cube_lod", 0)), int(config.get("double_precision", 0)))
 
     # ---- entry points --------------------------------------------------------------------
     def render(self, params: dict, textures: dict, config: dict, frame: dict, depth: np.ndarray,
@@ -346,6 +357,28 @@ class Oracle:
         sc = (C.c_float * 3)(*[float(v) for v in scale])
         self.lib.oracle_noise_cubemap(resolution, seed, frequency, octaves, gain, sc, out.ctypes.data_as(C.c_void_p))
         return out
+
+    @staticmethod
+    def cubemap_mip_chain(faces, levels=None):
+        """The mip chain Image.generate_mipmaps builds for an L8 cubemap (noise_cubemap.gd:107,135): level l+1 = 2x2 box of
+        level l, (a + b + c + d + 2) >> 2 (engine arithmetic; stated convention).  Returns [level0, level1, ...]."""
+        chain = [np.ascontiguousarray(faces, dtype=np.uint8)]
+        while chain[-1].shape[1] > 1 and (levels is None or len(chain) < levels):
+            p = chain[-1].astype(np.int32)
+            m = p.shape[1] // 2
+            box = (p[:, 0:2 * m:2, 0:2 * m:2] + p[:, 0:2 * m:2, 1:2 * m:2] + p[:, 1:2 * m:2, 0:2 * m:2] + p[:, 1:2 * m:2, 1:2 * m:2] + 2) >> 2
+            chain.append(box.astype(np.uint8))
+        return chain
+
+    def sample_cube_lod(self, chain, d, d_x=None, d_y=None):
+        """sample_cube_lod for one direction and its quad neighbours' directions (None = no neighbour)."""
+        t, keep = self.make_textures({"cubemap": chain})
+        nb = (self.real * 6)(*([float(v) for v in (d_x if d_x is not None else (0, 0, 0))] + [float(v) for v in (d_y if d_y is not None else (0, 0, 0))]))
+        valid = (C.c_int * 2)(int(d_x is not None), int(d_y is not None))
+        fn = getattr(self.lib, "oracle_sample_cube_lod" + self.sfx)
+        fn.restype = self.real
+        fn.argtypes = [C.POINTER(OracleTextures), C.POINTER(self.real), C.POINTER(self.real), C.POINTER(C.c_int)]
+        return float(fn(C.byref(t), self._vec(d), nb, valid))
 
     def noise_cubemap_atlas(self, faces):
         faces = np.ascontiguousarray(faces, dtype=np.uint8)

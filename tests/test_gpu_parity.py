@@ -996,3 +996,60 @@ def test_device_texture_layouts_equal_the_host_layouts():
     assert lib.atmo_set_texture(ctx, b"u_cloud_shape_texture", N.TEX_3D_R8, 8, 8, 8, 2, cube.ctypes.data_as(C.c_void_p), N.MEM_HOST, None) == N.ATMO_E_ARG
     assert lib.atmo_set_sampler_lod(ctx, 2) == N.ATMO_E_ARG
     lib.atmo_destroy(ctx)
+
+
+# ---- implicit cubemap LOD (atmo_set_sampler_lod) ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("config_name", ["clouds", "clouds_high", "clouds_high_rm", "v1_clouds_high"])
+def test_parity_implicit_cubemap_lod(oracle32, config_name):
+    """The linear-mipmap sampler of cloud_funcs.gdshaderinc:15,45: the device generates the mip chain (2x2 box) and
+    samples with the implicit LOD of the 2x2 pixel quad; the oracle restates the same rule (sample_cube_lod).  Small
+    viewports on purpose: neighbouring rays are several texels apart there, lambda reaches 3-5.  Also: rect renders
+    with odd origins split quads across the rect border and still equal the crop of the full frame, bit for bit."""
+    tex, params = demo_textures(), demo_params()
+    chain = oracle32.cubemap_mip_chain(tex["cubemap"])
+    worst, changed = 0.0, 0.0
+    for (w, h), pose in (((256, 144), "P_space"), ((160, 90), "P_clouds"), ((97, 61), "P_limb")):
+        cam = S.Camera.from_pose(w, h, pose)
+        depth = S.depth_ground_sphere(cam)
+        node = make_node(config_name, tex, params, cubemap_lod=True)
+        got = _gpu_render(node, cam, depth)
+        assert node.kernel_name.startswith("atmo_render_kernel<") and int(node.kernel_name.split("<")[1].split(",")[0]) & 32
+        lut = node.read_optical_depth() if _uses_lut(config_name) else None
+        want, _ = oracle32.render(params, dict(tex, cubemap=chain, optical_depth=lut), dict(CONFIGS[config_name][1], cube_lod=1),
+                                  demo_frame(cam), depth, nthreads=8)
+        assert np.array_equal(np.all(got == 0.0, axis=-1), np.all(want == 0.0, axis=-1))
+        worst = max(worst, float(np.abs(got - want).max()))
+        rect = (3, 5, w - 9, h - 4)
+        assert np.array_equal(_gpu_render(node, cam, depth, rect=rect), got[5:h - 4, 3:w - 9])
+        node.close()
+        base = make_node(config_name, tex, params)
+        lod0 = _gpu_render(base, cam, depth)
+        base.close()
+        changed = max(changed, float(np.abs(got - lod0).max()))
+    print(f"\n{config_name} implicit LOD: max |HIP - oracle| = {worst:.3e}; max |LOD - LOD0| = {changed:.3e}")
+    assert worst <= TOL
+    assert changed > 1e-3   # the mode does change the picture at these pixel footprints
+
+
+def test_implicit_lod_needs_a_chain_and_the_precise_lut_kernels(oracle32):
+    """Without mip levels the LOD mode is the LOD-0 sampler; with the fast cloud mode or the direct light mode it is
+    refused (ATMO_E_STATE) instead of silently sampling level 0."""
+    from godot_atmosphere_shader_amd import _native as N
+
+    tex, params = demo_textures(cube_n=64, shape_n=16), demo_params()
+    w, h = 128, 72
+    cam = S.Camera.from_pose(w, h, "P_space")
+    depth = S.depth_ground_sphere(cam)
+    a = make_node("clouds_high", tex, params)
+    b = make_node("clouds_high", dict(tex, cubemap=[tex["cubemap"]]), params, cubemap_lod=True)   # explicit single level
+    assert np.array_equal(_gpu_render(a, cam, depth), _gpu_render(b, cam, depth))
+    assert b.kernel_name.startswith("atmo_render_kernel<17,")
+    a.close()
+    b.close()
+    for kw in (dict(precise_clouds=False), dict(light_mode="direct", light_steps=4)):
+        node = make_node("clouds_high", tex, params, cubemap_lod=True, **kw)
+        with pytest.raises(N.AtmoError) as e:
+            _gpu_render(node, cam, depth)
+        assert e.value.code == N.ATMO_E_STATE
+        node.close()
