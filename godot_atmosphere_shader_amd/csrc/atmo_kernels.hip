@@ -870,6 +870,110 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
 }
 
 // ---- atmosphere_fragment ---------------------------------------------------------------------------
+// ---- raymarch_cloud with raymarched light, lit samples regrouped through LDS (ATMO_RM_QUEUE) -------------------------------
+// In clouds_high_rm only the samples with density > 0 need get_light_raymarched (6 more density evaluations each), and in a
+// lock-step march they are a changing subset of the wave: 21 % of the issued lanes idle (VALUUtilization 78.7 %,
+// profiles/round2/pmc_clouds_high_rm_1920x1080.json).  The light value does not feed back into the march -- it only scales
+// the sample's contribution to total_light -- so a wave can queue its lit samples and evaluate them later, a full wave at a time:
+//   phase A, every step: position chain, density, transmittance recurrence; a lit lane stores w = shadow * density * step *
+//     total_transmittance in its slot[step][lane] and appends (position, height ratio, slot) to the wave's ring queue in LDS
+//     (ballot + mbcnt give the lane its place; the fill count lives in an SGPR);
+//   phase B, whenever the queue holds one entry per marching lane (and at the end of a 16-step chunk): lane r takes entry r,
+//     evaluates the 6-tap light for THAT sample and multiplies it into the slot;
+//   phase C, end of the chunk: every lane adds its slots in step order.
+// Per ray the arithmetic is fixed (own slots, step order), so the picture does not depend on which rays share a wave.
+// LDS per wave: 5 x 128 queue words + 16 x 64 slots = 6.5 KB (26 KB per workgroup).
+#ifndef ATMO_RM_QUEUE
+#define ATMO_RM_QUEUE 1
+#endif
+constexpr int RMQ_CHUNK = 16, RMQ_CAP = 128;
+constexpr int RMQ_WORDS_PER_WAVE = 5 * RMQ_CAP + RMQ_CHUNK * 64;
+
+template <bool PRECISE>
+__device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, V3 dir_m, float t_begin, float t_end, float jitter,
+                                                        float *__restrict__ lds) {
+    float *qx = lds, *qy = lds + RMQ_CAP, *qz = lds + 2 * RMQ_CAP, *qh = lds + 3 * RMQ_CAP;
+    uint32_t *qs = reinterpret_cast<uint32_t *>(lds + 4 * RMQ_CAP);
+    float *slot = lds + 5 * RMQ_CAP;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long active = __builtin_amdgcn_ballot_w64(true);  // the lanes of this wave that march
+    auto rank_in = [&](unsigned long long m) {
+        return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    };
+    const int rank = rank_in(active);
+    const int batch = __builtin_popcountll(active);
+    int qhead = 0, qcount = 0;  // wave-uniform (SGPRs): entries [qhead, qcount) are waiting, indices modulo RMQ_CAP
+
+    const int steps = rc.cloud_steps;
+    const MarchRay self = cloud_march_ray(rc, dir_m, t_begin, t_end, jitter);
+    const float step_len = self.step_len;
+    float px = self.px, py = self.py, pz = self.pz;
+    const float ddx = self.ddx, ddy = self.ddy, ddz = self.ddz;
+    const float sx = rc.sun_dir_model[0], sy = rc.sun_dir_model[1], sz = rc.sun_dir_model[2];
+    float total_transmittance = 1.0f, total_light = 0.0f, one_minus_alpha = 1.0f;
+    const float scale_step = rc.cloud_density_scale * step_len;
+    const float neg_scale_step_log2e = -scale_step * LOG2E;
+
+    auto light_batch = [&](int avail) {  // phase B: lane `rank` lights queue entry qhead + rank
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (rank < avail) {
+            const int e = (qhead + rank) & (RMQ_CAP - 1);
+            const float ex = qx[e], ey = qy[e], ez = qz[e], eh = qh[e];
+            const uint32_t sl = qs[e];
+            const float light = light_raymarched<PRECISE>(rc, ex, ey, ez, eh, sx, sy, sz);
+            slot[sl] = light * slot[sl];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+
+    for (int c0 = 0; c0 < steps; c0 += RMQ_CHUNK) {
+        const int cn = steps - c0 < RMQ_CHUNK ? steps - c0 : RMQ_CHUNK;
+        uint32_t lit_bits = 0;
+        for (int k = 0; k < cn; ++k) {
+            float r, hr;
+            cloud_height(rc, px, py, pz, r, hr);
+            const float density = cloud_density<true, PRECISE>(rc, px, py, pz, hr);
+            const bool lit = density > 0.0f;
+            float w = 0.0f;
+            if (lit) {
+#pragma clang fp contract(fast)
+                // get_planet_shadow: smoothstep(-0.3, 0.3, dot(normalize(pos), -sun_dir))
+                const float sd = -(px * sx + py * sy + pz * sz) * hw_rcp(r);
+                const float st = sat((sd + 0.3f) * (1.0f / 0.6f));
+                const float shadow = st * st * (3.0f - 2.0f * st);
+                const float lb = fmaf(shadow, 0.002f - 1.0f, 1.0f);
+                const float transmittance = hw_exp2(density * neg_scale_step_log2e);
+                total_transmittance = fmaxf(total_transmittance * transmittance, 0.005f);
+                one_minus_alpha *= transmittance;
+                w = (lb * (density * scale_step)) * total_transmittance;
+            }
+            const unsigned long long lm = __builtin_amdgcn_ballot_w64(lit);
+            if (lit) {
+                const int e = (qcount + rank_in(lm)) & (RMQ_CAP - 1);
+                const uint32_t sl = (uint32_t)(k * 64 + lane);
+                qx[e] = px; qy[e] = py; qz[e] = pz; qh[e] = hr;
+                qs[e] = sl;
+                slot[sl] = w;
+                lit_bits |= 1u << k;
+            }
+            qcount += __builtin_popcountll(lm);
+            // exact: pos += ray_dir * step_len
+            px = px + ddx; py = py + ddy; pz = pz + ddz;
+            // a full batch is waiting -- or the chunk ends and its slots are read next: drain (one partial batch at most)
+            const bool last = k == cn - 1;
+            while (qcount - qhead >= batch || (last && qcount > qhead)) {  // single call site: one copy of the 6-tap block
+                const int avail = qcount - qhead < batch ? qcount - qhead : batch;
+                light_batch(avail);
+                qhead += avail;
+            }
+        }
+        for (int k = 0; k < cn; ++k)  // phase C, step order
+            if ((lit_bits >> k) & 1u) total_light += slot[k * 64 + lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    return make_float2(total_light, 1.0f - one_minus_alpha);
+}
+
 // The per-pixel set-up of atmosphere_fragment (main:128-169), exact: ray, shell hit, march interval, depth, jitter.
 struct PixelRay {
     bool hit;
@@ -1053,7 +1157,13 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
                     nbray[0] = pixel_march_ray(rc, px ^ 1, py);
                     nbray[1] = pixel_march_ray(rc, px, py ^ 1);
                 }
-                const float2 rr = march_clouds<RM, PRECISE, SPLIT, LOD>(rc, dir_m, c0, c1, jitter, half, nbray);
+                float2 rr;
+                if constexpr (RM && !LOD && SPLIT == 1 && ATMO_RM_QUEUE != 0) {
+                    __shared__ float rmq[(TILE_W * TILE_H / 64) * RMQ_WORDS_PER_WAVE];
+                    rr = march_clouds_rm_queue<PRECISE>(rc, dir_m, c0, c1, jitter, rmq + wave * RMQ_WORDS_PER_WAVE);
+                } else {
+                    rr = march_clouds<RM, PRECISE, SPLIT, LOD>(rc, dir_m, c0, c1, jitter, half, nbray);
+                }
                 {
 #pragma clang fp contract(fast)
                     const float cl = rr.x, ca = rr.y;
@@ -1109,13 +1219,18 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
 // SGPR cap: 256-thread workgroups are admitted 8 per CU only up to 80 SGPRs (81-96 => 7, although the occupancy API and
 // the compiler's "Occupancy" line still say 8: MI355X_MICROARCH.md "Residency").  The atmosphere-only kernels sat at 82
 // after RenderConsts grew, which cost the direct-light kernel 7 %; the cap makes hipcc keep a few uniforms in VGPRs instead.
+#ifdef ATMO_MIN_WAVES  // __launch_bounds__ second argument: minimum waves per SIMD the register allocation must allow
+#define ATMO_MIN_WAVES_ARG , ATMO_MIN_WAVES
+#else
+#define ATMO_MIN_WAVES_ARG
+#endif
 #ifdef ATMO_SGPR_CAP
 #define ATMO_SGPR_ATTR __attribute__((amdgpu_num_sgpr(ATMO_SGPR_CAP)))
 #else
 #define ATMO_SGPR_ATTR
 #endif
 template <int FLAGS, int LSTEPS, int SPLIT = 1>
-__global__ __launch_bounds__(TILE_W *TILE_H) ATMO_SGPR_ATTR void atmo_render_kernel(const RenderConsts rc) {
+__global__ __launch_bounds__(TILE_W *TILE_H ATMO_MIN_WAVES_ARG) ATMO_SGPR_ATTR void atmo_render_kernel(const RenderConsts rc) {
     // Keep this preamble exactly as it is for every variant.  Measured on the direct-light kernel (same loop ISA in all
     // three builds, profiles/round2/ab_direct_kernel.txt): this form 0.108-0.109 ms; a branch on tile_order in front of
     // the division (which serialises the prologue's scalar loads behind an early s_waitcnt) 0.115 ms; NO preamble at all
