@@ -81,6 +81,12 @@ constexpr int TILE_H = ATMO_TILE_H;
 #ifndef ATMO_CHORD_MAX
 #define ATMO_CHORD_MAX 1
 #endif
+#ifndef ATMO_CUBE_FLOAT_INDEX
+#define ATMO_CUBE_FLOAT_INDEX 1
+#endif
+#ifndef ATMO_LUT_FLOAT_INDEX
+#define ATMO_LUT_FLOAT_INDEX 1
+#endif
 // 1: texture gathers as buffer loads (SRSRC + 32-bit offset) instead of flat 64-bit addresses
 #ifndef ATMO_BUFFER_LOADS
 #define ATMO_BUFFER_LOADS 1
@@ -210,7 +216,14 @@ __device__ __forceinline__ float lut_sample_xy(const float *__restrict__ lut, in
 #if ATMO_BUFFER_LOADS && !ATMO_ABLATE_FETCH
     {
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(lut, (uint32_t)(stride * rows) * 4u);
+#if ATMO_LUT_FLOAT_INDEX
+        // byte offset ((yf + 1) * stride + xf + 1) * 4 formed in fp32 (exact: < 2^24) with two fast-class FMAs and one
+        // conversion, instead of two conversions + integer multiply-add + shift (all slow class)
+        const float s4 = (float)(stride * 4);
+        const uint32_t off = (uint32_t)fmaf(yf, s4, fmaf(xf, 4.0f, s4 + 4.0f));
+#else
         const uint32_t off = (uint32_t)(((int)yf + 1) * stride + ((int)xf + 1)) * 4u;
+#endif
         const f32x2 r0 = buf_f32x2(rs, off), r1 = buf_f32x2(rs, off + (uint32_t)stride * 4u);
         const float a = r0.x + (r0.y - r0.x) * fx;
         const float b = r1.x + (r1.y - r1.x) * fx;
@@ -334,8 +347,24 @@ __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, in
     const float y = fmaf(qt + 1.0f, hn, -0.5f);
     const float xf = floorf(x), yf = floorf(y);
     const float fx = x - xf, fy = y - yf;
-    const int i = min(max((int)xf, -1), n - 1) + 1, j = min(max((int)yf, -1), n - 1) + 1;
     const int stride = n + 1;
+#if ATMO_CUBE_FLOAT_INDEX && ATMO_BUFFER_LOADS && !ATMO_ABLATE_FETCH
+    if (n <= 1024) {
+        // byte offset ((face * stride + j) * stride + i) * 4, i = clamp(xf, -1, n-1) + 1, formed in fp32 (exact below 2^24:
+        // 6 (n+1)^2 * 4 < 2^24 up to n = 1024): 2 med3 + 3 FMA + 1 conversion instead of 3 conversions, 4 integer
+        // min/max, a 64-bit multiply-add, a multiply, an add and a shift-add
+        const float nm1 = (float)(n - 1), s4 = (float)(stride * 4);
+        const float ic = __builtin_amdgcn_fmed3f(xf, -1.0f, nm1), jc = __builtin_amdgcn_fmed3f(yf, -1.0f, nm1);
+        const uint32_t off = (uint32_t)fmaf(fid, s4 * (float)stride, fmaf(jc, s4, fmaf(ic, 4.0f, s4 + 4.0f)));
+        const uint32_t w = buf_u32(make_rsrc(fp, (uint32_t)(6 * stride * stride) * 4u), off);
+        if (PRECISE || ATMO_CUBE_EXACT) return bilinear_unorm8_exact(w, fx, fy);
+        const float t00 = ub0(w), t10 = ub1(w), t01 = ub2(w), t11 = ub3(w);
+        const float a = t00 + (t10 - t00) * fx;
+        const float b = t01 + (t11 - t01) * fx;
+        return (a + (b - a) * fy) * (1.0f / 255.0f);
+    }
+#endif
+    const int i = min(max((int)xf, -1), n - 1) + 1, j = min(max((int)yf, -1), n - 1) + 1;
 #if ATMO_ABLATE_FETCH
     const uint32_t w = (uint32_t)(((int)fid * stride + j) * stride + i) * 2654435761u;
 #else
