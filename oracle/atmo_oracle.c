@@ -1,6 +1,6 @@
 /*
  * atmo_oracle.c -- scalar CPU restatement of the reference's per-pixel atmosphere/cloud raymarch.
- * TEST INFRASTRUCTURE ONLY (see atmo_oracle.h).  PARITY UNPINNED (reference ships no tests).
+ * TEST INFRASTRUCTURE ONLY (see atmo_oracle.h).  Pinned to the executed reference text by tests/test_reference_exec.py (see atmo_oracle.h).
  *
  * Evaluation order follows the GDShader source statement by statement; build with
  * -ffp-contract=off so nothing is fused.  "ref:" comments cite /root/reference/addons/

@@ -5,12 +5,19 @@
  * link, import or execute anything in oracle/.  Only tests/, __graft_entry__.smoke() and the
  * cpu_baseline leg of bench.py use it, and only as the checker / reported baseline.
  *
- * PARITY UNPINNED: the reference is GDShader (Godot's GLSL dialect) and ships no tests, golden
- * vectors or fixtures; neither Godot nor a GLSL compiler exists in this image, so the reference
- * itself cannot be executed.  This restatement is pinned only by (i) analytic known-answer tests
- * derived from the reference's formulas (tests/test_oracle_kat.py), (ii) its own fp64 twin
- * (same source compiled with -DORACLE_F64), (iii) golden frames it generated at the reference's
- * demo-scene parameters (tests/golden/).
+ * PARITY PINNED TO THE REFERENCE'S SHADER TEXT, EXECUTED (round 2): the reference is GDShader (Godot's GLSL dialect)
+ * and ships no tests, golden vectors or fixtures; neither Godot nor a GLSL compiler exists in this image.  The shader
+ * source itself is therefore run by an interpreter of the shading language (tests/golden/gdshader_vm.py, fed the files
+ * under /root/reference at generation time by tests/golden/make_reference_vectors.py); its outputs -- 70 frames over all
+ * seven planet_atmosphere_*.gdshader variants, two scenes, five poses, the DOUBLE_PRECISION switch, the vertex-stage
+ * varyings and the full 256x256 optical_depth.gdshader bake -- are committed as tests/golden/reference_exec.npz.
+ * tests/test_reference_exec.py holds this restatement to them: LUT and varyings bit for bit, pixels within 5e-7
+ * (measured 2.4e-7 = 1-2 ulp: glibc expf and the four-squarings pow vs correctly rounded).  What stays a STATED
+ * CONVENTION, not pinned by anything the reference holds, is engine / hardware behaviour: texture filtering and LOD,
+ * source_color conversion, SCREEN_UV rounding, transcendental accuracy (list below), and the NoiseCubemap's noise
+ * function (Godot's FastNoiseLite, not in the reference tree).
+ * Also checked by: analytic known-answer tests (tests/test_oracle_kat.py), its own fp64 twin (same source compiled with
+ * -DORACLE_F64), a separate numpy restatement (tests/numpy_restatement.py), golden frames at the demo-scene parameters.
  *
  * Reference files restated (all under /root/reference/addons/zylann.atmosphere/shaders/):
  *   include/planet_atmosphere_main.gdshaderinc:106-197   atmosphere_fragment

@@ -1,7 +1,7 @@
 """ctypes loader for the CPU oracle (oracle/atmo_oracle.c).
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
-leg -- never by anything under godot_atmosphere_shader_amd/.  PARITY UNPINNED (see atmo_oracle.h).
+leg -- never by anything under godot_atmosphere_shader_amd/.  Pinned to the executed reference shader text by tests/test_reference_exec.py (see atmo_oracle.h).
 
 The wrapper is deliberately free of any import from the product package: scenes are handed over as
 plain dicts / numpy arrays (see `render`).

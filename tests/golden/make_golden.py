@@ -2,8 +2,9 @@
 """Generates tests/golden/*.npz: small frames rendered by the fp32 CPU oracle at the reference's demo-scene
 parameters (addons/zylann.atmosphere/demo/planet_atmosphere_test.tscn:96-114).
 
-The reference ships no golden vectors and cannot be executed here (GDShader; no Godot), so these fixtures
-pin the oracle against itself over time (regression) and give the GPU tests committed expected outputs.
+The reference ships no golden vectors; the vectors produced by EXECUTING its shader text live next door
+(make_reference_vectors.py -> reference_exec.npz).  These larger frames pin the oracle against itself over time
+(regression) and give the GPU tests committed expected outputs.
 They are data: inputs are regenerated from seeds (texture CRCs are stored to detect generator drift),
 expected outputs are the stored RGBA arrays.
 

@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/reference_exec.npz: outputs of the REFERENCE'S OWN SHADER SOURCE executed here.
+
+The reference (GDShader) ships no tests and neither Godot nor a GLSL compiler exists in this image, so this script runs
+the shader text itself: tests/golden/gdshader_vm.py interprets the files under
+/root/reference/addons/zylann.atmosphere/shaders/ (read at generation time only -- nothing of them is stored) with IEEE
+binary32 arithmetic, the engine's texture units supplied by tests/golden/vm_textures.py under the conventions stated in
+DESIGN.md section 2.  The committed .npz holds inputs (scene parameters, matrices, depth buffers; textures are
+regenerated from seeds and pinned by CRC) and the expected outputs (RGBA per pixel, the baked optical-depth LUT, the
+vertex-stage varyings).  tests/test_reference_exec.py checks the CPU oracle against them (-m "not gpu") and the HIP path
+through the C ABI (-m gpu).
+
+    python tests/golden/make_reference_vectors.py            # needs /root/reference; about a minute
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import gdshader_vm as VM  # noqa: E402
+import vm_textures as T  # noqa: E402
+from godot_atmosphere_shader_amd import scene as S  # noqa: E402
+from reference_scenes import CUBE_N, H, POSES, SHAPE_N, VARIANTS, W, scenes  # noqa: E402
+from oracle.oracle import Oracle  # noqa: E402
+
+SHADERS = "/root/reference/addons/zylann.atmosphere/shaders"
+F32 = np.float32
+
+def uniforms_for(parser, params, world_to_model):
+    """Host values for the uniforms the shader declares (those the scene does not set keep the shader's defaults)."""
+    out = {}
+    for name in parser.uniforms:
+        if name == "u_world_to_model_matrix":
+            out[name] = S.col_major(world_to_model)
+        elif name == "u_sun_position":
+            out[name] = S.DEMO_SUN_POSITION
+        elif name in params:
+            out[name] = params[name]
+    return out
+
+
+def run_bake(params):
+    """optical_depth.gdshader fragment() for every texel of the 256 x 256 target, then what the baker does with it:
+    RGBA8 viewport -> bytes reinterpreted as R32F (optical_depth_baker.gd)."""
+    n = 256
+    p = VM.load(os.path.join(SHADERS, "optical_depth.gdshader"))
+    m = VM.Machine(p, n * n, {}, {k: params[k] for k in ("u_planet_radius", "u_atmosphere_height", "u_density")})
+    ii, jj = np.meshgrid(np.arange(n), np.arange(n))
+    uv = np.stack([(ii.reshape(-1).astype(F32) + F32(0.5)) / F32(n), (jj.reshape(-1).astype(F32) + F32(0.5)) / F32(n)])
+    m.globals["UV"] = VM.V("vec2", uv.astype(F32))
+    m.globals["COLOR"] = m.zero("vec4")
+    m.run("fragment")
+    color = m.globals["COLOR"].a  # (4, lanes) floats k / 255
+    # the RGBA8 render target stores round(c * 255)
+    b = np.rint(color.astype(np.float64) * 255.0).astype(np.uint32)
+    bits = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24)
+    return bits.astype(np.uint32).view(F32).reshape(n, n), m.calls
+
+
+def run_frame(shader, defines, params, world_to_model, model_matrix, cam, depth, tex_units, time_s=0.0):
+    p = VM.load(os.path.join(SHADERS, shader + ".gdshader"), defines)
+    n = cam.width * cam.height
+    samplers = dict(tex_units, u_depth_texture=T.DepthTexture(depth))
+    m = VM.Machine(p, n, samplers, uniforms_for(p, params, world_to_model), source_color=S.srgb_to_linear)
+    g = m.globals
+    ident = m.from_host("mat4", np.eye(4).reshape(-1))
+    # vertex stage: the quad's vertices all produce the same varyings, one lane is enough
+    g["VERTEX"] = m.zero("vec3")
+    g["POSITION"] = m.zero("vec4")
+    g["PROJECTION_MATRIX"] = ident
+    g["MODELVIEW_MATRIX"] = ident
+    g["MODEL_MATRIX"] = m.from_host("mat4", S.col_major(model_matrix))
+    g["VIEW_MATRIX"] = m.from_host("mat4", S.col_major(cam.view))
+    g["TIME"] = m.from_host("float", [time_s])
+    m.run("vertex")
+    varyings = (g["v_planet_center_viewspace"].a[:, 0].copy(), g["v_sun_center_viewspace"].a[:, 0].copy())
+    # fragment stage, one lane per pixel
+    px, py = np.meshgrid(np.arange(cam.width), np.arange(cam.height))
+    uv = np.stack([(px.reshape(-1).astype(F32) + F32(0.5)) / F32(cam.width),
+                   (py.reshape(-1).astype(F32) + F32(0.5)) / F32(cam.height)])
+    g["SCREEN_UV"] = VM.V("vec2", uv.astype(F32))
+    g["VIEWPORT_SIZE"] = m.from_host("vec2", [cam.width, cam.height])
+    g["INV_PROJECTION_MATRIX"] = m.from_host("mat4", S.col_major(cam.inv_projection))
+    g["INV_VIEW_MATRIX"] = m.from_host("mat4", S.col_major(cam.inv_view))
+    g["ALBEDO"] = m.zero("vec3")
+    g["ALPHA"] = m.zero("float")
+    m.run("fragment")
+    rgb = np.broadcast_to(g["ALBEDO"].a, (3, n))
+    a = np.broadcast_to(g["ALPHA"].a, (n,))
+    out = np.concatenate([rgb, a[None, :]], axis=0).T.reshape(cam.height, cam.width, 4).astype(F32).copy()
+    disc = m.discarded.reshape(cam.height, cam.width)
+    out[disc] = 0.0  # a discarded fragment leaves the (cleared) target untouched
+    return out, disc, varyings, m.calls
+
+
+def main():
+    t0 = time.time()
+    o = Oracle("f32")
+    blue = S.make_blue_noise()
+    shape = S.make_shape_texture(SHAPE_N)
+    cube = S.make_coverage_cubemap(CUBE_N)
+    padded = T.pad_cubemap(cube, lambda f, i, j: o.cube_texel(cube, f, i, j))
+    out = {
+        "viewport": np.array([W, H]), "shape_n": np.int64(SHAPE_N), "cube_n": np.int64(CUBE_N),
+        "crc_blue_noise": np.uint32(S.checksum(blue)), "crc_shape": np.uint32(S.checksum(shape)),
+        "crc_cubemap": np.uint32(S.checksum(cube)),
+        "poses": np.array(POSES), "variants": np.array(list(VARIANTS)), "scenes": np.array(list(scenes())),
+    }
+    calls = {}
+    for sname, (params, model_matrix) in scenes().items():
+        world_to_model = np.linalg.inv(model_matrix)
+        lut, c = run_bake(params)
+        calls.update(c)
+        out[f"lut_{sname}"] = lut
+        out[f"model_matrix_{sname}"] = model_matrix
+        units = dict(u_optical_depth_texture=T.LutTexture(lut), u_blue_noise_texture=T.ByteTexture2D(blue),
+                     u_cloud_shape_texture=T.ShapeTexture(shape), u_cloud_coverage_cubemap=T.CubeTexture(padded))
+        for pose in POSES:
+            cam = S.Camera.from_pose(W, H, pose)
+            if sname == "alt":  # the planet of the second scene is not at the origin
+                depth = S.depth_ground_sphere(cam, center_world=model_matrix[:3, 3], radius=params["u_planet_radius"])
+            else:
+                depth = S.depth_ground_sphere(cam)
+            out[f"depth_{sname}_{pose}"] = depth
+            for shader in VARIANTS:
+                rgba, disc, vary, c = run_frame(shader, None, params, world_to_model, model_matrix, cam, depth, units)
+                calls.update(c)
+                key = f"{sname}_{pose}_{shader}"
+                out[f"rgba_{key}"] = rgba
+                out[f"discard_{key}"] = np.packbits(disc)
+                out[f"planet_vs_{sname}_{pose}"], out[f"sun_vs_{sname}_{pose}"] = vary
+                print(f"{time.time() - t0:6.1f}s {key}: {int((~disc).sum())} of {disc.size} fragments kept, "
+                      f"max rgba {rgba.max():.4f}", flush=True)
+    # the DOUBLE_PRECISION compile switch (planet_atmosphere_main.gdshaderinc:25,118-125), one frame
+    params, model_matrix = scenes()["demo"]
+    cam = S.Camera.from_pose(W, H, "P_limb")
+    units = dict(u_optical_depth_texture=T.LutTexture(out["lut_demo"]), u_blue_noise_texture=T.ByteTexture2D(blue),
+                 u_cloud_shape_texture=T.ShapeTexture(shape), u_cloud_coverage_cubemap=T.CubeTexture(padded))
+    neg = S.Camera.from_pose(W, H, "P_limb")
+    neg.inv_view = cam.inv_view.copy()
+    neg.inv_view[:3, 3] *= -1.0  # what a double-precision engine build hands the shader
+    rgba, disc, _, _ = run_frame("planet_atmosphere_clouds", {"DOUBLE_PRECISION": ""}, params, np.eye(4), model_matrix, neg,
+                                 out["depth_demo_P_limb"], units)
+    out["rgba_double_precision_P_limb_planet_atmosphere_clouds"] = rgba
+    out["called_functions"] = np.array(sorted(calls))
+    path = os.path.join(HERE, "reference_exec.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", "functions executed:", ", ".join(sorted(calls)))
+
+
+if __name__ == "__main__":
+    main()

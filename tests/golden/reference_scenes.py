@@ -1,0 +1,38 @@
+"""The scenes tests/golden/reference_exec.npz was generated for (shared by make_reference_vectors.py, which needs the
+reference tree, and tests/test_reference_exec.py, which does not)."""
+import numpy as np
+
+from godot_atmosphere_shader_amd.demo import demo_params
+
+W, H = 48, 27
+SHAPE_N, CUBE_N = 32, 64
+
+# reference shader file -> the step-count configuration it #defines (the checker's config dict)
+VARIANTS = {
+    "planet_atmosphere_no_clouds": dict(view_steps=8),
+    "planet_atmosphere_clouds": dict(view_steps=8, cloud_steps=32),
+    "planet_atmosphere_clouds_high": dict(view_steps=8, cloud_steps=64),
+    "planet_atmosphere_clouds_high_rm": dict(view_steps=8, cloud_steps=64, cloud_light_rm=1),
+    "planet_atmosphere_v1_no_clouds": dict(view_steps=16, lite=1),
+    "planet_atmosphere_v1_clouds": dict(view_steps=16, lite=1, cloud_steps=32),
+    "planet_atmosphere_v1_clouds_high": dict(view_steps=16, lite=1, cloud_steps=64),
+}
+POSES = ["P_space", "P_ground", "P_limb", "P_clouds", "P_night"]
+
+# parameter sets: the demo scene, and a second scene that takes the branches the demo leaves alone
+ALT_MODEL = np.array([[0.96, 0.0, 0.28, 0.0], [0.0, 1.0, 0.0, 0.0], [-0.28, 0.0, 0.96, 0.0], [1.5, -2.0, 0.75, 1.0]],
+                     dtype=np.float64)  # column-major rows below are COLUMNS: rotation about y + translation
+
+
+def scenes():
+    demo = demo_params()
+    alt = demo_params(u_cloud_shape_invert=0.0, u_sphere_depth_factor=0.35, u_cloud_blend=0.2, u_cloud_coverage_bias=0.08,
+                      u_cloud_density_scale=35.0, u_cloud_shape_factor=0.6, u_cloud_shape_scale=0.37, u_density=0.17,
+                      u_scattering_strength=14.0, u_scattering_wavelengths=(680.0, 550.0, 450.0),
+                      u_atmosphere_modulate=(0.9, 1.0, 0.8), u_atmosphere_ambient_color=(0.01, 0.0, 0.02),
+                      u_cloud_bottom=0.25, u_cloud_top=0.6, u_day_night_transition_scale=1.4,
+                      u_day_color0=(0.3, 0.7, 1.0, 1.0), u_day_color1=(0.9, 0.6, 0.3, 1.0),
+                      u_night_color0=(0.02, 0.05, 0.3, 1.0), u_night_color1=(0.1, 0.0, 0.2, 1.0))
+    return {"demo": (demo, np.eye(4)), "alt": (alt, ALT_MODEL.T.copy())}
+
+

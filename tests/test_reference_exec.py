@@ -1,0 +1,300 @@
+"""Parity against the REFERENCE ITSELF, executed: tests/golden/reference_exec.npz holds the outputs of the reference's own
+shader source (all seven planet_atmosphere_*.gdshader variants and optical_depth.gdshader) run by the GDShader interpreter of
+tests/golden/gdshader_vm.py in this container, where /root/reference exists (tests/golden/make_reference_vectors.py).
+
+  -m "not gpu":  the CPU oracle against those vectors (this is what pins oracle/atmo_oracle.c to something outside this
+                 repo's reading of the shader), the host mirror of atmosphere_vertex, the interpreter's own unit tests, and --
+                 only where /root/reference is present -- a re-execution of a sample of the vectors.
+  -m gpu:        the HIP path through the C ABI against the same vectors, tolerance BASELINE.json's 1e-4; LUT bake bit-exact.
+
+Nothing here reads /root/reference on the GPU box.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from common import TOL, make_node
+from godot_atmosphere_shader_amd import scene as S
+from godot_atmosphere_shader_amd.planet_atmosphere import atmosphere_vertex, make_frame
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, GOLDEN)
+
+import gdshader_vm as VM  # noqa: E402
+import reference_scenes as RS  # noqa: E402
+
+# the oracle follows the reference statement by statement; what is left is expf (glibc vs correctly rounded) and
+# pow(x, 16) (four squarings vs correctly rounded): 2 ulp of the largest channel values (~3)
+ORACLE_TOL = 5e-7
+
+# reference shader file -> (CONFIGS name of the product binding, which uses the same file)
+NODE_CONFIG = {
+    "planet_atmosphere_no_clouds": "no_clouds_8", "planet_atmosphere_clouds": "clouds",
+    "planet_atmosphere_clouds_high": "clouds_high", "planet_atmosphere_clouds_high_rm": "clouds_high_rm",
+    "planet_atmosphere_v1_no_clouds": "v1_no_clouds", "planet_atmosphere_v1_clouds": "v1_clouds",
+    "planet_atmosphere_v1_clouds_high": "v1_clouds_high",
+}
+
+
+@pytest.fixture(scope="module")
+def vectors():
+    z = np.load(os.path.join(GOLDEN, "reference_exec.npz"))
+    assert list(z["variants"]) == list(RS.VARIANTS) and list(z["poses"]) == RS.POSES and list(z["scenes"]) == list(RS.scenes())
+    assert tuple(z["viewport"]) == (RS.W, RS.H)
+    return z
+
+
+@pytest.fixture(scope="module")
+def textures(vectors):
+    tex = dict(blue_noise=S.make_blue_noise(), shape=S.make_shape_texture(RS.SHAPE_N), cubemap=S.make_coverage_cubemap(RS.CUBE_N))
+    # the vectors were produced with exactly these texels
+    assert S.checksum(tex["blue_noise"]) == int(vectors["crc_blue_noise"])
+    assert S.checksum(tex["shape"]) == int(vectors["crc_shape"])
+    assert S.checksum(tex["cubemap"]) == int(vectors["crc_cubemap"])
+    return tex
+
+
+def _scene(sname):
+    params, model = RS.scenes()[sname]
+    return dict(params, u_world_to_model_matrix=S.col_major(np.linalg.inv(model))), model
+
+
+# ------------------------------------------------------------------------------------------------- CPU: oracle vs reference
+def test_reference_vectors_cover_the_path(vectors):
+    """Every function of the hot path was executed from the reference text when the vectors were made."""
+    called = set(vectors["called_functions"])
+    for fn in ("atmosphere_vertex", "atmosphere_fragment", "ray_sphere", "compute_atmosphere_v2", "get_baked_optical_depth",
+               "get_atmosphere_density", "compute_atmosphere", "get_atmo_factor", "render_clouds", "raymarch_cloud",
+               "get_density_full", "get_density", "get_density_low", "height_curve", "get_light", "get_light_cheap",
+               "get_light_raymarched", "get_planet_shadow", "blend_colors", "get_optical_depth", "encode_float_to_viewport",
+               "pow2", "pow4"):
+        assert fn in called, fn
+
+
+@pytest.mark.parametrize("sname", list(RS.scenes()))
+def test_oracle_bake_equals_reference_bake(oracle32, vectors, sname):
+    """optical_depth.gdshader executed for all 256 x 256 texels, through the RGBA8 viewport packing: bit for bit."""
+    params, _ = _scene(sname)
+    lut = oracle32.bake_optical_depth(params["u_planet_radius"], params["u_atmosphere_height"], params["u_density"])
+    ref = vectors[f"lut_{sname}"]
+    assert ref.shape == (256, 256) and np.isfinite(ref).all() and ref.max() > 0
+    assert np.array_equal(lut.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("pose", RS.POSES)
+@pytest.mark.parametrize("sname", list(RS.scenes()))
+def test_host_vertex_stage_equals_reference(vectors, sname, pose):
+    """atmosphere_vertex (planet_atmosphere_main.gdshaderinc:66-104) runs on the host in this build: same varyings, bit for bit."""
+    _, model = _scene(sname)
+    cam = S.Camera.from_pose(RS.W, RS.H, pose)
+    planet, sun = atmosphere_vertex(cam.view, model, S.DEMO_SUN_POSITION)
+    assert np.array_equal(np.asarray(planet, dtype=np.float32), vectors[f"planet_vs_{sname}_{pose}"])
+    assert np.array_equal(np.asarray(sun, dtype=np.float32), vectors[f"sun_vs_{sname}_{pose}"])
+
+
+@pytest.mark.parametrize("shader", list(RS.VARIANTS))
+@pytest.mark.parametrize("pose", RS.POSES)
+@pytest.mark.parametrize("sname", list(RS.scenes()))
+def test_oracle_equals_reference_fragment(oracle32, vectors, textures, sname, pose, shader):
+    params, model = _scene(sname)
+    cam = S.Camera.from_pose(RS.W, RS.H, pose)
+    frame = make_frame(cam, model, S.DEMO_SUN_POSITION, 0.0)
+    depth = vectors[f"depth_{sname}_{pose}"]
+    got, hits = oracle32.render(params, dict(textures, optical_depth=vectors[f"lut_{sname}"]), RS.VARIANTS[shader], frame, depth,
+                                nthreads=4)
+    want = vectors[f"rgba_{sname}_{pose}_{shader}"]
+    discarded = np.unpackbits(vectors[f"discard_{sname}_{pose}_{shader}"])[:RS.W * RS.H].reshape(RS.H, RS.W).astype(bool)
+    assert hits == int((~discarded).sum())
+    assert np.all(got[discarded] == 0.0)
+    err = np.abs(got - want).max()
+    assert err <= ORACLE_TOL, f"{sname}/{pose}/{shader}: oracle vs executed reference {err:.3e}"
+
+
+def test_oracle_equals_reference_double_precision_switch(oracle32, vectors, textures):
+    """#define DOUBLE_PRECISION (planet_atmosphere_main.gdshaderinc:25,118-125) executed from the reference text with the
+    negated camera origin a double-precision engine hands over; the oracle's switch undoes it the same way."""
+    params, model = _scene("demo")
+    cam = S.Camera.from_pose(RS.W, RS.H, "P_limb")
+    frame = make_frame(cam, model, S.DEMO_SUN_POSITION, 0.0)
+    inv_view = np.array(frame["inv_view_matrix"], dtype=np.float64).copy()
+    inv_view[12:15] *= -1.0
+    frame = dict(frame, inv_view_matrix=inv_view)
+    cfg = dict(RS.VARIANTS["planet_atmosphere_clouds"], double_precision=1)
+    got, _ = oracle32.render(params, dict(textures, optical_depth=vectors["lut_demo"]), cfg, frame, vectors["depth_demo_P_limb"])
+    want = vectors["rgba_double_precision_P_limb_planet_atmosphere_clouds"]
+    assert np.abs(got - want).max() <= ORACLE_TOL
+    # and the switch matters: without it the negated origin gives a different picture
+    plain, _ = oracle32.render(params, dict(textures, optical_depth=vectors["lut_demo"]), RS.VARIANTS["planet_atmosphere_clouds"],
+                               frame, vectors["depth_demo_P_limb"])
+    assert np.abs(plain - want).max() > 1e-3
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/addons/zylann.atmosphere/shaders"), reason="needs the reference tree")
+def test_vectors_reproduce_from_the_reference_tree(vectors, textures, oracle32):
+    """Where the reference is present (the build container), re-execute a sample of the vectors from its source."""
+    import make_reference_vectors as G
+    import vm_textures as T
+
+    lut, _ = G.run_bake(RS.scenes()["alt"][0])
+    assert np.array_equal(lut.view(np.uint32), vectors["lut_alt"].view(np.uint32))
+    params, model = RS.scenes()["alt"]
+    cube = textures["cubemap"]
+    padded = T.pad_cubemap(cube, lambda f, i, j: oracle32.cube_texel(cube, f, i, j))
+    units = dict(u_optical_depth_texture=T.LutTexture(lut), u_blue_noise_texture=T.ByteTexture2D(textures["blue_noise"]),
+                 u_cloud_shape_texture=T.ShapeTexture(textures["shape"]), u_cloud_coverage_cubemap=T.CubeTexture(padded))
+    cam = S.Camera.from_pose(RS.W, RS.H, "P_clouds")
+    rgba, _, _, _ = G.run_frame("planet_atmosphere_clouds_high_rm", None, params, np.linalg.inv(model), model, cam,
+                                vectors["depth_alt_P_clouds"], units)
+    assert np.array_equal(rgba, vectors["rgba_alt_P_clouds_planet_atmosphere_clouds_high_rm"])
+
+
+# ------------------------------------------------------------------------------------------------ the interpreter's own tests
+def _run(tmp_path, text, lanes, inputs, entry="main", uniforms=None):
+    path = tmp_path / "t.gdshader"
+    path.write_text(text)
+    m = VM.Machine(VM.load(str(path)), lanes, {}, uniforms or {})
+    for k, (ty, val) in inputs.items():
+        m.globals[k] = m.from_host(ty, val)
+    m.run(entry)
+    return m
+
+
+def test_vm_divergent_control_flow_and_early_return(tmp_path):
+    src = """
+    float pick(float x) {
+        if (x < 0.0) {
+            return -1.0;
+        }
+        float y = x * 2.0;
+        if (y > 4.0) { return 4.0; } else { y += 0.5; }
+        return y;
+    }
+    void main() { OUT = pick(IN); }
+    """
+    x = np.array([-3.0, 0.25, 1.0, 2.5, 9.0], dtype=np.float32)
+    m = _run(tmp_path, src, 5, {"IN": ("float", x), "OUT": ("float", np.zeros(5))})
+    assert np.array_equal(m.globals["OUT"].a, np.array([-1.0, 1.0, 2.5, 4.0, 4.0], dtype=np.float32))
+
+
+def test_vm_out_params_swizzles_loops_and_structs(tmp_path):
+    src = """
+    struct S { float a; vec2 b; };
+    void split(vec3 v, out float lo, inout vec2 acc) {
+        lo = min(min(v.x, v.y), v.z);
+        acc.y += v.z;
+        acc.x = acc.x * 2.0;
+    }
+    void main() {
+        S s;
+        s.a = 1.5;
+        s.b = vec2(IN.x, 1.0);
+        float lo;
+        vec2 acc = vec2(1.0, 2.0);
+        for (int i = 0; i < 3; ++i) {
+            if (IN.y > 0.0) {
+                split(IN * float(i), lo, acc);
+            }
+        }
+        OUT = vec4(lo, acc, s.a + s.b.x);
+        OUT.zw = OUT.wz;
+    }
+    """
+    v = np.array([[1.0, 2.0], [1.0, -1.0], [3.0, 4.0]], dtype=np.float32)  # two lanes; lane 1 skips the call
+    m = _run(tmp_path, src, 2, {"IN": ("vec3", v), "OUT": ("vec4", np.zeros((4, 2)))})
+    out = m.globals["OUT"].a
+    # lane 0: i = 0,1,2 -> lo = min(v * 2) = 2 ; acc.x = 1 * 8 ; acc.y = 2 + 0 + 3 + 6
+    assert out[:, 0].tolist() == [2.0, 8.0, 2.5, 11.0]
+    assert out[:, 1].tolist() == [0.0, 1.0, 3.5, 2.0]
+
+
+def test_vm_float32_arithmetic_and_matrix_order(tmp_path):
+    src = """
+    uniform mat4 M;
+    void main() {
+        vec4 r = M * IN;
+        OUT = r;
+        float big = 16777216.0;
+        F = (big + 1.0) - big;          // 0 in binary32, 1 in binary64
+        G = normalize(vec3(3.0, 0.0, 4.0)).x;
+        U = float((floatBitsToUint(1.0) >> 23u) & 255u);
+        I = float(ivec2(vec2(-2.7, 260.9)).y & 0xff);
+    }
+    """
+    mat = np.arange(16, dtype=np.float32) * np.float32(0.1)  # flat column-major
+    v = np.array([[1.0], [2.0], [3.0], [4.0]], dtype=np.float32)
+    m = _run(tmp_path, src, 1, {"IN": ("vec4", v), "OUT": ("vec4", np.zeros((4, 1))), "F": ("float", [0]), "G": ("float", [0]),
+                                "U": ("float", [0]), "I": ("float", [0])}, uniforms={"M": mat})
+    cols = mat.reshape(4, 4)
+    want = ((cols[0] * v[0, 0] + cols[1] * v[1, 0]) + cols[2] * v[2, 0]) + cols[3] * v[3, 0]  # left to right, float32
+    assert np.array_equal(m.globals["OUT"].a[:, 0], want.astype(np.float32))
+    assert m.globals["F"].a[0] == 0.0
+    assert m.globals["G"].a[0] == np.float32(3.0) * (np.float32(1.0) / np.sqrt(np.float32(25.0)))
+    assert m.globals["U"].a[0] == 127.0 and m.globals["I"].a[0] == 4.0
+
+
+def test_vm_preprocessor(tmp_path):
+    (tmp_path / "inc.gdshaderinc").write_text("#ifndef G\n#define G\nfloat twice(float x) { return x * 2.0; }\n#endif\n")
+    src = """
+    #define STEPS 3
+    #include "inc.gdshaderinc"
+    #include "inc.gdshaderinc"
+    #ifdef NOPE
+    float f() { return 1.0; }
+    #else
+    float f() { return float(STEPS); } // comment
+    #endif
+    /* block
+       comment */
+    void main() { OUT = twice(f()); }
+    """
+    m = _run(tmp_path, src, 1, {"OUT": ("float", [0])})
+    assert m.globals["OUT"].a[0] == 6.0
+
+
+def test_vm_rejects_what_it_does_not_model(tmp_path):
+    with pytest.raises(VM.ShaderError):
+        _run(tmp_path, "void main() { while (true) { } }", 1, {})
+    with pytest.raises(VM.ShaderError):
+        _run(tmp_path, "void main() { float x = 1; vec3 v = vec3(1.0) + vec2(1.0); }", 1, {})
+
+
+# ------------------------------------------------------------------------------------------------------ GPU: HIP vs reference
+def _gpu_render(node, cam, depth_np):
+    import torch as _t
+    out = node.render(cam, _t.from_numpy(np.ascontiguousarray(depth_np)).cuda())
+    _t.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sname", list(RS.scenes()))
+def test_hip_bake_equals_reference_bake(vectors, textures, sname):
+    params, _ = _scene(sname)
+    node = make_node("no_clouds_8", textures, params)
+    lut = node.read_optical_depth()
+    node.close()
+    assert np.array_equal(lut.view(np.uint32), vectors[f"lut_{sname}"].view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shader", list(RS.VARIANTS))
+@pytest.mark.parametrize("sname", list(RS.scenes()))
+def test_hip_equals_reference_fragment(vectors, textures, sname, shader):
+    """The product path (PlanetAtmosphere node -> C ABI -> gfx950 kernels) against the executed reference, all poses."""
+    params, model = _scene(sname)
+    node = make_node(NODE_CONFIG[shader], textures, params)
+    node.global_transform = model
+    worst = 0.0
+    for pose in RS.POSES:
+        cam = S.Camera.from_pose(RS.W, RS.H, pose)
+        node._process(0.0, cam, time=0.0)
+        node.set_shader_parameter("u_cloud_coverage_rotation", np.asarray(params["u_cloud_coverage_rotation"], dtype=np.float32))
+        got = _gpu_render(node, cam, vectors[f"depth_{sname}_{pose}"])
+        want = vectors[f"rgba_{sname}_{pose}_{shader}"]
+        discarded = np.unpackbits(vectors[f"discard_{sname}_{pose}_{shader}"])[:RS.W * RS.H].reshape(RS.H, RS.W).astype(bool)
+        assert np.all(got[discarded] == 0.0), f"{pose}: a fragment the reference discards was shaded"
+        worst = max(worst, float(np.abs(got - want).max()))
+    node.close()
+    assert worst <= TOL, f"{sname}/{shader}: HIP vs executed reference {worst:.3e}"
