@@ -26,7 +26,8 @@ sys.path.insert(0, HERE)
 import gdshader_vm as VM  # noqa: E402
 import vm_textures as T  # noqa: E402
 from godot_atmosphere_shader_amd import scene as S  # noqa: E402
-from reference_scenes import CUBE_N, H, POSES, SHAPE_N, VARIANTS, W, scenes  # noqa: E402
+from reference_scenes import CUBE_N, FULL_SIZE, H, POSES, SHAPE_N, VARIANTS, W, camera_matrices, scenes  # noqa: E402
+from godot_atmosphere_shader_amd.demo import demo_textures  # noqa: E402
 from oracle.oracle import Oracle  # noqa: E402
 
 SHADERS = "/root/reference/addons/zylann.atmosphere/shaders"
@@ -63,9 +64,11 @@ def run_bake(params):
     return bits.astype(np.uint32).view(F32).reshape(n, n), m.calls
 
 
-def run_frame(shader, defines, params, world_to_model, model_matrix, cam, depth, tex_units, time_s=0.0):
+def run_frame(shader, defines, params, world_to_model, model_matrix, cam, depth, tex_units, time_s=0.0, rows=None):
+    """vertex() once, fragment() for every pixel of the viewport (or of the given rows)."""
     p = VM.load(os.path.join(SHADERS, shader + ".gdshader"), defines)
-    n = cam.width * cam.height
+    rows = list(range(cam.height)) if rows is None else list(rows)
+    n = cam.width * len(rows)
     samplers = dict(tex_units, u_depth_texture=T.DepthTexture(depth))
     m = VM.Machine(p, n, samplers, uniforms_for(p, params, world_to_model), source_color=S.srgb_to_linear)
     g = m.globals
@@ -81,7 +84,7 @@ def run_frame(shader, defines, params, world_to_model, model_matrix, cam, depth,
     m.run("vertex")
     varyings = (g["v_planet_center_viewspace"].a[:, 0].copy(), g["v_sun_center_viewspace"].a[:, 0].copy())
     # fragment stage, one lane per pixel
-    px, py = np.meshgrid(np.arange(cam.width), np.arange(cam.height))
+    px, py = np.meshgrid(np.arange(cam.width), np.asarray(rows))
     uv = np.stack([(px.reshape(-1).astype(F32) + F32(0.5)) / F32(cam.width),
                    (py.reshape(-1).astype(F32) + F32(0.5)) / F32(cam.height)])
     g["SCREEN_UV"] = VM.V("vec2", uv.astype(F32))
@@ -93,8 +96,8 @@ def run_frame(shader, defines, params, world_to_model, model_matrix, cam, depth,
     m.run("fragment")
     rgb = np.broadcast_to(g["ALBEDO"].a, (3, n))
     a = np.broadcast_to(g["ALPHA"].a, (n,))
-    out = np.concatenate([rgb, a[None, :]], axis=0).T.reshape(cam.height, cam.width, 4).astype(F32).copy()
-    disc = m.discarded.reshape(cam.height, cam.width)
+    out = np.concatenate([rgb, a[None, :]], axis=0).T.reshape(len(rows), cam.width, 4).astype(F32).copy()
+    disc = m.discarded.reshape(len(rows), cam.width)
     out[disc] = 0.0  # a discarded fragment leaves the (cleared) target untouched
     return out, disc, varyings, m.calls
 
@@ -123,6 +126,7 @@ def main():
                      u_cloud_shape_texture=T.ShapeTexture(shape), u_cloud_coverage_cubemap=T.CubeTexture(padded))
         for pose in POSES:
             cam = S.Camera.from_pose(W, H, pose)
+            out[f"cam_{W}x{H}_{pose}"] = camera_matrices(cam)
             if sname == "alt":  # the planet of the second scene is not at the origin
                 depth = S.depth_ground_sphere(cam, center_world=model_matrix[:3, 3], radius=params["u_planet_radius"])
             else:
@@ -148,6 +152,20 @@ def main():
     rgba, disc, _, _ = run_frame("planet_atmosphere_clouds", {"DOUBLE_PRECISION": ""}, params, np.eye(4), model_matrix, neg,
                                  out["depth_demo_P_limb"], units)
     out["rgba_double_precision_P_limb_planet_atmosphere_clouds"] = rgba
+    # BASELINE.json sizes (configs[2], configs[3]), whole rows, the bench's textures
+    big = demo_textures()
+    out["crc_shape_full"], out["crc_cubemap_full"] = np.uint32(S.checksum(big["shape"])), np.uint32(S.checksum(big["cubemap"]))
+    padded_big = T.pad_cubemap(big["cubemap"], lambda f, i, j: o.cube_texel(big["cubemap"], f, i, j))
+    units = dict(u_optical_depth_texture=T.LutTexture(out["lut_demo"]), u_blue_noise_texture=T.ByteTexture2D(blue),
+                 u_cloud_shape_texture=T.ShapeTexture(big["shape"]), u_cloud_coverage_cubemap=T.CubeTexture(padded_big))
+    for shader, w, h, pose, rows in FULL_SIZE:
+        cam = S.Camera.from_pose(w, h, pose)
+        out[f"cam_{w}x{h}_{pose}"] = camera_matrices(cam)
+        depth = S.depth_ground_sphere(cam)
+        rgba, disc, _, _ = run_frame(shader, None, params, np.eye(4), model_matrix, cam, depth, units, rows=rows)
+        key = f"full_{w}x{h}_{pose}_{shader}"
+        out[f"rgba_{key}"], out[f"rows_{key}"], out[f"depth_{key}"] = rgba, np.asarray(rows), depth[list(rows)]
+        print(f"{time.time() - t0:6.1f}s {key}: rows {rows}, {int((~disc).sum())} of {disc.size} fragments kept", flush=True)
     out["called_functions"] = np.array(sorted(calls))
     path = os.path.join(HERE, "reference_exec.npz")
     np.savez_compressed(path, **out)

@@ -2,6 +2,7 @@
 reference tree, and tests/test_reference_exec.py, which does not)."""
 import numpy as np
 
+from godot_atmosphere_shader_amd import scene as S
 from godot_atmosphere_shader_amd.demo import demo_params
 
 W, H = 48, 27
@@ -36,3 +37,26 @@ def scenes():
     return {"demo": (demo, np.eye(4)), "alt": (alt, ALT_MODEL.T.copy())}
 
 
+
+
+# BASELINE.json sizes: (reference shader file, viewport, pose, rows executed).  configs[2] = clouds_high 1920x1080,
+# configs[3] = clouds_high_rm 3840x2160; whole rows spread over the frame incl. the limb rows of P_space.
+FULL_SIZE = [
+    ("planet_atmosphere_no_clouds", 1920, 1080, "P_space", (40, 330, 539, 1000)),
+    ("planet_atmosphere_clouds_high", 1920, 1080, "P_space", (40, 200, 400, 539, 540, 700, 900, 1040)),
+    ("planet_atmosphere_clouds_high", 1920, 1080, "P_clouds", (0, 300, 539, 800, 1079)),
+    ("planet_atmosphere_clouds_high_rm", 3840, 2160, "P_space", (80, 400, 800, 1079, 1400, 1800, 2080)),
+    ("planet_atmosphere_clouds_high_rm", 3840, 2160, "P_clouds", (0, 600, 1079, 1600, 2159)),
+]
+
+
+def camera_matrices(cam):
+    """What a fixture stores of a camera (numpy's 4x4 inverse may differ in the last bit between hosts)."""
+    return np.stack([cam.inv_projection, cam.inv_view, cam.view]).astype(np.float64)
+
+
+def camera_from_fixture(z, w, h, pose):
+    cam = S.Camera.from_pose(w, h, pose)
+    m = z[f"cam_{w}x{h}_{pose}"]
+    cam.inv_projection, cam.inv_view, cam.view = m[0].copy(), m[1].copy(), m[2].copy()
+    return cam

@@ -88,7 +88,7 @@ def test_oracle_bake_equals_reference_bake(oracle32, vectors, sname):
 def test_host_vertex_stage_equals_reference(vectors, sname, pose):
     """atmosphere_vertex (planet_atmosphere_main.gdshaderinc:66-104) runs on the host in this build: same varyings, bit for bit."""
     _, model = _scene(sname)
-    cam = S.Camera.from_pose(RS.W, RS.H, pose)
+    cam = RS.camera_from_fixture(vectors, RS.W, RS.H, pose)
     planet, sun = atmosphere_vertex(cam.view, model, S.DEMO_SUN_POSITION)
     assert np.array_equal(np.asarray(planet, dtype=np.float32), vectors[f"planet_vs_{sname}_{pose}"])
     assert np.array_equal(np.asarray(sun, dtype=np.float32), vectors[f"sun_vs_{sname}_{pose}"])
@@ -99,7 +99,7 @@ def test_host_vertex_stage_equals_reference(vectors, sname, pose):
 @pytest.mark.parametrize("sname", list(RS.scenes()))
 def test_oracle_equals_reference_fragment(oracle32, vectors, textures, sname, pose, shader):
     params, model = _scene(sname)
-    cam = S.Camera.from_pose(RS.W, RS.H, pose)
+    cam = RS.camera_from_fixture(vectors, RS.W, RS.H, pose)
     frame = make_frame(cam, model, S.DEMO_SUN_POSITION, 0.0)
     depth = vectors[f"depth_{sname}_{pose}"]
     got, hits = oracle32.render(params, dict(textures, optical_depth=vectors[f"lut_{sname}"]), RS.VARIANTS[shader], frame, depth,
@@ -112,11 +112,38 @@ def test_oracle_equals_reference_fragment(oracle32, vectors, textures, sname, po
     assert err <= ORACLE_TOL, f"{sname}/{pose}/{shader}: oracle vs executed reference {err:.3e}"
 
 
+def _full_case(vectors, shader, w, h, pose):
+    from common import demo_textures
+    key = f"full_{w}x{h}_{pose}_{shader}"
+    tex = demo_textures()
+    assert S.checksum(tex["shape"]) == int(vectors["crc_shape_full"]) and S.checksum(tex["cubemap"]) == int(vectors["crc_cubemap_full"])
+    cam = RS.camera_from_fixture(vectors, w, h, pose)
+    rows = [int(r) for r in vectors[f"rows_{key}"]]
+    depth = S.depth_ground_sphere(cam)
+    depth[rows] = vectors[f"depth_{key}"]  # the rows the reference was executed on, exactly as it saw them
+    return tex, cam, rows, depth, vectors[f"rgba_{key}"]
+
+
+@pytest.mark.parametrize("case", RS.FULL_SIZE, ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}-{c[3]}")
+def test_oracle_equals_reference_at_baseline_sizes(oracle32, vectors, case):
+    """BASELINE.json configs[2] / configs[3] at their stated sizes: whole rows executed from the reference text."""
+    shader, w, h, pose, _ = case
+    tex, cam, rows, depth, want = _full_case(vectors, shader, w, h, pose)
+    frame = make_frame(cam, np.eye(4), S.DEMO_SUN_POSITION, 0.0)
+    params, _ = _scene("demo")
+    worst = 0.0
+    for k, r in enumerate(rows):
+        got, _ = oracle32.render(params, dict(tex, optical_depth=vectors["lut_demo"]), RS.VARIANTS[shader], frame, depth,
+                                 rect=(0, r, w, r + 1), nthreads=4)
+        worst = max(worst, float(np.abs(got[0] - want[k]).max()))
+    assert worst <= ORACLE_TOL, f"{shader} {w}x{h} {pose}: oracle vs executed reference {worst:.3e}"
+
+
 def test_oracle_equals_reference_double_precision_switch(oracle32, vectors, textures):
     """#define DOUBLE_PRECISION (planet_atmosphere_main.gdshaderinc:25,118-125) executed from the reference text with the
     negated camera origin a double-precision engine hands over; the oracle's switch undoes it the same way."""
     params, model = _scene("demo")
-    cam = S.Camera.from_pose(RS.W, RS.H, "P_limb")
+    cam = RS.camera_from_fixture(vectors, RS.W, RS.H, "P_limb")
     frame = make_frame(cam, model, S.DEMO_SUN_POSITION, 0.0)
     inv_view = np.array(frame["inv_view_matrix"], dtype=np.float64).copy()
     inv_view[12:15] *= -1.0
@@ -144,7 +171,7 @@ def test_vectors_reproduce_from_the_reference_tree(vectors, textures, oracle32):
     padded = T.pad_cubemap(cube, lambda f, i, j: oracle32.cube_texel(cube, f, i, j))
     units = dict(u_optical_depth_texture=T.LutTexture(lut), u_blue_noise_texture=T.ByteTexture2D(textures["blue_noise"]),
                  u_cloud_shape_texture=T.ShapeTexture(textures["shape"]), u_cloud_coverage_cubemap=T.CubeTexture(padded))
-    cam = S.Camera.from_pose(RS.W, RS.H, "P_clouds")
+    cam = RS.camera_from_fixture(vectors, RS.W, RS.H, "P_clouds")
     rgba, _, _, _ = G.run_frame("planet_atmosphere_clouds_high_rm", None, params, np.linalg.inv(model), model, cam,
                                 vectors["depth_alt_P_clouds"], units)
     assert np.array_equal(rgba, vectors["rgba_alt_P_clouds_planet_atmosphere_clouds_high_rm"])
@@ -288,7 +315,7 @@ def test_hip_equals_reference_fragment(vectors, textures, sname, shader):
     node.global_transform = model
     worst = 0.0
     for pose in RS.POSES:
-        cam = S.Camera.from_pose(RS.W, RS.H, pose)
+        cam = RS.camera_from_fixture(vectors, RS.W, RS.H, pose)
         node._process(0.0, cam, time=0.0)
         node.set_shader_parameter("u_cloud_coverage_rotation", np.asarray(params["u_cloud_coverage_rotation"], dtype=np.float32))
         got = _gpu_render(node, cam, vectors[f"depth_{sname}_{pose}"])
@@ -298,3 +325,20 @@ def test_hip_equals_reference_fragment(vectors, textures, sname, shader):
         worst = max(worst, float(np.abs(got - want).max()))
     node.close()
     assert worst <= TOL, f"{sname}/{shader}: HIP vs executed reference {worst:.3e}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", RS.FULL_SIZE, ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}-{c[3]}")
+def test_hip_equals_reference_at_baseline_sizes(vectors, case):
+    """BASELINE.json configs[2] (clouds_high, 1920x1080) and configs[3] (clouds_high_rm, 3840x2160): the full frame is drawn by
+    the product path, the rows the reference text was executed on are compared."""
+    shader, w, h, pose, _ = case
+    tex, cam, rows, depth, want = _full_case(vectors, shader, w, h, pose)
+    params, _ = _scene("demo")
+    node = make_node(NODE_CONFIG[shader], tex, params)
+    got = _gpu_render(node, cam, depth)[rows]
+    node.close()
+    err = float(np.abs(got - want).max())
+    print(f"{shader} {w}x{h} {pose}: max |HIP - executed reference| = {err:.3e} over {want.shape[0] * want.shape[1]} pixels")
+    assert np.array_equal(np.all(got == 0.0, axis=-1), np.all(want == 0.0, axis=-1))
+    assert err <= TOL
