@@ -1,6 +1,6 @@
 // atmo_kernels.hip -- gfx950 (CDNA4 / MI355X) kernels for the per-pixel atmosphere + cloud raymarch.
 //
-// One wavefront lane per view ray; a 256-thread workgroup shades a 16x16 pixel tile, each 64-lane
+// One wavefront lane per view ray; a 128-thread workgroup shades a 16x8 pixel tile, each 64-lane
 // wave a 16x4 strip, so a wave's RGBA float4 stores are four 256-byte contiguous runs.
 //
 // Numerical contract (tests/test_gpu_parity.py): max |channel - fp32 oracle| <= 1e-4.
@@ -31,14 +31,16 @@
 
 namespace atmo {
 
-// Workgroup tile in pixels.  16x16 = 4 waves; 16x4 = one wave per workgroup (finer-grained dispatch: shorter tail when
-// heavy cloud tiles and empty-sky tiles mix).  There is no LDS and no barrier, so the choice is purely scheduling.
+// Workgroup tile in pixels.  16x16 = 4 waves, 16x8 = 2 (shipped), 16x4 = one wave per workgroup.  Waves never
+// synchronise (the LDS queue of clouds_high_rm is wave-private), so the choice is purely scheduling: finer tiles give the
+// dispatcher and the tile-order feedback a finer grain.  profiles/round2/ab_tile_height.txt: 16x8 and 16x4 are 3 % faster
+// than 16x16 on clouds_high_rm at 1920x1080 and within +-1 % everywhere else.
 #ifndef ATMO_TILE_H
-#define ATMO_TILE_H 16
+#define ATMO_TILE_H 8
 #endif
 constexpr int TILE_W = 16;
 constexpr int TILE_H = ATMO_TILE_H;
-// Pixels of one 64-lane wave inside the 16x16 workgroup tile: WAVE_W x (64 / WAVE_W).  16x4 keeps a wave's
+// Pixels of one 64-lane wave inside the workgroup tile: WAVE_W x (64 / WAVE_W).  16x4 keeps a wave's
 // float4 stores in 256-byte runs; 8x8 halves that but makes a wave's rays more coherent (tools/ab_build.sh).
 #ifndef ATMO_WAVE_W
 #define ATMO_WAVE_W 16
