@@ -203,6 +203,8 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
     for (int r = 0; r < 3; ++r) rc.cam_pos_world[r] = V[0 + r] * 0.0f + V[4 + r] * 0.0f + V[8 + r] * 0.0f + V[12 + r] * 1.0f;
     rc.vw = (float)f->viewport_w;
     rc.vh = (float)f->viewport_h;
+    rc.rcp_vw = 1.0f / rc.vw;  // pixel_coord(): exact for every viewport size atmo_render accepts (tools/uv_division.c)
+    rc.rcp_vh = 1.0f / rc.vh;
     rc.w = f->viewport_w; rc.h = f->viewport_h;
     rc.x0 = f->x0; rc.y0 = f->y0; rc.x1 = f->x1; rc.y1 = f->y1;
     for (int i = 0; i < 3; ++i) rc.center[i] = f->planet_center_viewspace[i];

@@ -141,6 +141,31 @@ __device__ __forceinline__ float exact_div_uniform(float a, float c, float rc) {
     return __builtin_fmaf(__builtin_fmaf(-q1, c, a), rc, q1);
 }
 
+// Once-per-pixel prologue with the short exact sequences (ATMO_PROLOGUE_DIET), the same bits as ieee_sqrt / ieee_div:
+//   prologue_sqrt  exact_sqrt, 1 + 8 instead of 1 + 15 instructions.  Equal to IEEE for x = 0, every x >= 2^-96, inf and NaN;
+//                  for 0 < x < 2^-96 (the FMA residuals underflow) it may be 1 ulp off -- of a root below 3.6e-15, which
+//                  needs a planet radius below 1e-11 or a camera closer than that to the depth sample;
+//   pixel_coord    (i + 0.5) / n as ONE Markstein correction of (i + 0.5) * RN(1/n): 3 instead of 12 instructions.  Equal to
+//                  the IEEE quotient for every 0 <= i < n <= 65536, the largest viewport atmo_render accepts (checked exhaustively:
+//                  2.1e9 quotients, tools/uv_division.c);
+//   unorm8_exact   byte / 255 in 2 instead of 12 (already used for every texel).
+#ifndef ATMO_PROLOGUE_DIET
+#define ATMO_PROLOGUE_DIET 1
+#endif
+// Both forms give the same bits; which one a kernel variant uses is a measured choice (profiles/round2/ab_prologue.txt:
+// the short forms gain 3-4 % on the baked-LUT atmosphere kernels and cost the direct-light and the raymarched-cloud-light
+// kernels 2-3 % at 1920x1080 although they execute fewer instructions -- see the note at atmo_render_kernel).
+template <bool DIET = true>
+__device__ __forceinline__ float prologue_sqrt(float x) { return DIET ? exact_sqrt(x) : ieee_sqrt(x); }
+template <bool DIET = true>
+__device__ __forceinline__ float pixel_coord(float a, float n, float rcp_n) {
+    if (!DIET) return ieee_div(a, n);
+    const float q0 = a * rcp_n;
+    return __builtin_fmaf(__builtin_fmaf(-q0, n, a), rcp_n, q0);
+}
+template <bool DIET = true>
+__device__ __forceinline__ float blue_noise_value(uint8_t b);
+
 // ---- lane-split mode: two adjacent lanes share one ray (SPLIT = 2) -------------------------------------------------
 // At 1920x1080 a frame is only ~20 000 busy waves for 1024 SIMDs x 7-8 wave slots: too few to keep two waves' fast
 // instructions pairing on a SIMD and to cover the gathers (tools/concurrency_probe.py: two concurrent frames finish in
@@ -173,10 +198,11 @@ __device__ __forceinline__ SphereHit sphere_setup(V3 center, V3 dir) {
     return s;
 }
 // returns (x, y); equal (1e6, 1e6) when missed
+template <bool DIET = true>
 __device__ __forceinline__ float2 hit_radius(SphereHit s, float radius) {
     float h = radius * radius - s.qc2;
     if (h < 0.0f) return make_float2(1000000.0f, 1000000.0f);
-    h = ieee_sqrt(h);
+    h = prologue_sqrt<DIET>(h);
     return make_float2(-s.b - h, -s.b + h);
 }
 
@@ -304,6 +330,8 @@ __device__ __forceinline__ float unorm8_exact(float b) {
     const float c_lo = __uint_as_float(0xaf7efeffu);  // RN(1/255 - c_hi)
     return __builtin_fmaf(b, c_hi, b * c_lo);
 }
+template <bool DIET>
+__device__ __forceinline__ float blue_noise_value(uint8_t b) { return DIET ? unorm8_exact((float)b) : ieee_div((float)b, 255.0f); }
 __device__ __forceinline__ float bilinear_unorm8_exact(uint32_t w, float fx, float fy) {
     const float t00 = unorm8_exact(ub0(w)), t10 = unorm8_exact(ub1(w));
     const float t01 = unorm8_exact(ub2(w)), t11 = unorm8_exact(ub3(w));
@@ -1015,8 +1043,8 @@ struct PixelRay {
 __device__ __forceinline__ PixelRay pixel_ray(const RenderConsts &rc, int px, int py) {
     PixelRay o;
     const float nonlinear_depth = rc.depth[(size_t)py * rc.w + px];
-    const float uvx = ieee_div((float)px + 0.5f, rc.vw);
-    const float uvy = ieee_div((float)py + 0.5f, rc.vh);
+    const float uvx = pixel_coord((float)px + 0.5f, rc.vw, rc.rcp_vw);
+    const float uvy = pixel_coord((float)py + 0.5f, rc.vh, rc.rcp_vh);
     const float nx = uvx * 2.0f - 1.0f, ny = uvy * 2.0f - 1.0f, nz = nonlinear_depth;
     const float *P = rc.inv_p;
     const float vx = P[0] * nx + P[4] * ny + P[8] * nz + P[12] * 1.0f;
@@ -1030,11 +1058,11 @@ __device__ __forceinline__ PixelRay pixel_ray(const RenderConsts &rc, int px, in
     const float ww = Vm[3] * vx + Vm[7] * vy + Vm[11] * vz + Vm[15] * vw;
     const float pwx = ieee_div(wx, ww), pwy = ieee_div(wy, ww), pwz = ieee_div(wz, ww);
     const float ddx = rc.cam_pos_world[0] - pwx, ddy = rc.cam_pos_world[1] - pwy, ddz = rc.cam_pos_world[2] - pwz;
-    float linear_depth = ieee_sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
+    float linear_depth = prologue_sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
 
     // ray_dir = normalize(view_coords.xyz - 0) = v * (1/sqrt(dot(v,v)))
     const float vvx = vx - 0.0f, vvy = vy - 0.0f, vvz = vz - 0.0f;
-    const float inv_len = ieee_div(1.0f, ieee_sqrt(vvx * vvx + vvy * vvy + vvz * vvz));
+    const float inv_len = ieee_div(1.0f, prologue_sqrt(vvx * vvx + vvy * vvy + vvz * vvz));
     o.dir = V3{vvx * inv_len, vvy * inv_len, vvz * inv_len};
     const V3 center = {rc.center[0], rc.center[1], rc.center[2]};
 
@@ -1054,7 +1082,7 @@ __device__ __forceinline__ PixelRay pixel_ray(const RenderConsts &rc, int px, in
         o.linear_depth = linear_depth;
         const float jx = rc.vw * uvx, jy = rc.vh * uvy;
         const int ji = ((int)jx) & 0xff, jj = ((int)jy) & 0xff;
-        o.jitter = ieee_div((float)rc.blue[jj * 256 + ji], 255.0f);
+        o.jitter = blue_noise_value<true>(rc.blue[jj * 256 + ji]);
     }
     return o;
 }
@@ -1098,6 +1126,7 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
     constexpr bool LITE = (FLAGS & KF_LITE) != 0;
     constexpr bool PRECISE = (FLAGS & KF_PRECISE) != 0;
     constexpr bool LOD = (FLAGS & KF_CUBE_LOD) != 0;
+    constexpr bool DIET = ATMO_PROLOGUE_DIET && !DIRECT && !((FLAGS & KF_CLOUDS) && (FLAGS & KF_CLOUD_LIGHT_RM));
     static_assert(!LOD || (CLOUDS && PRECISE && SPLIT == 1), "implicit cubemap LOD: precise cloud kernels, one lane per ray");
 
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
@@ -1117,8 +1146,8 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
     // (written out here; pixel_ray() / cloud_gate() above are the same statements packaged for the quad partners of the
     //  LOD mode -- routing this path through them changed hipcc's block layout and cost the direct-light kernel 6 %)
     const float nonlinear_depth = rc.depth[(size_t)py * rc.w + px];
-    const float uvx = ieee_div((float)px + 0.5f, rc.vw);
-    const float uvy = ieee_div((float)py + 0.5f, rc.vh);
+    const float uvx = pixel_coord<DIET>((float)px + 0.5f, rc.vw, rc.rcp_vw);
+    const float uvy = pixel_coord<DIET>((float)py + 0.5f, rc.vh, rc.rcp_vh);
     const float nx = uvx * 2.0f - 1.0f, ny = uvy * 2.0f - 1.0f, nz = nonlinear_depth;
     const float *P = rc.inv_p;
     const float vx = P[0] * nx + P[4] * ny + P[8] * nz + P[12] * 1.0f;
@@ -1132,16 +1161,16 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
     const float ww = Vm[3] * vx + Vm[7] * vy + Vm[11] * vz + Vm[15] * vw;
     const float pwx = ieee_div(wx, ww), pwy = ieee_div(wy, ww), pwz = ieee_div(wz, ww);
     const float ddx = rc.cam_pos_world[0] - pwx, ddy = rc.cam_pos_world[1] - pwy, ddz = rc.cam_pos_world[2] - pwz;
-    float linear_depth = ieee_sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
+    float linear_depth = prologue_sqrt<DIET>(ddx * ddx + ddy * ddy + ddz * ddz);
 
     // ray_dir = normalize(view_coords.xyz - 0) = v * (1/sqrt(dot(v,v)))
     const float vvx = vx - 0.0f, vvy = vy - 0.0f, vvz = vz - 0.0f;
-    const float inv_len = ieee_div(1.0f, ieee_sqrt(vvx * vvx + vvy * vvy + vvz * vvz));
+    const float inv_len = ieee_div(1.0f, prologue_sqrt<DIET>(vvx * vvx + vvy * vvy + vvz * vvz));
     const V3 dir = {vvx * inv_len, vvy * inv_len, vvz * inv_len};
     const V3 center = {rc.center[0], rc.center[1], rc.center[2]};
 
     const SphereHit sh = sphere_setup(center, dir);
-    const float2 rs_atmo = hit_radius(sh, rc.atmosphere_radius);
+    const float2 rs_atmo = hit_radius<DIET>(sh, rc.atmosphere_radius);
 
     if (rs_atmo.x == rs_atmo.y) {  // discard: nothing reaches the blend stage
         if (!rc.composite && half == 0) *out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1149,7 +1178,7 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
     }
     const float t_begin = fmaxf(rs_atmo.x, 0.0f);
     float t_end = fmaxf(rs_atmo.y, 0.0f);
-    const float2 rs_ground = hit_radius(sh, rc.planet_radius);
+    const float2 rs_ground = hit_radius<DIET>(sh, rc.planet_radius);
     float gd = 10000000.0f;
     if (rs_ground.x != rs_ground.y) gd = rs_ground.x;
     linear_depth = linear_depth * (1.0f - rc.sphere_depth_factor) + gd * rc.sphere_depth_factor;
@@ -1157,7 +1186,7 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
 
     const float jx = rc.vw * uvx, jy = rc.vh * uvy;
     const int ji = ((int)jx) & 0xff, jj = ((int)jy) & 0xff;
-    const float jitter = ieee_div((float)rc.blue[jj * 256 + ji], 255.0f);
+    const float jitter = blue_noise_value<DIET>(rc.blue[jj * 256 + ji]);
 
     float4 rgba;
     if (LITE) {
@@ -1169,9 +1198,9 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
 
     if (CLOUDS) {
         // --- render_clouds (cloud_funcs.gdshaderinc:249-324), gates evaluated exactly -----------------
-        const float2 rs_top = hit_radius(sh, rc.clouds_top);
+        const float2 rs_top = hit_radius<DIET>(sh, rc.clouds_top);
         if (rs_top.x != rs_top.y) {
-            const float2 rs_bottom = hit_radius(sh, rc.clouds_bottom);
+            const float2 rs_bottom = hit_radius<DIET>(sh, rc.clouds_bottom);
             const float c0 = fmaxf(rs_top.x, 0.0f);
             const float c1 = fminf(rs_top.y, linear_depth);
             if (c0 < linear_depth && (linear_depth > rs_bottom.y || rs_bottom.x > 0.0f)) {
