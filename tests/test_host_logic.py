@@ -277,3 +277,26 @@ def test_forward_z_camera_conventions():
     rev = S.Camera.from_pose(64, 36, "P_space")
     assert np.allclose(cam.pixel_view_dirs(), rev.pixel_view_dirs())
     assert np.array_equal(d < 1.0, S.depth_ground_sphere(rev) > 0.0)
+
+
+def test_pixel_coordinate_division_is_exact(tmp_path):
+    """pixel_coord() of csrc/atmo_kernels.hip replaces (i + 0.5) / n by one Markstein correction: the exhaustive check
+    (tools/uv_division.c, every n <= 65536 when run without argument) on the prefix n <= 6000, plus the large power-of-two
+    and display sizes in numpy float32 with an exact FMA emulated in float64 (a * r and the residual fit 53 bits)."""
+    import subprocess
+
+    exe = tmp_path / "uv_division"
+    subprocess.check_call(["gcc", "-O2", "-o", str(exe), os.path.join(ROOT, "tools", "uv_division.c"), "-lm"])
+    out = subprocess.run([str(exe), "6000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert "pixel_coord: 0 mismatches" in out.stdout and "unorm8_exact: 0 mismatches" in out.stdout
+    f32, f64 = np.float32, np.float64
+    for n in (7680, 8192, 15360, 16384, 32768, 65535, 65536):
+        a = np.arange(n, dtype=f32) + f32(0.5)
+        c = f32(n)
+        r = f32(1.0) / c
+        q0 = a * r
+        # fma(-q0, c, a): the product of two float32 is exact in float64, and so is its difference to a here (|.| < 2^-20 |a|)
+        res = (a.astype(f64) - q0.astype(f64) * f64(c)).astype(f32)
+        q1 = (q0.astype(f64) + res.astype(f64) * f64(r)).astype(f32)  # float64 sum, then one float32 rounding
+        assert np.array_equal(q1, a / c), n
