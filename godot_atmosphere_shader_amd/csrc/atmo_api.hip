@@ -382,6 +382,7 @@ int atmo_create(int device, int variant, int view_steps, int cloud_steps, int li
     ctx->light_steps = (light_mode == ATMO_LIGHT_DIRECT && !lite) ? light_steps : 0;
     ctx->flags = 0;
     if (ctx->cloud_steps > 0) ctx->flags |= atmo::KF_CLOUDS | atmo::KF_PRECISE;  // precise cloud density is the default
+    if (lite) ctx->flags |= atmo::KF_PRECISE;                                    // and so is the v1 march in reference order
     if (variant == ATMO_VARIANT_CLOUDS_HIGH_RM) ctx->flags |= atmo::KF_CLOUD_LIGHT_RM;
     if (light_mode == ATMO_LIGHT_DIRECT && !lite) ctx->flags |= atmo::KF_LIGHT_DIRECT;
     if (lite) ctx->flags |= atmo::KF_LITE;  // the v1 atmosphere reads no optical-depth LUT and has no light march
@@ -873,8 +874,8 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
 
 int atmo_set_precision(AtmoContext *ctx, int mode) {
     if (!ctx) return ATMO_E_ARG;
-    if (mode != 0 && mode != 1) return fail(ctx, ATMO_E_ARG, "atmo_set_precision: mode must be 0 (fast) or 1 (precise cloud density)");
-    if (mode == 1 && (ctx->flags & atmo::KF_CLOUDS)) ctx->flags |= atmo::KF_PRECISE;  // only the cloud kernels have a precise form
+    if (mode != 0 && mode != 1) return fail(ctx, ATMO_E_ARG, "atmo_set_precision: mode must be 0 (fast) or 1 (precise)");
+    if (mode == 1 && (ctx->flags & (atmo::KF_CLOUDS | atmo::KF_LITE))) ctx->flags |= atmo::KF_PRECISE;  // the v2 atmosphere has a single form
     else ctx->flags &= ~atmo::KF_PRECISE;
     return ATMO_OK;
 }

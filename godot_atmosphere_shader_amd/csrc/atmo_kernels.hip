@@ -709,6 +709,45 @@ __device__ __forceinline__ float4 march_atmosphere_v1(const RenderConsts &rc, V3
     return o;
 }
 
+// The same in the reference's operation order (atmo_set_precision(ctx, 1), the default of the v1 variants): unfused, IEEE
+// sqrt and divisions, the position accumulated step by step.  The fast form above is within 1e-6 of it while
+// density * step_len < 1, i.e. inside the model's range; outside (a thick, dense atmosphere marched in 16 steps) the
+// product of (1 - density * step_len) grows like 1e5 and amplifies the fast form's rsq / fused rounding to 2e-4 relative
+// (found by the executed-reference fuzz, tests/test_reference_exec.py seed 10).  ~3x the instructions of the fast form,
+// still the cheapest kernels of the set.  SPLIT = 2: both lanes of a ray evaluate the whole march (no sharing).
+__device__ __forceinline__ float4 march_atmosphere_v1_precise(const RenderConsts &rc, V3 dir, float t_begin, float t_end) {
+#pragma clang fp contract(off)
+    const float inv_steps = ieee_div(1.0f, (float)rc.view_steps);
+    const float step_len = (t_end - t_begin) * inv_steps;
+    const float svx = dir.x * step_len, svy = dir.y * step_len, svz = dir.z * step_len;
+    // ray_origin + ray_dir * t_begin with ray_origin = 0
+    float px = 0.0f + dir.x * t_begin, py = 0.0f + dir.y * t_begin, pz = 0.0f + dir.z * t_begin;
+    float factor = 1.0f, light_sum = 0.0f;
+    for (int i = 0; i < rc.view_steps; ++i) {
+        const float rx = px - rc.center[0], ry = py - rc.center[1], rz = pz - rc.center[2];
+        const float d = exact_sqrt(rx * rx + ry * ry + rz * rz);
+        const float ux = ieee_div(rx, d), uy = ieee_div(ry, d), uz = ieee_div(rz, d);
+        // get_atmosphere_density(d), atmosphere_common.gdshaderinc:12-24
+        const float sd = d - rc.planet_radius;
+        const float h = fminf(fmaxf(ieee_div(sd, rc.atmosphere_height), 0.0f), 1.0f);
+        const float y = 1.0f - h;
+        const float density = y * y * y * rc.density;
+        float light = fminf(fmaxf(1.2f * (rc.sun_dir[0] * ux + rc.sun_dir[1] * uy + rc.sun_dir[2] * uz) + 0.5f, 0.0f), 1.0f);
+        light = light * light;
+        light_sum += light * inv_steps;
+        factor *= (1.0f - density * step_len);
+        px += svx; py += svy; pz += svz;
+    }
+    const float atmo_factor = 1.0f - factor;
+    const float day_factor = fminf(fmaxf(light_sum * rc.day_night_transition_scale, 0.0f), 1.0f);
+    float4 o;
+    o.x = mixf(mixf(rc.night0[0], rc.night1[0], atmo_factor), mixf(rc.day0[0], rc.day1[0], atmo_factor), day_factor);
+    o.y = mixf(mixf(rc.night0[1], rc.night1[1], atmo_factor), mixf(rc.day0[1], rc.day1[1], atmo_factor), day_factor);
+    o.z = mixf(mixf(rc.night0[2], rc.night1[2], atmo_factor), mixf(rc.day0[2], rc.day1[2], atmo_factor), day_factor);
+    o.w = fminf(fmaxf(atmo_factor, 0.0f), 1.0f);
+    return o;
+}
+
 // ---- clouds ----------------------------------------------------------------------------------------
 
 // Precise mode (atmo_set_precision(ctx, 1)): the whole density expression in the reference's operation order, unfused,
@@ -1190,7 +1229,8 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
 
     float4 rgba;
     if (LITE) {
-        rgba = march_atmosphere_v1<SPLIT>(rc, dir, t_begin, t_end, half);  // main:172-175
+        if constexpr (PRECISE) rgba = march_atmosphere_v1_precise(rc, dir, t_begin, t_end);
+        else rgba = march_atmosphere_v1<SPLIT>(rc, dir, t_begin, t_end, half);  // main:172-175
     } else {
         const float view_step_len = ieee_div(t_end - t_begin, (float)rc.view_steps);
         rgba = march_atmosphere<DIRECT, LSTEPS, SPLIT>(rc, dir, t_begin, view_step_len, jitter, half);
@@ -1616,6 +1656,7 @@ hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream
     case KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM: return launch_t<KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM, 0>(rc, split, stream);
     case KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT:
         return launch_direct<KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT>(rc, split, stream);
+    case KF_PRECISE | KF_LITE: return launch_t<KF_PRECISE | KF_LITE, 0>(rc, split, stream);
     case KF_PRECISE | KF_LITE | KF_CLOUDS: return launch_t<KF_PRECISE | KF_LITE | KF_CLOUDS, 0>(rc, split, stream);
     // implicit cubemap LOD (atmo_set_sampler_lod 1): precise cloud kernels with LUT light, one lane per ray
     case KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS: return launch_s<KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS, 0, 1>(rc, stream);

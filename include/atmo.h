@@ -183,11 +183,14 @@ int atmo_render(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev
 int atmo_render_composite(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *scene_rgba_dev, void *stream);
 
 /*
- * Numerical mode of the cloud kernels (no reference counterpart; the atmosphere-only variants have a single form).
+ * Numerical mode of the cloud kernels and of the v1 ("lite") atmosphere (no reference counterpart; the v2 atmosphere has a
+ * single form).
  * 1 (default, precise): the whole cloud density expression, both texture filters included, is evaluated in the
  *   reference's operation order with exact UNORM8 conversions, so the x50 density ramp sees bit-identical inputs; the
  *   deviation from a scalar fp32 evaluation of the GDShader is that of the atmosphere term (<= 2.1e-5) on every
- *   planet scale tested (tests/test_gpu_parity.py::test_parity_other_planet_scales).
+ *   planet scale tested (tests/test_gpu_parity.py::test_parity_other_planet_scales).  The v1 atmosphere march runs in the
+ *   reference's operation order as well (unfused, IEEE sqrt / divide): needed outside the model's range, where
+ *   density * step_len > 1 makes the product of (1 - density * step_len) amplify rounding to > 1e-4 relative.
  * 0 (fast): the well-conditioned part of the density expression runs fused: ~15 % more cloud-kernel throughput, max
  *   deviation 5.1e-5 at 1920x1080 and 6.9e-5 at 3840x2160 on the demo scene, but it grows with u_cloud_density_scale
  *   (1.8e-4 at 10x the demo's value), i.e. the 1e-4 contract is scene-dependent in this mode.

@@ -26,6 +26,7 @@ sys.path.insert(0, HERE)
 import gdshader_vm as VM  # noqa: E402
 import vm_textures as T  # noqa: E402
 from godot_atmosphere_shader_amd import scene as S  # noqa: E402
+import reference_scenes as RS  # noqa: E402
 from reference_scenes import CUBE_N, FULL_SIZE, H, POSES, SHAPE_N, VARIANTS, W, camera_matrices, scenes  # noqa: E402
 from godot_atmosphere_shader_amd.demo import demo_textures  # noqa: E402
 from oracle.oracle import Oracle  # noqa: E402
@@ -33,14 +34,14 @@ from oracle.oracle import Oracle  # noqa: E402
 SHADERS = "/root/reference/addons/zylann.atmosphere/shaders"
 F32 = np.float32
 
-def uniforms_for(parser, params, world_to_model):
+def uniforms_for(parser, params, world_to_model, sun=S.DEMO_SUN_POSITION):
     """Host values for the uniforms the shader declares (those the scene does not set keep the shader's defaults)."""
     out = {}
     for name in parser.uniforms:
         if name == "u_world_to_model_matrix":
             out[name] = S.col_major(world_to_model)
         elif name == "u_sun_position":
-            out[name] = S.DEMO_SUN_POSITION
+            out[name] = sun
         elif name in params:
             out[name] = params[name]
     return out
@@ -64,13 +65,14 @@ def run_bake(params):
     return bits.astype(np.uint32).view(F32).reshape(n, n), m.calls
 
 
-def run_frame(shader, defines, params, world_to_model, model_matrix, cam, depth, tex_units, time_s=0.0, rows=None):
+def run_frame(shader, defines, params, world_to_model, model_matrix, cam, depth, tex_units, time_s=0.0, rows=None,
+              sun=S.DEMO_SUN_POSITION):
     """vertex() once, fragment() for every pixel of the viewport (or of the given rows)."""
     p = VM.load(os.path.join(SHADERS, shader + ".gdshader"), defines)
     rows = list(range(cam.height)) if rows is None else list(rows)
     n = cam.width * len(rows)
     samplers = dict(tex_units, u_depth_texture=T.DepthTexture(depth))
-    m = VM.Machine(p, n, samplers, uniforms_for(p, params, world_to_model), source_color=S.srgb_to_linear)
+    m = VM.Machine(p, n, samplers, uniforms_for(p, params, world_to_model, sun), source_color=S.srgb_to_linear)
     g = m.globals
     ident = m.from_host("mat4", np.eye(4).reshape(-1))
     # vertex stage: the quad's vertices all produce the same varyings, one lane is enough
@@ -172,5 +174,47 @@ def main():
     print("wrote", path, os.path.getsize(path), "bytes;", "functions executed:", ", ".join(sorted(calls)))
 
 
+class UnsetCube:
+    """An unbound samplerCube: the engine's default white texture (README.md:46 "cover uniformly")."""
+
+    def texture(self, d):
+        return np.ones(d.shape[1], dtype=F32)
+
+
+def main_fuzz():
+    import json
+
+    t0 = time.time()
+    o = Oracle("f32")
+    out = {"seeds": np.int64(RS.FUZZ_SEEDS), "viewport": np.array([RS.FUZZ_W, RS.FUZZ_H])}
+    for k in range(RS.FUZZ_SEEDS):
+        params, cam_args, sun, model, depth_kind = RS.random_scene(k)
+        tex = RS.fuzz_textures(k)
+        cam = S.Camera(RS.FUZZ_W, RS.FUZZ_H, **cam_args)
+        depth = (S.depth_ground_sphere(cam, center_world=model[:3, 3], radius=params["u_planet_radius"]) if depth_kind == "ground"
+                 else S.depth_far(cam))
+        bake_params = {kk: params[kk] for kk in ("u_planet_radius", "u_atmosphere_height", "u_density")}
+        lut, _ = run_bake(bake_params)
+        cube = tex["cubemap"]
+        cube_unit = UnsetCube() if cube is None else T.CubeTexture(T.pad_cubemap(cube, lambda f, i, j: o.cube_texel(cube, f, i, j)))
+        units = dict(u_optical_depth_texture=T.LutTexture(lut), u_blue_noise_texture=T.ByteTexture2D(tex["blue_noise"]),
+                     u_cloud_shape_texture=T.ShapeTexture(tex["shape"]), u_cloud_coverage_cubemap=cube_unit)
+        out[f"params_{k}"] = np.array(json.dumps({kk: (list(v) if isinstance(v, tuple) else v) for kk, v in params.items()}))
+        out[f"cam_{k}"], out[f"sun_{k}"], out[f"model_{k}"], out[f"depth_{k}"] = camera_matrices(cam), np.array(sun), model, depth
+        out[f"lut_crc_{k}"] = np.uint32(S.checksum(lut))
+        out[f"tex_crc_{k}"] = np.array([S.checksum(tex["blue_noise"]), S.checksum(tex["shape"]),
+                                        0 if cube is None else S.checksum(cube)], dtype=np.uint32)
+        for shader in RS.fuzz_variants(k):
+            rgba, disc, vary, _ = run_frame(shader, None, params, np.linalg.inv(model), model, cam, depth, units, sun=sun)
+            out[f"rgba_{k}_{shader}"] = rgba
+            out[f"planet_vs_{k}"], out[f"sun_vs_{k}"] = vary
+            print(f"{time.time() - t0:6.1f}s seed {k} {shader}: {int((~disc).sum())} of {disc.size} kept, max {np.nanmax(rgba):.3f}", flush=True)
+    path = os.path.join(HERE, "reference_exec_fuzz.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if "--fuzz-only" not in sys.argv:
+        main()
+    main_fuzz()

@@ -60,3 +60,62 @@ def camera_from_fixture(z, w, h, pose):
     m = z[f"cam_{w}x{h}_{pose}"]
     cam.inv_projection, cam.inv_view, cam.view = m[0].copy(), m[1].copy(), m[2].copy()
     return cam
+
+
+# ---- random scenes (reference_exec_fuzz.npz): planets, cameras, suns and shader parameters the demo does not cover -------
+FUZZ_SEEDS = 14
+FUZZ_W, FUZZ_H = 40, 24
+
+
+def fuzz_variants(k):
+    """Three of the seven reference shader files per seed, rotating so that each is used six times."""
+    names = list(VARIANTS)
+    return [names[(3 * k + j) % len(names)] for j in range(3)]
+
+
+def fuzz_textures(k):
+    shape_n = [32, 24, 16, 48][k % 4]          # 24 and 48 are not powers of two
+    cube_n = [64, 32, 17, 128][k % 4]
+    return dict(blue_noise=S.make_blue_noise(k + 1), shape=S.make_shape_texture(shape_n, seed=k, cells=4),
+                cubemap=None if k % 5 == 4 else S.make_coverage_cubemap(cube_n, seed=k))
+
+
+def random_scene(k):
+    """Returns (params, camera arguments, sun position, planet model matrix, depth kind) for seed k."""
+    rng = np.random.default_rng(7000 + k)
+    R = float(rng.choice([1.0, 10.0, 100.0, 637.1]))
+    H = R * float(rng.uniform(0.03, 0.25))
+    dens_target = float(rng.uniform(0.3, 3.0))  # vertical optical depth rho^2 * H / 4 of order one
+    a = float(rng.uniform(0, 2 * np.pi))
+    params = demo_params(
+        u_planet_radius=R, u_atmosphere_height=H, u_density=float(np.sqrt(4.0 * dens_target / H)),
+        u_scattering_strength=float(rng.uniform(0.3, 3.0)),
+        u_scattering_wavelengths=(float(rng.uniform(600, 750)), float(rng.uniform(500, 580)), float(rng.uniform(400, 480))),
+        u_atmosphere_modulate=tuple(rng.uniform(0.5, 1.0, 3).tolist()),
+        u_atmosphere_ambient_color=tuple(rng.uniform(0.0, 0.01, 3).tolist()),
+        u_sphere_depth_factor=float(rng.choice([0.0, 0.35, 1.0])),
+        u_cloud_density_scale=float(rng.uniform(0.5, 60.0) / H * 8.0),
+        u_cloud_bottom=float(rng.uniform(0.05, 0.3)), u_cloud_top=float(rng.uniform(0.4, 0.9)),
+        u_cloud_blend=float(rng.uniform(0.0, 1.0)), u_cloud_shape_invert=float(rng.choice([0.0, 1.0])),
+        u_cloud_coverage_bias=float(rng.uniform(-0.2, 0.2)), u_cloud_shape_factor=float(rng.uniform(0.0, 1.2)),
+        u_cloud_shape_scale=float(rng.uniform(0.05, 0.4) * 100.0 / R),
+        u_day_night_transition_scale=float(rng.uniform(0.5, 3.0)),
+        u_day_color0=tuple(rng.uniform(0, 1, 3).tolist()) + (1.0,), u_day_color1=tuple(rng.uniform(0, 1, 3).tolist()) + (1.0,),
+        u_night_color0=tuple(rng.uniform(0, 0.5, 3).tolist()) + (1.0,), u_night_color1=tuple(rng.uniform(0, 0.5, 3).tolist()) + (1.0,),
+        u_cloud_coverage_rotation=(float(np.cos(a)), float(np.sin(a)), float(-np.sin(a)), float(np.cos(a))),
+    )
+    alt = float(rng.choice([0.02 * H, 0.4 * H, 0.9 * H, 1.5 * H, 0.6 * R, 2.0 * R]))
+    d = rng.normal(size=3)
+    d /= np.linalg.norm(d)
+    center = rng.normal(size=3) * R * 0.05 if k % 2 else np.zeros(3)   # every second planet is off the origin ...
+    yaw = float(rng.uniform(0, 2 * np.pi)) if k % 2 else 0.0           # ... and rotated about y
+    model = np.array([[np.cos(yaw), 0, np.sin(yaw), center[0]], [0, 1, 0, center[1]], [-np.sin(yaw), 0, np.cos(yaw), center[2]],
+                      [0, 0, 0, 1]], dtype=np.float64)
+    eye = center + d * (R + alt)
+    tangent = np.cross(d, rng.normal(size=3))
+    tangent /= np.linalg.norm(tangent)
+    target = eye + tangent * R * 0.5 - d * R * float(rng.uniform(-0.1, 0.6))
+    sun = rng.normal(size=3)
+    sun = center + sun / np.linalg.norm(sun) * R * 50.0
+    cam_args = dict(eye=eye, target=target, fovy_deg=float(rng.uniform(40, 90)), near=0.05 * H, far=20.0 * R)
+    return params, cam_args, tuple(float(v) for v in sun), model, ("ground" if k % 3 else "far")

@@ -177,6 +177,55 @@ def test_vectors_reproduce_from_the_reference_tree(vectors, textures, oracle32):
     assert np.array_equal(rgba, vectors["rgba_alt_P_clouds_planet_atmosphere_clouds_high_rm"])
 
 
+# ------------------------------------------------------------------------------------- random scenes (reference_exec_fuzz.npz)
+@pytest.fixture(scope="module")
+def fuzz():
+    return np.load(os.path.join(GOLDEN, "reference_exec_fuzz.npz"))
+
+
+def _fuzz_case(fuzz, k):
+    """Inputs of random scene k exactly as the reference text saw them (parameters and matrices come from the fixture)."""
+    import json
+
+    params = {kk: (tuple(v) if isinstance(v, list) else v) for kk, v in json.loads(str(fuzz[f"params_{k}"])).items()}
+    _, cam_args, _, _, _ = RS.random_scene(k)
+    cam = S.Camera(RS.FUZZ_W, RS.FUZZ_H, **cam_args)
+    m = fuzz[f"cam_{k}"]
+    cam.inv_projection, cam.inv_view, cam.view = m[0].copy(), m[1].copy(), m[2].copy()
+    model = fuzz[f"model_{k}"]
+    params["u_world_to_model_matrix"] = S.col_major(np.linalg.inv(model))
+    tex = RS.fuzz_textures(k)
+    crc = [S.checksum(tex["blue_noise"]), S.checksum(tex["shape"]), 0 if tex["cubemap"] is None else S.checksum(tex["cubemap"])]
+    assert crc == [int(c) for c in fuzz[f"tex_crc_{k}"]]
+    return params, cam, tuple(fuzz[f"sun_{k}"].tolist()), model, tex, fuzz[f"depth_{k}"]
+
+
+def _rel_err(got, want):
+    """Absolute up to 1, relative above (cloud light and the v1 model are unbounded)."""
+    finite = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), finite)
+    return float((np.abs(got - want)[finite] / np.maximum(1.0, np.abs(want[finite]))).max())
+
+
+@pytest.mark.parametrize("k", range(RS.FUZZ_SEEDS))
+def test_oracle_equals_reference_random_scenes(oracle32, fuzz, k):
+    """Random planets (R = 1 ... 637), cameras inside / outside the atmosphere and the cloud layer, suns, planet transforms,
+    parameter sets, non-power-of-two textures, an unset cubemap: three reference shader files per scene, executed."""
+    params, cam, sun, model, tex, depth = _fuzz_case(fuzz, k)
+    lut = oracle32.bake_optical_depth(params["u_planet_radius"], params["u_atmosphere_height"], params["u_density"])
+    assert S.checksum(lut) == int(fuzz[f"lut_crc_{k}"])  # the reference's bake of this planet, bit for bit
+    planet, sun_vs = atmosphere_vertex(cam.view, model, sun)
+    assert np.array_equal(np.asarray(planet, dtype=np.float32), fuzz[f"planet_vs_{k}"])
+    assert np.array_equal(np.asarray(sun_vs, dtype=np.float32), fuzz[f"sun_vs_{k}"])
+    frame = make_frame(cam, model, sun, 0.0)
+    for shader in RS.fuzz_variants(k):
+        got, _ = oracle32.render(params, dict(tex, optical_depth=lut), RS.VARIANTS[shader], frame, depth, nthreads=4)
+        want = fuzz[f"rgba_{k}_{shader}"]
+        assert np.array_equal(np.all(got == 0.0, axis=-1), np.all(want == 0.0, axis=-1))
+        err = _rel_err(got, want)
+        assert err <= ORACLE_TOL, f"seed {k} {shader}: oracle vs executed reference {err:.3e}"
+
+
 # ------------------------------------------------------------------------------------------------ the interpreter's own tests
 def _run(tmp_path, text, lanes, inputs, entry="main", uniforms=None):
     path = tmp_path / "t.gdshader"
@@ -342,3 +391,32 @@ def test_hip_equals_reference_at_baseline_sizes(vectors, case):
     print(f"{shader} {w}x{h} {pose}: max |HIP - executed reference| = {err:.3e} over {want.shape[0] * want.shape[1]} pixels")
     assert np.array_equal(np.all(got == 0.0, axis=-1), np.all(want == 0.0, axis=-1))
     assert err <= TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", range(RS.FUZZ_SEEDS))
+def test_hip_equals_reference_random_scenes(fuzz, k):
+    from godot_atmosphere_shader_amd import PlanetAtmosphere, load_shader
+    from godot_atmosphere_shader_amd.planet_atmosphere import LinearColor, _SOURCE_COLOR
+
+    params, cam, sun, model, tex, depth = _fuzz_case(fuzz, k)
+    for shader in RS.fuzz_variants(k):
+        node = PlanetAtmosphere(blue_noise=tex["blue_noise"])
+        node.custom_shader = load_shader(shader)
+        node.planet_radius, node.atmosphere_height, node.sun_path = params["u_planet_radius"], params["u_atmosphere_height"], sun
+        for name, v in params.items():
+            if name in ("u_planet_radius", "u_atmosphere_height", "u_cloud_coverage_rotation", "u_world_to_model_matrix"):
+                continue
+            node.set(f"shader_params/{name}", LinearColor(v) if name in _SOURCE_COLOR else v)  # the fixture holds linear colours
+        node.global_transform = model
+        node._process(0.0, cam, time=0.0)
+        node.set_shader_parameter("u_cloud_coverage_rotation", np.asarray(params["u_cloud_coverage_rotation"], dtype=np.float32))
+        node.set_shader_parameter("u_cloud_shape_texture", tex["shape"])
+        if tex["cubemap"] is not None:
+            node.set_shader_parameter("u_cloud_coverage_cubemap", tex["cubemap"])
+        got = _gpu_render(node, cam, depth)
+        node.close()
+        want = fuzz[f"rgba_{k}_{shader}"]
+        assert np.array_equal(np.all(got == 0.0, axis=-1), np.all(want == 0.0, axis=-1)), f"seed {k} {shader}: discard sets differ"
+        err = _rel_err(got, want)
+        assert err <= TOL, f"seed {k} {shader}: HIP vs executed reference {err:.3e}"
