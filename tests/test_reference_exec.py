@@ -419,4 +419,5 @@ def test_hip_equals_reference_random_scenes(fuzz, k):
         want = fuzz[f"rgba_{k}_{shader}"]
         assert np.array_equal(np.all(got == 0.0, axis=-1), np.all(want == 0.0, axis=-1)), f"seed {k} {shader}: discard sets differ"
         err = _rel_err(got, want)
+        print(f"seed {k} {shader}: HIP vs executed reference {err:.3e}")
         assert err <= TOL, f"seed {k} {shader}: HIP vs executed reference {err:.3e}"
