@@ -167,7 +167,7 @@ def parse_args():
     ap.add_argument("--shard", default="viewports", choices=["viewports", "bands"],
                     help="N>1: 'viewports' = one full viewport per GPU (weak scaling, default); 'bands' = ONE viewport cut "
                          "into hit-balanced row bands, one per GPU, gathered in place into the frame on rank 0 (strong scaling)")
-    ap.add_argument("--also", default="lut32,shipped8,clouds_high,clouds_high_rm,direct32x8@3840x2160,clouds_high_rm@3840x2160,noise_cubemap",
+    ap.add_argument("--also", default="lut32,shipped8,clouds_high,clouds_high_rm,direct32x8@3840x2160,clouds_high_rm@3840x2160,direct32x8+2vp,noise_cubemap",
                     help="comma-separated extra workloads (name or name@WxH) timed at N=1 after the headline and reported under "
                          "'extra', each with its own roofline blocks: the reference-exact LUT mode and the shipped 8-step shader "
                          "(SURVEY.md 8d), BASELINE configs[2] (clouds_high 1080p) and configs[3] (clouds_high_rm 3840x2160); '' to skip")
@@ -383,6 +383,40 @@ def run_workload(torch, S, name, w, h, pose, steps, warmup, textures, params, lo
     return res
 
 
+def bench_two_viewports(torch, S, name, w, h, steps, warmup, textures, params, local_rank):
+    """Two independent viewports of the same size drawn concurrently on two streams by two contexts (the single-GPU form of
+    BASELINE configs[4]'s "independent viewports"): how much of the chip one 1920x1080 draw leaves idle.  Reported
+    next to the one-viewport rate, never instead of it."""
+    from godot_atmosphere_shader_amd.demo import make_node
+
+    config_name, desc = WORKLOADS[name]
+    cams = [S.Camera.from_pose(w, h, "P_space"), S.Camera.from_pose(w, h, S.orbit_pose(1, 8))]
+    nodes, frames, depths, outs, streams = [], [], [], [], []
+    for cam in cams:
+        node = make_node(config_name, textures, params, device=local_rank, **node_kwargs(name))
+        nodes.append(node)
+        frames.append(node.prepare_frame(cam))
+        depths.append(torch.from_numpy(S.depth_ground_sphere(cam)).cuda())
+        outs.append(torch.empty((h, w, 4), dtype=torch.float32, device="cuda"))
+        streams.append(torch.cuda.Stream())
+
+    def loop(n):
+        for _ in range(n):
+            for k in range(2):
+                nodes[k].render_prepared(frames[k], depths[k].data_ptr(), outs[k].data_ptr(), streams[k].cuda_stream)
+
+    loop(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loop(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for node in nodes:
+        node.close()
+    return {"workload": f"2 x ({desc}; {w}x{h}), two contexts on two streams, poses P_space and orbit 1/8",
+            "Mrays/s": 2 * w * h * steps / dt / 1e6, "ms_per_pair": dt / steps * 1e3, "steps": steps}
+
+
 def main():
     args = parse_args()
     import numpy as np
@@ -507,6 +541,9 @@ def main():
                 extra[item] = bench_noise_cubemap()
                 continue
             name, _, size = item.partition("@")
+            if name.endswith("+2vp"):
+                extra[item] = bench_two_viewports(torch, S, name[:-4], w, h, ex_steps, ex_warm, textures, params, local_rank)
+                continue
             ew, eh = (int(v) for v in size.split("x")) if size else (w, h)
             extra[item] = run_workload(torch, S, name, ew, eh, args.pose, ex_steps, ex_warm, textures, params, local_rank)
         result["extra"] = extra
