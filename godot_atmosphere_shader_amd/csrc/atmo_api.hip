@@ -113,6 +113,10 @@ struct AtmoContext {
     // tile order with cost feedback (atmo_set_tile_feedback): -1 = by variant (clouds_high_rm on), 0 off, 1 on
     int tile_feedback = -1;
     DeviceBuffer tile_cost[2], tile_order[2];          // double-buffered: draw N uses [N & 1]
+#ifdef ATMO_WAVE_TRACE
+    DeviceBuffer wave_trace;                           // diagnostic build only
+    size_t wave_trace_waves = 0;
+#endif
     int fb_tiles_x = 0, fb_tiles_y = 0, fb_split = 0;  // launch grid the buffers belong to
     unsigned fb_n = 0;                                 // draws of that grid so far
     bool fb_cost_valid[2] = {false, false};            // tile_cost[k] holds the costs of an enqueued draw
@@ -838,6 +842,18 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
             if (e1) (void)hipEventDestroy(e1);
         }
     } ev;
+#ifdef ATMO_WAVE_TRACE
+    {
+        const size_t waves = (size_t)gx * gy * 4;  // upper bound for every tile height
+        if (ctx->wave_trace_waves < waves) {
+            int rc1 = dev_alloc(ctx, ctx->wave_trace, waves * 4 * sizeof(unsigned long long));
+            if (rc1 != ATMO_OK) return rc1;
+            ctx->wave_trace_waves = waves;
+        }
+        HIP_TRY(ctx, hipMemsetAsync(ctx->wave_trace.ptr, 0, waves * 4 * sizeof(unsigned long long), s));
+        rc.wave_trace = (unsigned long long *)ctx->wave_trace.ptr;
+    }
+#endif
     const bool timed = ctx->timing > 0 && (ctx->launch_counter % ctx->timing) == 0;
     if (timed) {
         if (ctx->pending.size() >= 64) drain_timing(ctx, /*only_completed=*/true);  // a long loop with timing left on stays bounded
@@ -949,3 +965,14 @@ const char *atmo_last_error_string(AtmoContext *ctx) {
 }
 
 }  // extern "C"
+
+#ifdef ATMO_WAVE_TRACE
+// diagnostic build only: copies the wave trace of the last draw (4 x uint64 per wave) to the host; returns the wave count
+extern "C" long long atmo_debug_wave_trace(AtmoContext *ctx, unsigned long long *host, long long max_waves) {
+    if (!ctx || !ctx->wave_trace.ptr) return 0;
+    const long long n = (long long)ctx->wave_trace_waves < max_waves ? (long long)ctx->wave_trace_waves : max_waves;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(host, ctx->wave_trace.ptr, (size_t)n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
+}
+#endif

@@ -69,6 +69,9 @@ struct RenderConsts {
     int32_t tiles_x;                // tiles per row of the launch grid
     const uint32_t *tile_order;     // null => tile = linear block index; else the tile each block shades (heaviest first)
     uint32_t *tile_cost;            // null => no feedback; else per-tile max wave duration in shader cycles (atomicMax)
+#ifdef ATMO_WAVE_TRACE  // diagnostic build (tools/wave_timeline.py): 4 x uint64 per wave = start, end (100 MHz), HW_ID, XCC_ID
+    unsigned long long *wave_trace;
+#endif
     // --- exact short division of the pixel coordinates (pixel_coord in atmo_kernels.hip)
     float rcp_vw, rcp_vh;           // [host] RN(1 / vw), RN(1 / vh)
 };

@@ -1336,12 +1336,28 @@ __global__ __launch_bounds__(TILE_W *TILE_H ATMO_MIN_WAVES_ARG) ATMO_SGPR_ATTR v
     // the division (which serialises the prologue's scalar loads behind an early s_waitcnt) 0.115 ms; NO preamble at all
     // (blockIdx used directly) 0.115 ms as well -- the few hundred cycles of scalar work in front of the depth load
     // help (an explicit s_sleep stagger by blockIdx does not: +4..6 %).
+#ifdef ATMO_WAVE_TRACE
+    const uint64_t trace_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
     if (rc.tile_order != nullptr) tile = rc.tile_order[tile];
     const uint32_t tile_y = tile / (uint32_t)rc.tiles_x, tile_x = tile - tile_y * (uint32_t)rc.tiles_x;
     uint64_t t0 = 0;
     if (rc.tile_cost != nullptr) t0 = __builtin_amdgcn_s_memtime();
+#ifdef ATMO_WAVE_TRACE
+    const uint64_t trace_t0 = __builtin_amdgcn_s_memrealtime();
     shade_pixel<FLAGS, LSTEPS, SPLIT>(rc, (int)tile_x, (int)tile_y);
+    if (rc.wave_trace != nullptr && (threadIdx.x & 63) == 0) {
+        const uint32_t slot = (blockIdx.y * gridDim.x + blockIdx.x) * (TILE_W * TILE_H / 64) + (threadIdx.x >> 6);
+        unsigned long long *w = rc.wave_trace + 4ull * slot;
+        w[0] = trace_t0;
+        w[1] = __builtin_amdgcn_s_memrealtime();
+        w[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID, 32 bits
+        w[3] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu) | ((trace_t0 - trace_entry) << 8);  // HW_REG_XCC_ID, preamble ticks
+    }
+#else
+    shade_pixel<FLAGS, LSTEPS, SPLIT>(rc, (int)tile_x, (int)tile_y);
+#endif
     if (rc.tile_cost != nullptr && (threadIdx.x & 63) == 0) {
         const uint64_t dt = __builtin_amdgcn_s_memtime() - t0;
         atomicMax(&rc.tile_cost[tile], (uint32_t)(dt > 0xffffffffull ? 0xffffffffull : dt));
