@@ -110,17 +110,20 @@ struct AtmoContext {
     int lane_split = 0;             // 0 = choose per launch by size, 1 = one lane per ray, 2 = two lanes per ray
     int last_split = 1;             // what the most recent launch used (atmo_kernel_name)
     int last_flags = -1;
-    // tile order with cost feedback (atmo_set_tile_feedback): -1 = by variant (clouds_high_rm on), 0 off, 1 on
+    // tile order with cost feedback (atmo_set_tile_feedback): -1 = default (on), 0 off, 1 on
     int tile_feedback = -1;
-    DeviceBuffer tile_cost[2], tile_order[2];          // double-buffered: draw N uses [N & 1]
+    DeviceBuffer tile_cost[2], tile_order[2];          // one cost buffer ([0]); two orders: the one in use and the one being sorted
 #ifdef ATMO_WAVE_TRACE
     DeviceBuffer wave_trace;                           // diagnostic build only
     size_t wave_trace_waves = 0;
 #endif
     int fb_tiles_x = 0, fb_tiles_y = 0, fb_split = 0;  // launch grid the buffers belong to
     unsigned fb_n = 0;                                 // draws of that grid so far
-    bool fb_cost_valid[2] = {false, false};            // tile_cost[k] holds the costs of an enqueued draw
-    bool fb_order_valid[2] = {false, false};           // tile_order[k] was (or is being) written by the sort kernel
+    unsigned fb_last_record = 0;                       // fb_n of the last draw that recorded costs
+    int fb_active = -1;                                // tile_order[fb_active] is complete and in use; -1: row-major order
+    int fb_write = 0;                                  // tile_order[fb_write] is what the next / pending sort writes
+    bool fb_pending = false;                           // a sort is in flight on fb_stream
+    hipStream_t fb_draw_stream = nullptr;              // the stream the draws of this grid were enqueued on
     hipStream_t fb_stream = nullptr;                   // the sort kernel runs here, beside the draw
     hipEvent_t fb_ev_draw[2] = {nullptr, nullptr}, fb_ev_order[2] = {nullptr, nullptr};
     int timing = 0;          // 0 off; k >= 1: bracket every k-th launch with HIP events
@@ -796,18 +799,21 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     int gx = 0, gy = 0;
     atmo::render_grid(rc, split, &gx, &gy);
     rc.tiles_x = gx;
-    // default (-1): on for the raymarched-light variant, whose wave costs are the most skewed (profiles/round2/ab_tile_feedback.txt)
-    bool feedback = ctx->tile_feedback == 1 || (ctx->tile_feedback < 0 && (ctx->flags & atmo::KF_CLOUD_LIGHT_RM));
+    // default (-1): on for every variant since the sort no longer costs the draws anything (profiles/round2/ab_tile_feedback.txt)
+    bool feedback = ctx->tile_feedback != 0;
     if (const char *e = std::getenv("ATMO_TILE_FEEDBACK")) feedback = e[0] == '1';  // A/B runs
     if (feedback) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) feedback = false;  // no side-stream work inside a graph
     }
-    int fbk = -1;
+    // Every `period`-th draw records the wave durations per tile; a sort on the side stream turns them into the next
+    // order, which later draws pick up once a host-side event query says it is complete: no draw ever waits for a sort.
+    bool fb_record = false;
     if (feedback && (long long)gx * gy >= 512) {  // tiny launches: nothing to schedule
         const size_t bytes = (size_t)gx * gy * sizeof(uint32_t);
-        if (ctx->fb_tiles_x != gx || ctx->fb_tiles_y != gy || ctx->fb_split != split || !ctx->tile_cost[0].ptr) {
-            // first launch of this grid: allocate (synchronous, once) and start recording
+        static const unsigned period = [] { const char *e = std::getenv("ATMO_TILE_FEEDBACK_PERIOD"); int v = e ? std::atoi(e) : 8; return (unsigned)(v < 1 ? 1 : v); }();
+        if (ctx->fb_tiles_x != gx || ctx->fb_tiles_y != gy || ctx->fb_split != split || !ctx->tile_cost[0].ptr || ctx->fb_draw_stream != s) {
+            // first launch of this grid (or the caller moved to another stream): drain, allocate once, start over
             if (!ctx->fb_stream) {
                 HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->fb_stream, hipStreamNonBlocking));
                 for (int k = 0; k < 2; ++k) {
@@ -816,22 +822,28 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
                 }
             }
             HIP_TRY(ctx, hipStreamSynchronize(ctx->fb_stream));
-            for (int k = 0; k < 2; ++k) {
-                int rc1 = dev_alloc(ctx, ctx->tile_cost[k], bytes);
-                if (rc1 == ATMO_OK) rc1 = dev_alloc(ctx, ctx->tile_order[k], bytes);
-                if (rc1 != ATMO_OK) return rc1;
-                HIP_TRY(ctx, hipMemsetAsync(ctx->tile_cost[k].ptr, 0, bytes, s));
-                ctx->fb_cost_valid[k] = ctx->fb_order_valid[k] = false;
-            }
+            if (ctx->fb_draw_stream != s && ctx->fb_n > 0) HIP_TRY(ctx, hipStreamSynchronize(ctx->fb_draw_stream));  // draws still reading an order
+            int rc1 = dev_alloc(ctx, ctx->tile_cost[0], bytes);
+            for (int k = 0; k < 2 && rc1 == ATMO_OK; ++k) rc1 = dev_alloc(ctx, ctx->tile_order[k], bytes);
+            if (rc1 != ATMO_OK) return rc1;
+            HIP_TRY(ctx, hipMemsetAsync(ctx->tile_cost[0].ptr, 0, bytes, s));
             ctx->fb_tiles_x = gx; ctx->fb_tiles_y = gy; ctx->fb_split = split;
+            ctx->fb_draw_stream = s;
             ctx->fb_n = 0;
+            ctx->fb_last_record = 0;
+            ctx->fb_active = -1;
+            ctx->fb_write = 0;
+            ctx->fb_pending = false;
         }
-        fbk = (int)(ctx->fb_n & 1u);
-        if (ctx->fb_order_valid[fbk]) {  // sorted during the previous draw from the costs of the draw before it
-            HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->fb_ev_order[fbk], 0));
-            rc.tile_order = (const uint32_t *)ctx->tile_order[fbk].ptr;
+        if (ctx->fb_pending && hipEventQuery(ctx->fb_ev_order[ctx->fb_write]) == hipSuccess) {
+            ctx->fb_active = ctx->fb_write;  // complete: no stream-side wait needed
+            ctx->fb_write ^= 1;
+            ctx->fb_pending = false;
         }
-        rc.tile_cost = (uint32_t *)ctx->tile_cost[fbk].ptr;
+        if (ctx->fb_active >= 0) rc.tile_order = (const uint32_t *)ctx->tile_order[ctx->fb_active].ptr;
+        // the first draws record back to back (the order settles in a few frames), then every period-th
+        fb_record = !ctx->fb_pending && (ctx->fb_n < 4 || ctx->fb_n - ctx->fb_last_record >= period);
+        if (fb_record) rc.tile_cost = (uint32_t *)ctx->tile_cost[0].ptr;
     }
     // kernel timing brackets the draw kernel alone (the tile-order kernel runs beside the previous draw).  The event pair
     // is owned by a guard until it is handed to ctx->pending, so no error path leaks it.
@@ -863,21 +875,17 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     }
     HIP_TRY(ctx, atmo::launch_render(flags, split, rc, s));
     ctx->last_flags = flags;
-    if (fbk >= 0) {
-        // While this draw runs, sort the tiles for the NEXT draw on the side stream, from the costs the PREVIOUS draw
-        // left in the other buffer (the sort also clears them for the next draw to write).
-        HIP_TRY(ctx, hipEventRecord(ctx->fb_ev_draw[fbk], s));
-        ctx->fb_cost_valid[fbk] = true;
-        const int o = fbk ^ 1;
-        if (ctx->fb_cost_valid[o]) {
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->fb_stream, ctx->fb_ev_draw[o], 0));
-            HIP_TRY(ctx, atmo::launch_tile_order((uint32_t *)ctx->tile_cost[o].ptr, (uint32_t *)ctx->tile_order[o].ptr, gx * gy, ctx->fb_stream));
-            HIP_TRY(ctx, hipEventRecord(ctx->fb_ev_order[o], ctx->fb_stream));
-            ctx->fb_order_valid[o] = true;
-            ctx->fb_cost_valid[o] = false;
-        }
-        ctx->fb_n += 1;
+    if (fb_record) {
+        // Sort on the side stream as soon as this draw is done (the sort also clears the costs for the next recording).
+        // tile_order[fb_write] was last read by draws enqueued on `s` before this one, so the event orders the write too.
+        HIP_TRY(ctx, hipEventRecord(ctx->fb_ev_draw[0], s));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->fb_stream, ctx->fb_ev_draw[0], 0));
+        HIP_TRY(ctx, atmo::launch_tile_order((uint32_t *)ctx->tile_cost[0].ptr, (uint32_t *)ctx->tile_order[ctx->fb_write].ptr, gx * gy, ctx->fb_stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->fb_ev_order[ctx->fb_write], ctx->fb_stream));
+        ctx->fb_pending = true;
+        ctx->fb_last_record = ctx->fb_n;
     }
+    if (feedback && (long long)gx * gy >= 512) ctx->fb_n += 1;
     ctx->last_split = split;
     ctx->launch_counter += 1;  // counted only once the launch was accepted
     if (timed) {
