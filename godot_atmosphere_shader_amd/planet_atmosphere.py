@@ -225,7 +225,7 @@ class PlanetAtmosphere:
         self._precise_clouds = bool(precise_clouds)  # atmo_set_precision: bit-faithful cloud density (default); False = fast mode
         self._double_precision = bool(double_precision)  # `#define DOUBLE_PRECISION` (main:25): engine negates INV_VIEW origin
         self._lane_split = int(lane_split)  # atmo_set_lane_split: 0 auto, 1 / 2 lanes per ray
-        self._tile_feedback = int(tile_feedback)  # atmo_set_tile_feedback: -1 by variant, 0 off, 1 on
+        self._tile_feedback = int(tile_feedback)  # atmo_set_tile_feedback: -1 default (on), 0 off, 1 on
         self._cubemap_lod = bool(cubemap_lod)  # atmo_set_sampler_lod: implicit LOD of the coverage cubemap (2x2 quad derivatives)
         self._ctx = C.c_void_p()
         self._planet_radius = 1.0

@@ -215,14 +215,17 @@ int atmo_set_host_double_precision(AtmoContext *ctx, int enable);
 int atmo_set_lane_split(AtmoContext *ctx, int lanes_per_ray);
 
 /*
- * Launch order (no reference counterpart): with feedback on, every draw records how long each pixel tile's waves ran,
- * and while the next draw runs a small sort kernel on a side stream turns those costs into the tile order of the draw
- * after it: heaviest tiles first (longest-processing-time-first list scheduling; two draws of delay, nothing on the
- * critical path).  Cloud frames at 1920x1080 are bounded by the few tiles that sit entirely in dense cloud (~10x the
- * mean wave); starting those first shortens the draw of clouds_high_rm by 27 % (14 % at 3840x2160), while frames whose
- * tiles weigh about the same lose 1-6 % to the bookkeeping.  The picture does not depend on the order.
- * -1 (default) = on for ATMO_VARIANT_CLOUDS_HIGH_RM only; 0 = off; 1 = on.  Launches inside a HIP graph capture never
- * use it.  The per-grid buffers are allocated by the first launch of a grid size (synchronously).
+ * Launch order (no reference counterpart): with feedback on, every 8th draw (the first four back to back) records how
+ * long each pixel tile's waves ran; a small sort kernel on a side stream turns those costs into a tile order, heaviest
+ * tiles first (longest-processing-time-first list scheduling), and later draws pick it up once the host sees the sort
+ * complete (hipEventQuery): no draw waits for a sort, 7 of 8 draws carry no bookkeeping.  A draw in row-major order
+ * leaves the SIMDs empty for the last ~12 % of its time at 1920x1080; heaviest-first puts the cheap tiles (rays that
+ * miss the planet, clear sky) into that drain: direct light 32x8 +9.7 %, clouds_high +5 %, clouds_high_rm +49 %
+ * (its heaviest tiles are ~10x the mean), baked-LUT atmosphere +4..5 %; within +-1.5 % on frames whose tiles all weigh
+ * the same (profiles/round2/ab_tile_feedback.txt).  The picture does not depend on the order.
+ * -1 (default) = on; 0 = off; 1 = on.  Launches inside a HIP graph capture never use it.  The per-grid buffers are
+ * allocated by the first launch of a grid size (synchronously); draws of one context are expected on one stream (moving
+ * to another stream drains the old one once).
  */
 int atmo_set_tile_feedback(AtmoContext *ctx, int mode);
 

@@ -33,9 +33,9 @@ def main():
     cam = S.Camera.from_pose(w, h, pose)
     depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
     out = None
-    for _ in range(12):  # warm up; the tile-order feedback (if the variant uses it) needs a few draws to settle
+    for _ in range(12):  # paced like a frame loop: the tile-order feedback swaps a new order in when the HOST sees its sort done
         out = node.render(cam, depth, out=out)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     fn = node._lib.atmo_debug_wave_trace
     fn.restype = C.c_longlong
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong]
