@@ -877,8 +877,8 @@ def test_lane_split_two_equals_one(oracle32, config_name):
 
 @pytest.mark.parametrize("config_name,size", [("clouds_high_rm", (1920, 1080)), ("clouds_high", (1000, 700)), ("no_clouds_32x8_direct", (777, 555))])
 def test_tile_feedback_does_not_change_the_picture(config_name, size):
-    """Heaviest-tiles-first dispatch (the sorted order is in use from the third draw of a grid on) renders the same
-    bits as the plain row-major launch: every tile is shaded exactly once (the target is NaN-filled before each draw),
+    """Heaviest-tiles-first dispatch (costs recorded by the first draws and then every 8th; a sorted order is in use as soon
+    as the host has seen its sort complete) renders the same bits as the plain row-major launch: every tile is shaded exactly once (the target is NaN-filled before each draw),
     across a change of pose (stale costs), a change of rect (new grid) and back."""
     w, h = size
     tex, params = demo_textures(), demo_params()
@@ -896,13 +896,23 @@ def test_tile_feedback_does_not_change_the_picture(config_name, size):
         got = on.render(cam, depth, out=tgt, rect=rect)
         torch.cuda.synchronize()
         assert torch.equal(got, want), (pose, rect)
+    # a burst the host never waits on (orders are swapped in whenever a sort happens to be complete), 20 draws
+    cam = S.Camera.from_pose(w, h, "P_clouds")
+    depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
+    want = off.render(cam, depth)
+    outs = [torch.full((h, w, 4), float("nan"), dtype=torch.float32, device="cuda") for _ in range(20)]
+    for o in outs:
+        on.render(cam, depth, out=o)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, want)
     off.close()
     on.close()
 
 
 def test_tile_feedback_default_policy_and_graph_capture():
-    """-1 (default): only the raymarched-light variant reorders; a draw captured into a HIP graph never does (no
-    side-stream work inside a capture) and replays the same bits."""
+    """-1 (default): every variant reorders; a draw captured into a HIP graph never does (no side-stream work inside a
+    capture) and replays the same bits; moving the draws to another stream restarts the feedback state."""
     tex, params = demo_textures(), demo_params()
     w, h = 1280, 720
     cam = S.Camera.from_pose(w, h, "P_space")
