@@ -822,7 +822,12 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
                 }
             }
             HIP_TRY(ctx, hipStreamSynchronize(ctx->fb_stream));
-            if (ctx->fb_draw_stream != s && ctx->fb_n > 0) HIP_TRY(ctx, hipStreamSynchronize(ctx->fb_draw_stream));  // draws still reading an order
+            if (ctx->fb_draw_stream != s && ctx->fb_n > 0) {  // draws on the old stream may still read an order
+                if (hipStreamSynchronize(ctx->fb_draw_stream) != hipSuccess) {  // the caller may have destroyed that stream
+                    (void)hipGetLastError();
+                    HIP_TRY(ctx, hipDeviceSynchronize());
+                }
+            }
             int rc1 = dev_alloc(ctx, ctx->tile_cost[0], bytes);
             for (int k = 0; k < 2 && rc1 == ATMO_OK; ++k) rc1 = dev_alloc(ctx, ctx->tile_order[k], bytes);
             if (rc1 != ATMO_OK) return rc1;
