@@ -63,7 +63,7 @@ def camera_from_fixture(z, w, h, pose):
 
 
 # ---- random scenes (reference_exec_fuzz.npz): planets, cameras, suns and shader parameters the demo does not cover -------
-FUZZ_SEEDS = 14
+FUZZ_SEEDS = 24
 FUZZ_W, FUZZ_H = 40, 24
 
 
