@@ -92,6 +92,7 @@ struct AtmoContext {
     int view_steps = 8, cloud_steps = 0, light_steps = 0;
     Params p;
     DeviceBuffer lut, blue, shape, cube;
+    DeviceBuffer lut4;  // footprint copy of `lut` (derived on the device whenever `lut` is written): what the kernels sample
     int lut_w = 0, lut_h = 0, shape_n = 0, cube_n = 0;
     int cube_levels = 0;                 // mip levels bound (footprint arrays packed level after level in `cube`)
     DeviceBuffer cube_level_off;         // element offset of every level's footprint array (uint32 x 16, device)
@@ -292,6 +293,7 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
         }
     }
     rc.lut = (const float *)ctx->lut.ptr; rc.lut_w = ctx->lut_w; rc.lut_h = ctx->lut_h;
+    rc.lut4 = (const float *)ctx->lut4.ptr;
     rc.blue = (const uint8_t *)ctx->blue.ptr;
     rc.shape = (const uint32_t *)ctx->shape.ptr; rc.shape_n = ctx->shape_n;
     rc.cube = (const uint32_t *)ctx->cube.ptr; rc.cube_n = ctx->cube_n;
@@ -415,6 +417,7 @@ int atmo_destroy(AtmoContext *ctx) {
     (void)hipSetDevice(ctx->device);
     drain_timing(ctx);
     dev_free(ctx->lut);
+    dev_free(ctx->lut4);
     dev_free(ctx->blue);
     dev_free(ctx->shape);
     dev_free(ctx->cube);
@@ -512,14 +515,18 @@ int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h,
     if (!is_cube && data && mips != 0 && mips != 1) return fail(ctx, ATMO_E_ARG, "atmo_set_texture: only the cubemap takes mip levels");
 
     if (std::strcmp(name, "u_optical_depth_texture") == 0) {
-        if (!data) { dev_free(ctx->lut); ctx->lut_w = ctx->lut_h = 0; return ATMO_OK; }
+        if (!data) { dev_free(ctx->lut); dev_free(ctx->lut4); ctx->lut_w = ctx->lut_h = 0; return ATMO_OK; }
         if (kind != ATMO_TEX_2D_R32F) return fail(ctx, ATMO_E_ARG, "u_optical_depth_texture must be ATMO_TEX_2D_R32F");
-        if (w < 1 || h < 1 || w > 8192 || h > 8192) return fail(ctx, ATMO_E_ARG, "u_optical_depth_texture: bad size");
+        // the kernels form the footprint byte offset in fp32: (w + 1) (h + 1) 16 must stay below 2^24
+        if (w < 1 || h < 1 || w > 1023 || h > 1023) return fail(ctx, ATMO_E_ARG, "u_optical_depth_texture: each side must be 1..1023 texels (the reference bakes 256 x 256)");
         uint8_t *raw = nullptr;
         int rc = stage_texels(ctx, data, (size_t)w * h * sizeof(float), memory, s, 0, &raw);
         if (rc == ATMO_OK) rc = tex_alloc(ctx, ctx->lut, (size_t)(w + 2) * (h + 2) * sizeof(float));
         if (rc != ATMO_OK) return rc;
         HIP_TRY(ctx, atmo::launch_layout_lut((const float *)raw, w, h, (float *)ctx->lut.ptr, s));
+        rc = tex_alloc(ctx, ctx->lut4, (size_t)(w + 1) * (h + 1) * 16);
+        if (rc != ATMO_OK) return rc;
+        HIP_TRY(ctx, atmo::launch_lut_footprints((const float *)ctx->lut.ptr, w, h, (float *)ctx->lut4.ptr, s));
         ctx->lut_w = w; ctx->lut_h = h;
         return tex_updated(ctx, s);
     }
@@ -701,6 +708,7 @@ int atmo_bake_optical_depth(AtmoContext *ctx, void *stream) {
     const int w = 256, h = 256;  // optical_depth_baker.gd:24
     if (ctx->lut_w != w || ctx->lut_h != h) {
         int rc = dev_alloc(ctx, ctx->lut, (size_t)(w + 2) * (h + 2) * sizeof(float));  // a size change waits for the device (hipFree)
+        if (rc == ATMO_OK) rc = dev_alloc(ctx, ctx->lut4, (size_t)(w + 1) * (h + 1) * 16);
         if (rc != ATMO_OK) return rc;
         ctx->lut_w = w; ctx->lut_h = h;
     }
@@ -712,6 +720,7 @@ int atmo_bake_optical_depth(AtmoContext *ctx, void *stream) {
     bc.steps = 64;  // optical_depth.gdshader:18
     bc.out = (float *)ctx->lut.ptr;
     HIP_TRY(ctx, atmo::launch_bake(bc, (hipStream_t)stream));
+    HIP_TRY(ctx, atmo::launch_lut_footprints((const float *)ctx->lut.ptr, w, h, (float *)ctx->lut4.ptr, (hipStream_t)stream));
     return tex_updated(ctx, (hipStream_t)stream);  // draws and read-backs on other streams wait for this bake
 }
 

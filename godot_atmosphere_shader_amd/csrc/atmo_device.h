@@ -52,6 +52,7 @@ struct RenderConsts {
     // --- textures (device memory owned by the context)
     const float *lut;        // u_optical_depth_texture: (lut_h+2) rows of (lut_w+2), clamp-to-edge apron
     int32_t lut_w, lut_h;
+    const float *lut4;       // what the kernels sample: (lut_h+1) rows of (lut_w+1) footprints, 4 floats = the 2x2 apron texels at (i,j),(i+1,j),(i,j+1),(i+1,j+1)
     const uint8_t *blue;     // u_blue_noise_texture 256x256
     const uint32_t *shape;   // u_cloud_shape_texture: n^3 xy-footprint words (repeat wrap baked in)
     int32_t shape_n;
@@ -98,6 +99,7 @@ hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream
 hipError_t launch_bake(const BakeConsts &bc, hipStream_t stream);
 hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int n, hipStream_t stream);
 hipError_t launch_layout_lut(const float *lut, int w, int h, float *out, hipStream_t stream);
+hipError_t launch_lut_footprints(const float *apron, int w, int h, float *out4, hipStream_t stream);
 hipError_t launch_layout_shape(const uint8_t *t, int n, uint32_t *out, hipStream_t stream);
 hipError_t launch_layout_cube(const uint8_t *faces, int n, uint32_t *out, hipStream_t stream);
 hipError_t launch_cube_mip(const uint8_t *level, int n, uint8_t *next, hipStream_t stream);

@@ -208,8 +208,9 @@ __device__ __forceinline__ float2 hit_radius(SphereHit s, float radius) {
 
 // ---- samplers ----------------------------------------------------------------------------------
 // Device texture layouts (built by atmo_api.hip when a texture is set, see DESIGN.md "Data layout in HBM"):
-//   LUT    (w+2) x (h+2) fp32 with a clamp-to-edge apron: texel (i,j) at [(j+1)*(w+2) + i+1]; a bilinear
-//          footprint is two adjacent-pair loads, no index clamps in the loop.
+//   LUT    (w+2) x (h+2) fp32 with a clamp-to-edge apron: texel (i,j) at [(j+1)*(w+2) + i+1] (what is baked, read back
+//          and checked against the host statement), plus a footprint copy derived from it: (w+1) x (h+1) entries of 4
+//          floats, entry (i,j) = apron texels (i,j), (i+1,j), (i,j+1), (i+1,j+1): one 16-byte gather per bilinear sample.
 //   shape  n^3 uint32 "xy footprints": word (i,j,k) = bytes T(i,j,k), T(i+1,j,k), T(i,j+1,k), T(i+1,j+1,k) with the
 //          repeat wrap baked in; a trilinear fetch is 2 dword loads (planes k, k+1) instead of 8 byte loads.
 //   cube   6 x (n+1)^2 uint32 footprints of the apron-padded faces: word (i,j) = the 2x2 texels whose top-left
@@ -237,40 +238,23 @@ __device__ __forceinline__ float ub2(uint32_t w) { return (float)((w >> 16) & 0x
 __device__ __forceinline__ float ub3(uint32_t w) { return (float)(w >> 24); }
 
 // texture(u_optical_depth_texture, uv).r : bilinear, clamp-to-edge, R32F.  x = u*w - 0.5, y = v*h - 0.5 (texel space).
-__device__ __forceinline__ float lut_sample_xy(const float *__restrict__ lut, int stride, int rows, float x, float y) {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 buf_f32x4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+// One 16-byte gather from the footprint copy of the LUT (atmo_lut_footprint_kernel): the texture addresser was busy 62-70 %
+// of the lut32 draw with two 8-byte gathers per sample (19 cycles each per wave); one 16-byte gather costs about the same as
+// one of them.  lut32 -7 % (profiles/round2/ab_lut_footprint.txt).  The byte offset is formed in fp32 (exact: < 2^24).
+__device__ __forceinline__ float lut_sample_fp(const float *__restrict__ lut4, int w1, int h1, float x, float y) {
 #pragma clang fp contract(fast)
     const float xf = floorf(x), yf = floorf(y);
     const float fx = x - xf, fy = y - yf;
-#if ATMO_BUFFER_LOADS && !ATMO_ABLATE_FETCH
-    {
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(lut, (uint32_t)(stride * rows) * 4u);
-#if ATMO_LUT_FLOAT_INDEX
-        // byte offset ((yf + 1) * stride + xf + 1) * 4 formed in fp32 (exact: < 2^24) with two fast-class FMAs and one
-        // conversion, instead of two conversions + integer multiply-add + shift (all slow class)
-        const float s4 = (float)(stride * 4);
-        const uint32_t off = (uint32_t)fmaf(yf, s4, fmaf(xf, 4.0f, s4 + 4.0f));
-#else
-        const uint32_t off = (uint32_t)(((int)yf + 1) * stride + ((int)xf + 1)) * 4u;
-#endif
-        const f32x2 r0 = buf_f32x2(rs, off), r1 = buf_f32x2(rs, off + (uint32_t)stride * 4u);
-        const float a = r0.x + (r0.y - r0.x) * fx;
-        const float b = r1.x + (r1.y - r1.x) * fx;
-        return a + (b - a) * fy;
-    }
-#endif
-    // apron coordinates.  Keep the pointer form: the compiler merges each row's pair into one global_load_dwordx2;
-    // unsigned element offsets from the scalar base measured 1.5x slower on this loop (profiles/round1/ab_lut_loop.txt).
-    const int i = (int)xf + 1, j = (int)yf + 1;
-    const float *p = lut + j * stride + i;
-#if ATMO_ABLATE_FETCH
-    const float base = (float)(j * stride + i) * 1e-6f;
-    const float t00 = base, t10 = base + 1e-3f, t01 = base + 2e-3f, t11 = base + 3e-3f;
-    (void)p;
-#else
-    const float t00 = p[0], t10 = p[1], t01 = p[stride], t11 = p[stride + 1];
-#endif
-    const float a = t00 + (t10 - t00) * fx;
-    const float b = t01 + (t11 - t01) * fx;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(lut4, (uint32_t)(w1 * h1) * 16u);
+    const float s16 = (float)(w1 * 16);
+    const uint32_t off = (uint32_t)fmaf(yf, s16, fmaf(xf, 16.0f, s16 + 16.0f));  // footprint (xf + 1, yf + 1)
+    const f32x4 t = buf_f32x4(rs, off);
+    const float a = t.x + (t.y - t.x) * fx;
+    const float b = t.z + (t.w - t.z) * fx;
     return a + (b - a) * fy;
 }
 
@@ -508,7 +492,6 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
     const float inv_light_steps = LSTEPS > 0 ? 1.0f / (float)(LSTEPS > 0 ? LSTEPS : 1) : hw_rcp((float)light_steps);
     const float half_w = 0.5f * (float)rc.lut_w, x_off = half_w - 0.5f;
     const float lut_hf = (float)rc.lut_h, y_off = lut_hf - 0.5f;
-    const int lut_stride = rc.lut_w + 2;
 
     float ox = fmaf(dir.x, t_begin, -rc.center[0]);
     float oy = fmaf(dir.y, t_begin, -rc.center[1]);
@@ -623,7 +606,7 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
             // uv = (0.5 + 0.5*cos, height_ratio) -> texel space
             const float x = fmaf(bdot * inv_r, half_w, x_off);
             const float yv = fmaf(-y, lut_hf, y_off);
-            sun_od = lut_sample_xy(rc.lut, lut_stride, rc.lut_h + 2, x, yv);
+            sun_od = lut_sample_fp(rc.lut4, rc.lut_w + 1, rc.lut_h + 1, x, yv);
         }
 
         const float d = y3 * dstep;
@@ -1689,6 +1672,19 @@ const char *render_kernel_name(int flags, int light_steps, int split) {
     const int lsteps = ((flags & KF_LIGHT_DIRECT) && light_steps == 8) ? 8 : 0;
     snprintf(name, sizeof(name), "atmo_render_kernel<%d, %d, %d>", flags, lsteps, split == 2 ? 2 : 1);
     return name;
+}
+
+__global__ void atmo_lut_footprint_kernel(const float *__restrict__ apron, int w, int h, float *__restrict__ out4) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (i > w || j > h) return;
+    const int st = w + 2;
+    const float *p = apron + (size_t)j * st + i;
+    float *o = out4 + ((size_t)j * (w + 1) + i) * 4;
+    o[0] = p[0]; o[1] = p[1]; o[2] = p[st]; o[3] = p[st + 1];
+}
+hipError_t launch_lut_footprints(const float *apron, int w, int h, float *out4, hipStream_t stream) {
+    hipLaunchKernelGGL(atmo_lut_footprint_kernel, dim3((w + 1 + 255) / 256, h + 1), dim3(256), 0, stream, apron, w, h, out4);
+    return hipGetLastError();
 }
 
 hipError_t launch_bake(const BakeConsts &bc, hipStream_t stream) {

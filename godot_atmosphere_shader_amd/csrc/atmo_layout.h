@@ -2,7 +2,8 @@
 // the re-layout kernels of atmo_kernels.hip evaluate these functions per output element on the GPU, and the host
 // helpers of the C ABI (atmo_host_layout_*: the CPU checker of tests/test_host_logic.py) loop over them.
 //
-//   LUT    (w+2) x (h+2) fp32 with a clamp-to-edge apron (u_optical_depth_texture is `repeat_disable`, v2:7)
+//   LUT    (w+2) x (h+2) fp32 with a clamp-to-edge apron (u_optical_depth_texture is `repeat_disable`, v2:7); the kernels
+//          sample a footprint copy of it (4 floats per bilinear footprint, built on the device from the apron buffer)
 //   shape  n^3 uint32 "xy footprints": word (i,j,k) = T(i,j,k), T(i+1,j,k), T(i,j+1,k), T(i+1,j+1,k), repeat wrap
 //   cube   per mip level, 6 x (n+1)^2 uint32 footprints of the faces padded with a seamless apron: the border texel is
 //          the one reached by folding over the cube edge, a corner the rounded mean of the three corner texels

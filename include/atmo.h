@@ -113,7 +113,8 @@ int atmo_get_param_f32(AtmoContext *ctx, const char *name, float *v, int n);
  * Replaces: ShaderMaterial.set_shader_parameter(name, Texture) for u_optical_depth_texture
  * (planet_atmosphere.gd:156), u_blue_noise_texture (:107), u_cloud_shape_texture and
  * u_cloud_coverage_cubemap (user-set).  The data is copied; `memory` says where `data` lives.
- * data == NULL unsets the texture (cubemap => constant 1.0).  2-D: w x h; 3-D: w=h=d=n; cube: w=h=n, d=6.
+ * data == NULL unsets the texture (cubemap => constant 1.0).  2-D: w x h (u_optical_depth_texture: 1..1023 per side, the
+ * reference bakes 256 x 256); 3-D: w=h=d=n; cube: w=h=n, d=6.
  * mips (cubemap only; 0 or 1 for the others): number of mip levels in `data`, packed level after level (level l = 6 faces
  * of (n >> l)^2 texels); 1 = level 0 only; 0 = level 0 given, the rest of the chain generated on the device with the 2x2
  * box filter Image.generate_mipmaps applies to L8 (noise_cubemap.gd:107,135).  Levels above 0 are only read in the
