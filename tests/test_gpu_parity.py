@@ -404,9 +404,17 @@ def test_user_supplied_lut_of_other_size(oracle32):
     node._bake_if_needed()
     node.set_shader_parameter("u_optical_depth_texture", lut)
     got = _gpu_render(node, cam, depth)
-    node.close()
     want, _ = oracle32.render(params, dict(tex, optical_depth=lut), CONFIGS["no_clouds_32_lut"][1], demo_frame(cam), depth, nthreads=4)
     assert np.abs(got - want).max() <= TOL
+    # the footprint copy the kernels sample is addressed with exact fp32 byte offsets: sides up to 1023 texels
+    thin = np.linspace(0.0, 3.0, 1023 * 3, dtype=np.float32).reshape(3, 1023)
+    node.set_shader_parameter("u_optical_depth_texture", thin)
+    got = _gpu_render(node, cam, depth)
+    want, _ = oracle32.render(params, dict(tex, optical_depth=thin), CONFIGS["no_clouds_32_lut"][1], demo_frame(cam), depth, nthreads=4)
+    assert np.abs(got - want).max() <= TOL
+    with pytest.raises(Exception):
+        node.set_shader_parameter("u_optical_depth_texture", np.zeros((4, 1024), dtype=np.float32))
+    node.close()
 
 
 def test_render_composite_blends_in_place(oracle32):
