@@ -91,6 +91,8 @@ def valu_roofline(pmc, kernel_avg_ms):
         clock = min(SPEC_CLOCK_GHZ, c["GRBM_GUI_ACTIVE"] / 8.0 / pmc["profiled_kernel_ns"])
     floor_spec_ms = cyc_spec / (N_SIMD * SPEC_CLOCK_GHZ * 1e9) * 1e3
     floor_meas_ms = cyc_meas / (N_SIMD * clock * 1e9) * 1e3
+    cyc_strict = m["trans"] * t + max(m["slow"] * slow, m["fast"] * (slow + fast))  # no pairing penalty after transcendentals
+    floor_strict_ms = cyc_strict / (N_SIMD * clock * 1e9) * 1e3
     return {
         "bound": "valu-issue",
         "valu_wave_insts_per_launch": n,
@@ -101,13 +103,18 @@ def valu_roofline(pmc, kernel_avg_ms):
         "issue_floor_measured_ms": floor_meas_ms,
         "frac_vs_spec": floor_spec_ms / kernel_avg_ms,
         "frac_vs_measured": floor_meas_ms / kernel_avg_ms,
+        "issue_floor_measured_no_pairing_penalty_ms": floor_strict_ms,
+        "frac_vs_measured_no_pairing_penalty": floor_strict_ms / kernel_avg_ms,
         "sustained_clock_ghz": clock,
         "issue_costs": {"spec": ISSUE_SPEC, "measured": ISSUE_MEASURED,
                         "source": "tools/valu_issue.hip -> profiles/round2/valu_issue_mi355x.jsonl, valu_issue_set2_mi355x.jsonl; "
                                   "class counters calibrated in profiles/round2/counter_calibration.txt"},
         "note": "frac_vs_spec prices every non-transcendental op at 2 cycles (unreachable: half of the ISA issues in 4); "
-                "frac_vs_measured uses the per-class costs this chip sustains; the rest is occupancy (too few waves per SIMD "
-                "to pair instructions at 1920x1080, see tools/concurrency_probe.py) and lane divergence",
+                "frac_vs_measured uses the per-class costs this chip sustains, including +3.4 cycles per transcendental for "
+                "the fast-class ops that do not pair right after one (measured on clusters of 4-8); kernels that issue them in "
+                "longer clusters pay that less often, so this figure can reach 1.0-1.05 (direct light at 3840x2160) -- "
+                "frac_vs_measured_no_pairing_penalty drops the term and is a strict floor; the rest is the drain at the end of "
+                "a draw (tools/wave_timeline.py) and lane divergence",
     }
 
 
@@ -269,9 +276,24 @@ def time_workload(torch, node, cam, depth, steps, warmup, out=None):
     frame = node.prepare_frame(cam)
     stream = torch.cuda.current_stream().cuda_stream
     dptr, optr = depth.data_ptr(), out.data_ptr()
+    # W untimed steps; whatever W is, the context is primed outside the timed region (lazy LUT bake, feedback buffers,
+    # and -- after the synchronisation -- the first heaviest-first tile order): two untimed draws at least
     for _ in range(warmup):
         node.render_prepared(frame, dptr, optr, stream)
     torch.cuda.synchronize()
+    # A frame loop synchronises once per frame (present); this loop does not, so a context would keep the tile order
+    # of its first, cold draws for as long as the host runs ahead of the GPU.  Four more untimed draws, paced like frames,
+    # let the heaviest-first order settle before the timed region (atmo_set_tile_feedback; NOTES.md).
+    for _ in range(4):
+        node.render_prepared(frame, dptr, optr, stream)
+        torch.cuda.synchronize()
+    # ... and the GPU needs ~20 ms of sustained work to reach its sustained clocks in a fresh process (a 20-step run measured
+    # 8 % below a 200-step run otherwise: BENCH_r01 vs README in round 1): keep drawing, untimed, until that much has run
+    t_warm = time.perf_counter()
+    while time.perf_counter() - t_warm < 0.025:
+        for _ in range(8):
+            node.render_prepared(frame, dptr, optr, stream)
+        torch.cuda.synchronize()
     node.set_timing(True, every=TIMING_EVERY)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -475,6 +497,18 @@ def main():
             if buf.numel():
                 node.render_prepared(frame, depth.data_ptr(), buf.data_ptr(), stream)
 
+        # untimed, before the W warm-up steps of the timed loop: frame-paced draws so the tile order settles, then ~25 ms
+        # of work so the GPU is at its sustained clocks (see time_workload)
+        prime = torch.empty((max(1, frame.y1 - frame.y0), max(1, frame.x1 - frame.x0), 4), dtype=torch.float32, device=device)
+        for _ in range(4):
+            render_into(prime)
+            torch.cuda.synchronize()
+        t_warm = time.perf_counter()
+        while time.perf_counter() - t_warm < 0.025:
+            for _ in range(8):
+                render_into(prime)
+            torch.cuda.synchronize()
+        del prime
         node_timing = (lambda: node.set_timing(True, every=TIMING_EVERY), node.get_timing)
         dt_max, launches, kernel_ms = timed_loop_distributed(
             torch, dist, render_into, h, w, device, args.steps, args.warmup, args.gather, node_timing, bands=bands)
@@ -586,6 +620,11 @@ def bench_config4(torch, dist, S, textures, params, local_rank, rank, world, ste
     def render_into(buf):
         node.render_prepared(frame, depth.data_ptr(), buf.data_ptr(), stream)
 
+    prime = torch.empty((h, w, 4), dtype=torch.float32, device=device)
+    for _ in range(6):  # frame-paced, untimed: lets the heaviest-first tile order settle (see time_workload)
+        render_into(prime)
+        torch.cuda.synchronize()
+    del prime
     out = {}
     for mode in ("every", "none"):
         timing = (lambda: node.set_timing(True, every=TIMING_EVERY), node.get_timing)

@@ -855,8 +855,9 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
             ctx->fb_pending = false;
         }
         if (ctx->fb_active >= 0) rc.tile_order = (const uint32_t *)ctx->tile_order[ctx->fb_active].ptr;
-        // the first draws record back to back (the order settles in a few frames), then every period-th
-        fb_record = !ctx->fb_pending && (ctx->fb_n < 4 || ctx->fb_n - ctx->fb_last_record >= period);
+        // the first two draws of a grid are not measured (cold clocks and caches rank the tiles poorly); the next four
+        // record back to back (the order settles in a few frames), then every period-th
+        fb_record = !ctx->fb_pending && ctx->fb_n >= 2 && (ctx->fb_n < 6 || ctx->fb_n - ctx->fb_last_record >= period);
         if (fb_record) rc.tile_cost = (uint32_t *)ctx->tile_cost[0].ptr;
     }
     // kernel timing brackets the draw kernel alone (the tile-order kernel runs beside the previous draw).  The event pair
