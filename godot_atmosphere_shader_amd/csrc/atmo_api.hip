@@ -849,10 +849,14 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
             ctx->fb_write = 0;
             ctx->fb_pending = false;
         }
-        if (ctx->fb_pending && hipEventQuery(ctx->fb_ev_order[ctx->fb_write]) == hipSuccess) {
-            ctx->fb_active = ctx->fb_write;  // complete: no stream-side wait needed
-            ctx->fb_write ^= 1;
-            ctx->fb_pending = false;
+        if (ctx->fb_pending) {
+            if (hipEventQuery(ctx->fb_ev_order[ctx->fb_write]) == hipSuccess) {
+                ctx->fb_active = ctx->fb_write;  // complete: no stream-side wait needed
+                ctx->fb_write ^= 1;
+                ctx->fb_pending = false;
+            } else {
+                (void)hipGetLastError();  // hipErrorNotReady is an answer, not an error: keep it out of the launch checks below
+            }
         }
         if (ctx->fb_active >= 0) rc.tile_order = (const uint32_t *)ctx->tile_order[ctx->fb_active].ptr;
         // the first two draws of a grid are not measured (cold clocks and caches rank the tiles poorly); the next four
