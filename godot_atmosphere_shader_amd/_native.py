@@ -15,16 +15,21 @@ VARIANT_V1_NO_CLOUDS, VARIANT_V1_CLOUDS, VARIANT_V1_CLOUDS_HIGH = 4, 5, 6
 LIGHT_LUT, LIGHT_DIRECT = 0, 1
 TEX_2D_R32F, TEX_2D_R8, TEX_3D_R8, TEX_CUBE_R8 = range(4)
 MEM_HOST, MEM_DEVICE = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
-# every symbol include/atmo.h declares
-EXPORTED_SYMBOLS = (
-    "atmo_abi_version", "atmo_device_count", "atmo_create", "atmo_destroy", "atmo_set_param_f32",
-    "atmo_get_param_f32", "atmo_set_texture", "atmo_get_texture_size", "atmo_set_sampler_lod", "atmo_host_cubemap_mip", "atmo_read_texture_layout", "atmo_generate_noise_cubemap", "atmo_bake_optical_depth", "atmo_read_optical_depth",
-    "atmo_render", "atmo_render_composite", "atmo_set_precision", "atmo_set_host_double_precision", "atmo_set_lane_split", "atmo_set_tile_feedback", "atmo_set_timing", "atmo_get_timing", "atmo_selftest_exact_math", "atmo_host_layout_cubemap",
-    "atmo_host_layout_shape", "atmo_host_layout_lut", "atmo_kernel_name",
-    "atmo_last_error_string",
+# every symbol include/atmo.h declares: the surface a host binds (each replaces a reference interface)
+CORE_SYMBOLS = (
+    "atmo_abi_version", "atmo_device_count", "atmo_create", "atmo_destroy", "atmo_set_param_f32", "atmo_get_param_f32",
+    "atmo_set_texture", "atmo_get_texture_size", "atmo_set_sampler_lod", "atmo_bake_optical_depth",
+    "atmo_generate_noise_cubemap", "atmo_read_optical_depth", "atmo_render", "atmo_render_composite", "atmo_set_precision",
+    "atmo_set_host_double_precision", "atmo_set_tile_feedback", "atmo_last_error_string",
 )
+# every symbol include/atmo_debug.h declares: experiment knobs and diagnostics (tests, bench.py, tools/)
+DEBUG_SYMBOLS = (
+    "atmo_set_lane_split", "atmo_set_timing", "atmo_get_timing", "atmo_host_layout_cubemap", "atmo_host_layout_shape",
+    "atmo_host_layout_lut", "atmo_host_cubemap_mip", "atmo_read_texture_layout", "atmo_selftest_exact_math", "atmo_kernel_name",
+)
+EXPORTED_SYMBOLS = CORE_SYMBOLS + DEBUG_SYMBOLS
 
 
 class AtmoFrame(C.Structure):

@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # ATMO_HIP_LIB: load a differently-built library instead (A/B experiments on compiler flags; see tools/ab_build.sh)
 LIB_PATH = os.environ.get("ATMO_HIP_LIB") or os.path.join(_HERE, "libatmo_hip.so")
 SOURCES = ["atmo_api.hip", "atmo_kernels.hip"]
-HEADERS = ["atmo_device.h", os.path.join("..", "..", "include", "atmo.h")]
+HEADERS = ["atmo_device.h", "atmo_layout.h", os.path.join("..", "..", "include", "atmo.h"), os.path.join("..", "..", "include", "atmo_debug.h")]
 
 # -ffp-contract=off: the kernels and the host-side per-frame constants must round exactly like a scalar
 # fp32 evaluation of the shader wherever control flow or the ill-conditioned cloud chain is involved;

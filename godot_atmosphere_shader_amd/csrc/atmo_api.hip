@@ -6,6 +6,7 @@
 // fused), and enqueues the gfx950 kernels of atmo_kernels.hip.  There is no CPU fallback: without a
 // HIP device every compute entry point fails with ATMO_E_NO_DEVICE / ATMO_E_HIP.
 #include "../../include/atmo.h"
+#include "../../include/atmo_debug.h"
 #include "atmo_device.h"
 #include "atmo_layout.h"
 
@@ -113,20 +114,40 @@ struct AtmoContext {
     int last_flags = -1;
     // tile order with cost feedback (atmo_set_tile_feedback): -1 = default (on), 0 off, 1 on
     int tile_feedback = -1;
-    DeviceBuffer tile_cost[2], tile_order[2];          // one cost buffer ([0]); two orders: the one in use and the one being sorted
+    // One feedback state per (launch grid, lanes per ray, draw stream): a context that alternates between a few rects or
+    // streams (split screen, stereo eyes, uneven row bands) keeps one state for each instead of starting over -- and
+    // synchronising -- at every change.  Buffers are grow-only; a slot is recycled (least recently used) only when a
+    // fifth key appears, and a context that keeps producing new keys stops recycling (fb_thrash) and draws those in
+    // row-major order.
+    struct FeedbackState {
+        bool used = false;
+        int tiles_x = 0, tiles_y = 0, split = 0;
+        hipStream_t draw_stream = nullptr;
+        DeviceBuffer cost, order[2];   // one cost buffer; two orders: the one in use and the one being sorted
+        unsigned n = 0;                // draws of this key so far
+        unsigned last_record = 0;      // n of the last draw that recorded costs
+        int active = -1;               // order[active] is complete and in use; -1: row-major order
+        int write = 0;                 // order[write] is what the next / pending sort writes
+        bool pending = false;          // a sort is in flight on fb_stream
+        hipEvent_t ev_draw = nullptr, ev_order[2] = {nullptr, nullptr};
+        unsigned long long last_use = 0;
+    };
+    static constexpr int FB_SLOTS = 4;
+    FeedbackState fb[FB_SLOTS];
+    unsigned long long fb_clock = 0;
+    int fb_thrash = 0;                                 // consecutive slot recyclings without a state getting used
+    hipStream_t fb_stream = nullptr;                   // the sort kernels run here, beside the draws (high priority)
+    DeviceBuffer fb_scratch;                           // the sort's block histograms (sorts are serialised on fb_stream)
+    unsigned fb_period = 8;                            // every fb_period-th draw of a key records costs
+    // A/B overrides read ONCE, in atmo_create (tools/ab_feedback.sh, tools/ab_bench.sh): ATMO_TILE_FEEDBACK=0/1,
+    // ATMO_TILE_FEEDBACK_PERIOD=n, ATMO_LANE_SPLIT=1/2
+    int env_feedback = -1, env_split = 0;
+    bool drew = false;                                 // a draw of this context has been enqueued ...
+    hipStream_t last_draw_stream = nullptr;            // ... most recently on this stream (texture updates elsewhere wait)
 #ifdef ATMO_WAVE_TRACE
     DeviceBuffer wave_trace;                           // diagnostic build only
     size_t wave_trace_waves = 0;
 #endif
-    int fb_tiles_x = 0, fb_tiles_y = 0, fb_split = 0;  // launch grid the buffers belong to
-    unsigned fb_n = 0;                                 // draws of that grid so far
-    unsigned fb_last_record = 0;                       // fb_n of the last draw that recorded costs
-    int fb_active = -1;                                // tile_order[fb_active] is complete and in use; -1: row-major order
-    int fb_write = 0;                                  // tile_order[fb_write] is what the next / pending sort writes
-    bool fb_pending = false;                           // a sort is in flight on fb_stream
-    hipStream_t fb_draw_stream = nullptr;              // the stream the draws of this grid were enqueued on
-    hipStream_t fb_stream = nullptr;                   // the sort kernel runs here, beside the draw
-    hipEvent_t fb_ev_draw[2] = {nullptr, nullptr}, fb_ev_order[2] = {nullptr, nullptr};
     int timing = 0;          // 0 off; k >= 1: bracket every k-th launch with HIP events
     int launch_counter = 0;
     int timed_launches = 0;
@@ -307,16 +328,13 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
     rc.composite = 0;
 }
 
-// Lanes per ray for one launch (atmo_set_lane_split; ATMO_LANE_SPLIT overrides for A/B runs).  Two lanes per ray double
+// Lanes per ray for one launch (atmo_set_lane_split; ATMO_LANE_SPLIT, read in atmo_create, overrides for A/B runs).  Two lanes per ray double
 // the wave count at the price of a duplicated per-pixel prologue and regrouped view sums; measured on MI355X it pays
 // only where a few very long waves set the kernel time (clouds_high_rm, 1920x1080, pose P_space: -11 %) and costs
 // 5-40 % elsewhere (profiles/round2/ab_lane_split.txt), so "auto" (0) is one lane per ray.
 int choose_split(const AtmoContext *ctx, const AtmoFrame *f) {
     (void)f;
-    if (const char *e = std::getenv("ATMO_LANE_SPLIT")) {
-        if (e[0] == '1') return 1;
-        if (e[0] == '2') return 2;
-    }
+    if (ctx->env_split) return ctx->env_split;
     return ctx->lane_split == 2 ? 2 : 1;
 }
 
@@ -340,6 +358,78 @@ void drain_timing(AtmoContext *ctx, bool only_completed = false) {
         (void)hipEventDestroy(pr.second);
     }
     ctx->pending.swap(keep);
+}
+
+// Grow-only device buffer: reallocates (hipFree = device-wide wait) only when the capacity is too small.
+int dev_reserve(AtmoContext *ctx, DeviceBuffer &b, size_t bytes) {
+    if (b.ptr && b.bytes >= bytes) return ATMO_OK;
+    return dev_alloc(ctx, b, bytes);
+}
+
+// Waits until nothing on the device can still touch the buffers of feedback state `f` (its pending sort; draws on its
+// stream reading an order).  Only needed when the slot is recycled for another key or its buffers must grow.
+int feedback_quiesce(AtmoContext *ctx, AtmoContext::FeedbackState &f, hipStream_t new_stream) {
+    if (f.pending && ctx->fb_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->fb_stream));
+    if (f.n > 0 && f.draw_stream != new_stream) {
+        // the caller may have destroyed that stream since: a device-wide wait needs no handle
+        HIP_TRY(ctx, hipDeviceSynchronize());
+    }
+    f.pending = false;
+    return ATMO_OK;
+}
+
+// The feedback state for draws of a (gx, gy, split) grid on stream s: the cached one, a free slot, or -- at most a few
+// times in a row -- the least recently used slot recycled.  *out stays null when the context is producing new keys faster
+// than states get used (fb_thrash): those draws run in row-major order and nothing waits.
+int feedback_state(AtmoContext *ctx, int gx, int gy, int split, hipStream_t s, AtmoContext::FeedbackState **out) {
+    *out = nullptr;
+    ctx->fb_clock += 1;
+    AtmoContext::FeedbackState *slot = nullptr, *lru = nullptr;
+    for (AtmoContext::FeedbackState &f : ctx->fb) {
+        if (f.used && f.tiles_x == gx && f.tiles_y == gy && f.split == split && f.draw_stream == s) {
+            f.last_use = ctx->fb_clock;
+            *out = &f;
+            return ATMO_OK;
+        }
+        if (!f.used) { if (!slot) slot = &f; }
+        else if (!lru || f.last_use < lru->last_use) lru = &f;
+    }
+    if (!ctx->fb_stream) {
+        int lo = 0, hi = 0;  // numerically lower = higher priority
+        HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->fb_stream, hipStreamNonBlocking, hi));
+        const int rc0 = dev_reserve(ctx, ctx->fb_scratch, atmo::tile_order_scratch_bytes());
+        if (rc0 != ATMO_OK) return rc0;
+    }
+    if (!slot) {
+        if (ctx->fb_thrash >= 8) return ATMO_OK;  // no feedback for this draw
+        ctx->fb_thrash += 1;
+        slot = lru;
+        const int rc0 = feedback_quiesce(ctx, *slot, s);
+        if (rc0 != ATMO_OK) return rc0;
+    }
+    AtmoContext::FeedbackState &f = *slot;
+    const size_t bytes = (size_t)gx * gy * sizeof(uint32_t);
+    // (an unused slot is quiet by construction -- never used, or quiesced when it was released -- so growing may free)
+    int rc1 = dev_reserve(ctx, f.cost, bytes);
+    for (int k = 0; k < 2 && rc1 == ATMO_OK; ++k) rc1 = dev_reserve(ctx, f.order[k], bytes);
+    if (rc1 != ATMO_OK) { f.used = false; return rc1; }
+    if (!f.ev_draw) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&f.ev_draw, hipEventDisableTiming));
+        for (int k = 0; k < 2; ++k) HIP_TRY(ctx, hipEventCreateWithFlags(&f.ev_order[k], hipEventDisableTiming));
+    }
+    HIP_TRY(ctx, hipMemsetAsync(f.cost.ptr, 0, bytes, s));
+    f.used = true;
+    f.tiles_x = gx; f.tiles_y = gy; f.split = split;
+    f.draw_stream = s;
+    f.n = 0;
+    f.last_record = 0;
+    f.active = -1;
+    f.write = 0;
+    f.pending = false;
+    f.last_use = ctx->fb_clock;
+    *out = &f;
+    return ATMO_OK;
 }
 
 }  // namespace
@@ -396,6 +486,11 @@ int atmo_create(int device, int variant, int view_steps, int cloud_steps, int li
     if (light_mode == ATMO_LIGHT_DIRECT && !lite) ctx->flags |= atmo::KF_LIGHT_DIRECT;
     if (lite) ctx->flags |= atmo::KF_LITE;  // the v1 atmosphere reads no optical-depth LUT and has no light march
 
+    // A/B overrides for the tools (tools/ab_feedback.sh, tools/ab_bench.sh): read here, once -- never in the launch path
+    if (const char *ev = std::getenv("ATMO_LANE_SPLIT")) ctx->env_split = ev[0] == '1' ? 1 : (ev[0] == '2' ? 2 : 0);
+    if (const char *ev = std::getenv("ATMO_TILE_FEEDBACK")) ctx->env_feedback = ev[0] == '1' ? 1 : 0;
+    if (const char *ev = std::getenv("ATMO_TILE_FEEDBACK_PERIOD")) { const int v = std::atoi(ev); ctx->fb_period = (unsigned)(v < 1 ? 1 : v); }
+
     // u_blue_noise_texture starts all-zero (jitter 0), like an unset sampler
     int rc = dev_alloc(ctx, ctx->blue, 256 * 256);
     if (rc == ATMO_OK) {
@@ -427,15 +522,16 @@ int atmo_destroy(AtmoContext *ctx) {
     if (ctx->fb_stream) {
         (void)hipStreamSynchronize(ctx->fb_stream);
         (void)hipStreamDestroy(ctx->fb_stream);
+    }
+    for (AtmoContext::FeedbackState &f : ctx->fb) {
+        if (f.ev_draw) (void)hipEventDestroy(f.ev_draw);
         for (int k = 0; k < 2; ++k) {
-            if (ctx->fb_ev_draw[k]) (void)hipEventDestroy(ctx->fb_ev_draw[k]);
-            if (ctx->fb_ev_order[k]) (void)hipEventDestroy(ctx->fb_ev_order[k]);
+            if (f.ev_order[k]) (void)hipEventDestroy(f.ev_order[k]);
+            dev_free(f.order[k]);
         }
+        dev_free(f.cost);
     }
-    for (int k = 0; k < 2; ++k) {
-        dev_free(ctx->tile_cost[k]);
-        dev_free(ctx->tile_order[k]);
-    }
+    dev_free(ctx->fb_scratch);
     delete ctx;
     return ATMO_OK;
 }
@@ -483,12 +579,42 @@ static int stage_texels(AtmoContext *ctx, const void *data, size_t bytes, int me
 // same-size updates overwrite the bound copy in place (stream-ordered); a size change frees it, which waits for the device
 static int tex_alloc(AtmoContext *ctx, DeviceBuffer &b, size_t bytes) { return dev_alloc(ctx, b, bytes); }
 
+// The two device copies of a w x h optical-depth LUT (apron layout + footprints), allocated together: on failure
+// neither stays bound, so no launch ever pairs one copy with the other's stale size.
+static int lut_alloc(AtmoContext *ctx, int w, int h) {
+    int rc = tex_alloc(ctx, ctx->lut, (size_t)(w + 2) * (h + 2) * sizeof(float));
+    if (rc == ATMO_OK) rc = tex_alloc(ctx, ctx->lut4, (size_t)(w + 1) * (h + 1) * 16);
+    if (rc != ATMO_OK) {
+        dev_free(ctx->lut);
+        dev_free(ctx->lut4);
+        ctx->lut_w = ctx->lut_h = 0;
+        return rc;
+    }
+    ctx->lut_w = w; ctx->lut_h = h;
+    return ATMO_OK;
+}
+
 static int tex_updated(AtmoContext *ctx, hipStream_t s) {
     if (!ctx->tex_event) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->tex_event, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventRecord(ctx->tex_event, s));
     ctx->tex_stream = s;
     ctx->tex_pending = true;
     ctx->tex_version += 1;
+    return ATMO_OK;
+}
+
+// In front of every texture update on stream `s`:
+//   * an earlier update on ANOTHER stream is chained in front (hipStreamWaitEvent on its event), so the updates of a
+//     context happen in call order whatever streams they come in on, and a draw on `s` that finds tex_stream == s is
+//     behind all of them;
+//   * draws still reading the bound copy on another stream are waited for on the host (device-wide: the caller may have
+//     destroyed that stream since).  Updates are rare and normally arrive on the draw stream, where stream order is enough.
+static int tex_begin_update(AtmoContext *ctx, hipStream_t s) {
+    if (ctx->tex_pending && ctx->tex_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->tex_event, 0));
+    if (ctx->drew && ctx->last_draw_stream != s) {
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        ctx->drew = false;
+    }
     return ATMO_OK;
 }
 
@@ -520,20 +646,24 @@ int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h,
         // the kernels form the footprint byte offset in fp32: (w + 1) (h + 1) 16 must stay below 2^24
         if (w < 1 || h < 1 || w > 1023 || h > 1023) return fail(ctx, ATMO_E_ARG, "u_optical_depth_texture: each side must be 1..1023 texels (the reference bakes 256 x 256)");
         uint8_t *raw = nullptr;
-        int rc = stage_texels(ctx, data, (size_t)w * h * sizeof(float), memory, s, 0, &raw);
-        if (rc == ATMO_OK) rc = tex_alloc(ctx, ctx->lut, (size_t)(w + 2) * (h + 2) * sizeof(float));
+        int rc = tex_begin_update(ctx, s);
+        if (rc == ATMO_OK) rc = stage_texels(ctx, data, (size_t)w * h * sizeof(float), memory, s, 0, &raw);
+        if (rc == ATMO_OK) rc = lut_alloc(ctx, w, h);  // both copies, before anything is enqueued
         if (rc != ATMO_OK) return rc;
         HIP_TRY(ctx, atmo::launch_layout_lut((const float *)raw, w, h, (float *)ctx->lut.ptr, s));
-        rc = tex_alloc(ctx, ctx->lut4, (size_t)(w + 1) * (h + 1) * 16);
-        if (rc != ATMO_OK) return rc;
         HIP_TRY(ctx, atmo::launch_lut_footprints((const float *)ctx->lut.ptr, w, h, (float *)ctx->lut4.ptr, s));
-        ctx->lut_w = w; ctx->lut_h = h;
         return tex_updated(ctx, s);
     }
     if (std::strcmp(name, "u_blue_noise_texture") == 0) {
-        if (!data) { HIP_TRY(ctx, hipMemsetAsync(ctx->blue.ptr, 0, 256 * 256, s)); return tex_updated(ctx, s); }
+        if (!data) {
+            const int rc0 = tex_begin_update(ctx, s);
+            if (rc0 != ATMO_OK) return rc0;
+            HIP_TRY(ctx, hipMemsetAsync(ctx->blue.ptr, 0, 256 * 256, s));
+            return tex_updated(ctx, s);
+        }
         if (kind != ATMO_TEX_2D_R8) return fail(ctx, ATMO_E_ARG, "u_blue_noise_texture must be ATMO_TEX_2D_R8");
         if (w != 256 || h != 256) return fail(ctx, ATMO_E_ARG, "u_blue_noise_texture must be 256x256 (indexed & 0xff, main:169)");
+        { const int rc0 = tex_begin_update(ctx, s); if (rc0 != ATMO_OK) return rc0; }
         HIP_TRY(ctx, hipMemcpyAsync(ctx->blue.ptr, data, 256 * 256, ck, s));
         return tex_updated(ctx, s);
     }
@@ -542,7 +672,8 @@ int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h,
         if (kind != ATMO_TEX_3D_R8) return fail(ctx, ATMO_E_ARG, "u_cloud_shape_texture must be ATMO_TEX_3D_R8");
         if (w < 1 || w > 512 || h != w || d != w) return fail(ctx, ATMO_E_ARG, "u_cloud_shape_texture must be n x n x n, n <= 512");
         uint8_t *raw = nullptr;
-        int rc = stage_texels(ctx, data, (size_t)w * w * w, memory, s, 0, &raw);
+        int rc = tex_begin_update(ctx, s);
+        if (rc == ATMO_OK) rc = stage_texels(ctx, data, (size_t)w * w * w, memory, s, 0, &raw);
         if (rc == ATMO_OK) rc = tex_alloc(ctx, ctx->shape, (size_t)w * w * w * sizeof(uint32_t));
         if (rc != ATMO_OK) return rc;
         HIP_TRY(ctx, atmo::launch_layout_shape(raw, w, (uint32_t *)ctx->shape.ptr, s));
@@ -558,18 +689,25 @@ int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h,
         const int given = mips == 0 ? 1 : mips;      // levels present in `data`, packed level after level
         const int levels = mips == 0 ? full : mips;  // levels bound afterwards
         size_t given_bytes = 0, chain_bytes = 0, fp_words = 0;
+        uint32_t level_off[16] = {0};
         for (int l = 0; l < levels; ++l) {
             if (l < given) given_bytes += atmo::cube_level_texels(w, l);
             chain_bytes += atmo::cube_level_texels(w, l);
-            ctx->cube_level_off_host[l] = (uint32_t)fp_words;
+            level_off[l] = (uint32_t)fp_words;
             fp_words += atmo::cube_level_footprints(w, l);
         }
         // the texel chain lives in the staging buffer: given levels copied in, missing ones generated behind them
         uint8_t *raw = nullptr;
-        int rc = stage_texels(ctx, data, given_bytes, memory, s, chain_bytes - given_bytes + 1, &raw);
+        int rc = tex_begin_update(ctx, s);
+        if (rc == ATMO_OK) rc = stage_texels(ctx, data, given_bytes, memory, s, chain_bytes - given_bytes + 1, &raw);
         if (rc == ATMO_OK) rc = tex_alloc(ctx, ctx->cube, fp_words * sizeof(uint32_t));
         if (rc == ATMO_OK) rc = dev_alloc(ctx, ctx->cube_level_off, sizeof(ctx->cube_level_off_host));
-        if (rc != ATMO_OK) return rc;
+        if (rc != ATMO_OK) {  // nothing half-bound: the cubemap is unset (= 1.0) until a later update succeeds
+            dev_free(ctx->cube);
+            ctx->cube_n = 0; ctx->cube_levels = 0;
+            return rc;
+        }
+        std::memcpy(ctx->cube_level_off_host, level_off, sizeof(level_off));
         size_t off = 0;
         for (int l = 0; l < levels; ++l) {
             const int nl = w >> l;
@@ -706,11 +844,10 @@ int atmo_bake_optical_depth(AtmoContext *ctx, void *stream) {
     if (!ctx) return ATMO_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int w = 256, h = 256;  // optical_depth_baker.gd:24
-    if (ctx->lut_w != w || ctx->lut_h != h) {
-        int rc = dev_alloc(ctx, ctx->lut, (size_t)(w + 2) * (h + 2) * sizeof(float));  // a size change waits for the device (hipFree)
-        if (rc == ATMO_OK) rc = dev_alloc(ctx, ctx->lut4, (size_t)(w + 1) * (h + 1) * 16);
+    { const int rc0 = tex_begin_update(ctx, (hipStream_t)stream); if (rc0 != ATMO_OK) return rc0; }
+    if (ctx->lut_w != w || ctx->lut_h != h || !ctx->lut.ptr || !ctx->lut4.ptr) {
+        const int rc = lut_alloc(ctx, w, h);  // a size change waits for the device (hipFree)
         if (rc != ATMO_OK) return rc;
-        ctx->lut_w = w; ctx->lut_h = h;
     }
     atmo::BakeConsts bc;
     bc.planet_radius = ctx->p.u_planet_radius;
@@ -772,7 +909,7 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     if (frame->x0 == frame->x1 || frame->y0 == frame->y1) return ATMO_OK;  // empty rect: nothing to shade
     if (!depth_dev || !rgba_dev) return fail(ctx, ATMO_E_ARG, "atmo_render: null device pointer");
     if ((reinterpret_cast<uintptr_t>(rgba_dev) & 15u) != 0) return fail(ctx, ATMO_E_ARG, "atmo_render: rgba_dev must be 16-byte aligned");
-    if (!(ctx->flags & (atmo::KF_LIGHT_DIRECT | atmo::KF_LITE)) && !ctx->lut.ptr)
+    if (!(ctx->flags & (atmo::KF_LIGHT_DIRECT | atmo::KF_LITE)) && !(ctx->lut.ptr && ctx->lut4.ptr))
         return fail(ctx, ATMO_E_STATE, "atmo_render: u_optical_depth_texture not set (call atmo_bake_optical_depth or atmo_set_texture)");
     if ((ctx->flags & atmo::KF_CLOUDS) && !ctx->shape.ptr)
         return fail(ctx, ATMO_E_STATE, "atmo_render: u_cloud_shape_texture not set");
@@ -809,60 +946,35 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     atmo::render_grid(rc, split, &gx, &gy);
     rc.tiles_x = gx;
     // default (-1): on for every variant since the sort no longer costs the draws anything (profiles/round2/ab_tile_feedback.txt)
-    bool feedback = ctx->tile_feedback != 0;
-    if (const char *e = std::getenv("ATMO_TILE_FEEDBACK")) feedback = e[0] == '1';  // A/B runs
+    bool feedback = ctx->env_feedback >= 0 ? ctx->env_feedback != 0 : ctx->tile_feedback != 0;
+    if (feedback && (long long)gx * gy < 512) feedback = false;  // tiny launches: nothing to schedule
     if (feedback) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) feedback = false;  // no side-stream work inside a graph
     }
-    // Every `period`-th draw records the wave durations per tile; a sort on the side stream turns them into the next
+    // Every fb_period-th draw records the wave durations per tile; a sort on the side stream turns them into the next
     // order, which later draws pick up once a host-side event query says it is complete: no draw ever waits for a sort.
     bool fb_record = false;
-    if (feedback && (long long)gx * gy >= 512) {  // tiny launches: nothing to schedule
-        const size_t bytes = (size_t)gx * gy * sizeof(uint32_t);
-        static const unsigned period = [] { const char *e = std::getenv("ATMO_TILE_FEEDBACK_PERIOD"); int v = e ? std::atoi(e) : 8; return (unsigned)(v < 1 ? 1 : v); }();
-        if (ctx->fb_tiles_x != gx || ctx->fb_tiles_y != gy || ctx->fb_split != split || !ctx->tile_cost[0].ptr || ctx->fb_draw_stream != s) {
-            // first launch of this grid (or the caller moved to another stream): drain, allocate once, start over
-            if (!ctx->fb_stream) {
-                HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->fb_stream, hipStreamNonBlocking));
-                for (int k = 0; k < 2; ++k) {
-                    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fb_ev_draw[k], hipEventDisableTiming));
-                    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fb_ev_order[k], hipEventDisableTiming));
-                }
-            }
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->fb_stream));
-            if (ctx->fb_draw_stream != s && ctx->fb_n > 0) {  // draws on the old stream may still read an order
-                if (hipStreamSynchronize(ctx->fb_draw_stream) != hipSuccess) {  // the caller may have destroyed that stream
-                    (void)hipGetLastError();
-                    HIP_TRY(ctx, hipDeviceSynchronize());
-                }
-            }
-            int rc1 = dev_alloc(ctx, ctx->tile_cost[0], bytes);
-            for (int k = 0; k < 2 && rc1 == ATMO_OK; ++k) rc1 = dev_alloc(ctx, ctx->tile_order[k], bytes);
-            if (rc1 != ATMO_OK) return rc1;
-            HIP_TRY(ctx, hipMemsetAsync(ctx->tile_cost[0].ptr, 0, bytes, s));
-            ctx->fb_tiles_x = gx; ctx->fb_tiles_y = gy; ctx->fb_split = split;
-            ctx->fb_draw_stream = s;
-            ctx->fb_n = 0;
-            ctx->fb_last_record = 0;
-            ctx->fb_active = -1;
-            ctx->fb_write = 0;
-            ctx->fb_pending = false;
-        }
-        if (ctx->fb_pending) {
-            if (hipEventQuery(ctx->fb_ev_order[ctx->fb_write]) == hipSuccess) {
-                ctx->fb_active = ctx->fb_write;  // complete: no stream-side wait needed
-                ctx->fb_write ^= 1;
-                ctx->fb_pending = false;
+    AtmoContext::FeedbackState *fb = nullptr;
+    if (feedback) {
+        const int rc1 = feedback_state(ctx, gx, gy, split, s, &fb);
+        if (rc1 != ATMO_OK) return rc1;
+    }
+    if (fb) {
+        if (fb->pending) {
+            if (hipEventQuery(fb->ev_order[fb->write]) == hipSuccess) {
+                fb->active = fb->write;  // complete: no stream-side wait needed
+                fb->write ^= 1;
+                fb->pending = false;
             } else {
                 (void)hipGetLastError();  // hipErrorNotReady is an answer, not an error: keep it out of the launch checks below
             }
         }
-        if (ctx->fb_active >= 0) rc.tile_order = (const uint32_t *)ctx->tile_order[ctx->fb_active].ptr;
-        // the first two draws of a grid are not measured (cold clocks and caches rank the tiles poorly); the next four
-        // record back to back (the order settles in a few frames), then every period-th
-        fb_record = !ctx->fb_pending && ctx->fb_n >= 2 && (ctx->fb_n < 6 || ctx->fb_n - ctx->fb_last_record >= period);
-        if (fb_record) rc.tile_cost = (uint32_t *)ctx->tile_cost[0].ptr;
+        if (fb->active >= 0) rc.tile_order = (const uint32_t *)fb->order[fb->active].ptr;
+        // the first two draws of a key are not measured (cold clocks and caches rank the tiles poorly); the next four
+        // record back to back (the order settles in a few frames), then every fb_period-th
+        fb_record = !fb->pending && fb->n >= 2 && (fb->n < 6 || fb->n - fb->last_record >= ctx->fb_period);
+        if (fb_record) rc.tile_cost = (uint32_t *)fb->cost.ptr;
     }
     // kernel timing brackets the draw kernel alone (the tile-order kernel runs beside the previous draw).  The event pair
     // is owned by a guard until it is handed to ctx->pending, so no error path leaks it.
@@ -896,15 +1008,21 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     ctx->last_flags = flags;
     if (fb_record) {
         // Sort on the side stream as soon as this draw is done (the sort also clears the costs for the next recording).
-        // tile_order[fb_write] was last read by draws enqueued on `s` before this one, so the event orders the write too.
-        HIP_TRY(ctx, hipEventRecord(ctx->fb_ev_draw[0], s));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->fb_stream, ctx->fb_ev_draw[0], 0));
-        HIP_TRY(ctx, atmo::launch_tile_order((uint32_t *)ctx->tile_cost[0].ptr, (uint32_t *)ctx->tile_order[ctx->fb_write].ptr, gx * gy, ctx->fb_stream));
-        HIP_TRY(ctx, hipEventRecord(ctx->fb_ev_order[ctx->fb_write], ctx->fb_stream));
-        ctx->fb_pending = true;
-        ctx->fb_last_record = ctx->fb_n;
+        // order[write] was last read by draws enqueued on `s` before this one, so the event orders the write too.
+        HIP_TRY(ctx, hipEventRecord(fb->ev_draw, s));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->fb_stream, fb->ev_draw, 0));
+        HIP_TRY(ctx, atmo::launch_tile_order((uint32_t *)fb->cost.ptr, (uint32_t *)fb->order[fb->write].ptr, gx * gy,
+                                             (uint32_t *)ctx->fb_scratch.ptr, ctx->fb_stream));
+        HIP_TRY(ctx, hipEventRecord(fb->ev_order[fb->write], ctx->fb_stream));
+        fb->pending = true;
+        fb->last_record = fb->n;
     }
-    if (feedback && (long long)gx * gy >= 512) ctx->fb_n += 1;
+    if (fb) {
+        fb->n += 1;
+        if (fb->n >= 16) ctx->fb_thrash = 0;  // this state is being used, not just created
+    }
+    ctx->drew = true;
+    ctx->last_draw_stream = s;
     ctx->last_split = split;
     ctx->launch_counter += 1;  // counted only once the launch was accepted
     if (timed) {
@@ -933,7 +1051,19 @@ int atmo_set_tile_feedback(AtmoContext *ctx, int mode) {
     if (!ctx) return ATMO_E_ARG;
     if (mode < -1 || mode > 1) return fail(ctx, ATMO_E_ARG, "atmo_set_tile_feedback: -1 (by variant), 0 (off) or 1 (on)");
     ctx->tile_feedback = mode;
-    ctx->fb_tiles_x = ctx->fb_tiles_y = 0;  // restart the feedback state at the next launch
+    // restart every feedback state at its next launch (buffers are kept; a device-wide wait makes the slots quiet)
+    bool busy = false;
+    for (AtmoContext::FeedbackState &f : ctx->fb) busy = busy || (f.used && f.n > 0);
+    if (busy) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipDeviceSynchronize());
+    }
+    for (AtmoContext::FeedbackState &f : ctx->fb) {
+        f.used = false;
+        f.pending = false;
+        f.n = 0;
+    }
+    ctx->fb_thrash = 0;
     return ATMO_OK;
 }
 
@@ -944,11 +1074,11 @@ int atmo_set_lane_split(AtmoContext *ctx, int lanes_per_ray) {
     return ATMO_OK;
 }
 
-int atmo_set_timing(AtmoContext *ctx, int enable) {
+int atmo_set_timing(AtmoContext *ctx, int every_kth) {
     if (!ctx) return ATMO_E_ARG;
     (void)hipSetDevice(ctx->device);
     drain_timing(ctx);
-    ctx->timing = enable > 0 ? enable : 0;
+    ctx->timing = every_kth > 0 ? every_kth : 0;
     ctx->launch_counter = 0;
     ctx->timed_launches = 0;
     ctx->timed_ms = 0.0;

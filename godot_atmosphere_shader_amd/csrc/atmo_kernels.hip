@@ -364,9 +364,11 @@ __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, in
     const int stride = n + 1;
 #if ATMO_CUBE_FLOAT_INDEX && ATMO_BUFFER_LOADS && !ATMO_ABLATE_FETCH
     if (n <= 1024) {
-        // byte offset ((face * stride + j) * stride + i) * 4, i = clamp(xf, -1, n-1) + 1, formed in fp32 (exact below 2^24:
-        // 6 (n+1)^2 * 4 < 2^24 up to n = 1024): 2 med3 + 3 FMA + 1 conversion instead of 3 conversions, 4 integer
-        // min/max, a 64-bit multiply-add, a multiply, an add and a shift-add
+        // byte offset ((face * stride + j) * stride + i) * 4, i = clamp(xf, -1, n-1) + 1, formed in fp32.  Exact although the
+        // largest offset, 6 (n+1)^2 * 4 = 25.2 M at n = 1024, exceeds 2^24: every term and every partial sum of the three FMAs
+        // is an integer multiple of 4 below 2^26, i.e. 4 x (an integer below 2^24), and those are all representable.
+        // 2 med3 + 3 FMA + 1 conversion instead of 3 conversions, 4 integer min/max, a 64-bit multiply-add, a multiply, an
+        // add and a shift-add
         const float nm1 = (float)(n - 1), s4 = (float)(stride * 4);
         const float ic = __builtin_amdgcn_fmed3f(xf, -1.0f, nm1), jc = __builtin_amdgcn_fmed3f(yf, -1.0f, nm1);
         const uint32_t off = (uint32_t)fmaf(fid, s4 * (float)stride, fmaf(jc, s4, fmaf(ic, 4.0f, s4 + 4.0f)));
@@ -963,7 +965,7 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
 //     evaluates the 6-tap light for THAT sample and multiplies it into the slot;
 //   phase C, end of the chunk: every lane adds its slots in step order.
 // Per ray the arithmetic is fixed (own slots, step order), so the picture does not depend on which rays share a wave.
-// LDS per wave: 5 x 128 queue words + 16 x 64 slots = 6.5 KB (26 KB per workgroup).
+// LDS per wave: 5 x 128 queue words + 16 x 64 slots = 6.5 KB (13 KB per 2-wave workgroup).
 #ifndef ATMO_RM_QUEUE
 #define ATMO_RM_QUEUE 1
 #endif
@@ -1348,45 +1350,67 @@ __global__ __launch_bounds__(TILE_W *TILE_H ATMO_MIN_WAVES_ARG) ATMO_SGPR_ATTR v
     }
 }
 
-// Stable counting sort of the tiles by the cost the previous launch recorded, heaviest class first; clears the costs
-// for the next launch.  32 classes = half octaves of the wave duration (2^8 .. 2^24 cycles); tiles of one class keep
-// their row-major order, so neighbouring tiles -- which share texture footprints in L1/L2 -- still run together.
-// One workgroup of 512 threads: every thread owns a contiguous chunk of tiles (read 16 at a time with independent
-// loads) and a private column of counters in LDS (no atomics); the 32 x 512 counters are scanned per class with wave
-// shuffles; then every thread scatters its chunk in order.  ~5 us for the 8 160 tiles of a 1920x1080 launch.
-constexpr int ORDER_THREADS = 512, ORDER_CLASSES = 32, ORDER_BATCH = 16;
+// Stable counting sort of the tiles by the cost a recording draw measured, heaviest class first; clears the costs for
+// the next recording.  32 classes = half octaves of the wave duration (2^8 .. 2^24 cycles); tiles of one class keep their
+// row-major order, so neighbouring tiles -- which share texture footprints in L1/L2 -- still run together.
+// Three small kernels on the context's high-priority side stream (round 3; the round-2 form was ONE 512-thread workgroup
+// with 64 KB of LDS that had to find a free CU beside the draw it runs next to: 33 us at best, 52-713 us on average --
+// that latency is feedback lag when the camera moves):
+//   histogram  256 single-wave workgroups, each owns a contiguous chunk of tiles and counts its 32 classes (wave ballots);
+//   scan       one workgroup turns the 256 x 32 counts into the first output index of every (chunk, class);
+//   scatter    the 256 waves write their tiles, in order, behind those indices and clear the costs.
+constexpr int ORDER_BLOCKS = 256, ORDER_CLASSES = 32;
 __device__ __forceinline__ uint32_t tile_cost_class(uint32_t c) {
     if (c == 0) return ORDER_CLASSES - 1;
     const int msb = 31 - __builtin_clz(c);
     const int q = msb * 2 + (msb > 0 ? (int)((c >> (msb - 1)) & 1u) : 0) - 16;
     return (uint32_t)(ORDER_CLASSES - 1 - (q < 0 ? 0 : (q > ORDER_CLASSES - 1 ? ORDER_CLASSES - 1 : q)));
 }
+// lanes of this wave whose 5-bit key equals mine (inactive lanes excluded by `valid`)
+__device__ __forceinline__ unsigned long long match_class(uint32_t key, bool valid) {
+    unsigned long long m = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll
+    for (int bit = 0; bit < 5; ++bit) {
+        const bool one = (key >> bit) & 1u;
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(one);
+        m &= one ? b : ~b;
+    }
+    return m;
+}
+__device__ __forceinline__ int lanes_below(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 
-__global__ __launch_bounds__(ORDER_THREADS) void atmo_tile_order_kernel(uint32_t *__restrict__ cost, uint32_t *__restrict__ order, int n) {
-    __shared__ uint32_t cnt[ORDER_CLASSES][ORDER_THREADS];
-    __shared__ uint32_t base[ORDER_CLASSES];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int chunk = (n + ORDER_THREADS - 1) / ORDER_THREADS;
-    const int i0 = min(t * chunk, n), i1 = min(i0 + chunk, n);
-#pragma unroll
-    for (int b = 0; b < ORDER_CLASSES; ++b) cnt[b][t] = 0;
-    for (int i = i0; i < i1; i += ORDER_BATCH) {
-        uint32_t c[ORDER_BATCH];
-#pragma unroll
-        for (int k = 0; k < ORDER_BATCH; ++k) c[k] = (i + k < i1) ? cost[i + k] : 0u;
-#pragma unroll
-        for (int k = 0; k < ORDER_BATCH; ++k)
-            if (i + k < i1) cnt[tile_cost_class(c[k])][t] += 1;
+__global__ __launch_bounds__(64) void atmo_tile_hist_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ hist, int n) {
+    __shared__ uint32_t cnt[ORDER_CLASSES];
+    const int lane = threadIdx.x, chunk = (n + ORDER_BLOCKS - 1) / ORDER_BLOCKS;
+    const int i0 = min((int)blockIdx.x * chunk, n), i1 = min(i0 + chunk, n);
+    if (lane < ORDER_CLASSES) cnt[lane] = 0;
+    __syncthreads();
+    for (int i = i0; i < i1; i += 64) {
+        const bool valid = i + lane < i1;
+        const uint32_t c = valid ? tile_cost_class(cost[i + lane]) : 0u;
+        const unsigned long long m = match_class(c, valid);
+        if (valid && lanes_below(m) == 0) cnt[c] += (uint32_t)__builtin_popcountll(m);  // one lane per class present
     }
     __syncthreads();
-    // exclusive scan of each class's 512 counters: 8 waves x 4 classes, 8 counters per lane + a wave scan
-    constexpr int PER_LANE = ORDER_THREADS / 64, PER_WAVE = ORDER_CLASSES / (ORDER_THREADS / 64);
-    for (int b = wave * PER_WAVE; b < (wave + 1) * PER_WAVE; ++b) {
-        uint32_t local[PER_LANE], sum = 0;
+    if (lane < ORDER_CLASSES) hist[blockIdx.x * ORDER_CLASSES + lane] = cnt[lane];
+}
+
+// hist[block][class] -> first output index of (block, class): classes in order 0 (heaviest) .. 31, blocks in order inside a class
+__global__ __launch_bounds__(256) void atmo_tile_scan_kernel(uint32_t *__restrict__ hist) {
+    __shared__ uint32_t total[ORDER_CLASSES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int PER_LANE = ORDER_BLOCKS / 64, PER_WAVE = ORDER_CLASSES / 4;
+    uint32_t excl_keep[PER_WAVE][PER_LANE];
+#pragma unroll
+    for (int q = 0; q < PER_WAVE; ++q) {
+        const int c = wave * PER_WAVE + q;
+        uint32_t sum = 0;
 #pragma unroll
         for (int k = 0; k < PER_LANE; ++k) {
-            local[k] = sum;
-            sum += cnt[b][lane * PER_LANE + k];
+            excl_keep[q][k] = sum;
+            sum += hist[(lane * PER_LANE + k) * ORDER_CLASSES + c];
         }
         uint32_t incl = sum;
 #pragma unroll
@@ -1394,40 +1418,60 @@ __global__ __launch_bounds__(ORDER_THREADS) void atmo_tile_order_kernel(uint32_t
             const uint32_t x = __shfl_up(incl, d);
             if (lane >= d) incl += x;
         }
-        const uint32_t excl = incl - sum;
 #pragma unroll
-        for (int k = 0; k < PER_LANE; ++k) cnt[b][lane * PER_LANE + k] = excl + local[k];
-        if (lane == 63) base[b] = incl;
+        for (int k = 0; k < PER_LANE; ++k) excl_keep[q][k] += incl - sum;
+        if (lane == 63) total[c] = incl;
     }
     __syncthreads();
-    if (t < 64) {  // exclusive scan of the 32 class totals
-        const uint32_t c = t < ORDER_CLASSES ? base[t] : 0u;
+    if (threadIdx.x < 64) {  // exclusive scan of the 32 class totals
+        const uint32_t c = lane < ORDER_CLASSES ? total[lane] : 0u;
         uint32_t incl = c;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t x = __shfl_up(incl, d);
             if (lane >= d) incl += x;
         }
-        if (t < ORDER_CLASSES) base[t] = incl - c;
+        if (lane < ORDER_CLASSES) total[lane] = incl - c;
     }
     __syncthreads();
-    for (int i = i0; i < i1; i += ORDER_BATCH) {
-        uint32_t c[ORDER_BATCH];
 #pragma unroll
-        for (int k = 0; k < ORDER_BATCH; ++k) c[k] = (i + k < i1) ? cost[i + k] : 0u;
+    for (int q = 0; q < PER_WAVE; ++q) {
+        const int c = wave * PER_WAVE + q;
 #pragma unroll
-        for (int k = 0; k < ORDER_BATCH; ++k)
-            if (i + k < i1) {
-                const uint32_t b = tile_cost_class(c[k]);
-                order[base[b] + cnt[b][t]] = (uint32_t)(i + k);
-                cnt[b][t] += 1;
-                cost[i + k] = 0;
-            }
+        for (int k = 0; k < PER_LANE; ++k) hist[(lane * PER_LANE + k) * ORDER_CLASSES + c] = total[c] + excl_keep[q][k];
     }
 }
 
-hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int n, hipStream_t stream) {
-    hipLaunchKernelGGL(atmo_tile_order_kernel, dim3(1), dim3(ORDER_THREADS), 0, stream, cost, order, n);
+__global__ __launch_bounds__(64) void atmo_tile_scatter_kernel(uint32_t *__restrict__ cost, const uint32_t *__restrict__ base,
+                                                               uint32_t *__restrict__ order, int n) {
+    __shared__ uint32_t off[ORDER_CLASSES];
+    const int lane = threadIdx.x, chunk = (n + ORDER_BLOCKS - 1) / ORDER_BLOCKS;
+    const int i0 = min((int)blockIdx.x * chunk, n), i1 = min(i0 + chunk, n);
+    if (lane < ORDER_CLASSES) off[lane] = base[blockIdx.x * ORDER_CLASSES + lane];
+    __syncthreads();
+    for (int i = i0; i < i1; i += 64) {
+        const bool valid = i + lane < i1;
+        const uint32_t c = valid ? tile_cost_class(cost[i + lane]) : 0u;
+        const unsigned long long m = match_class(c, valid);
+        const int r = lanes_below(m);
+        uint32_t pos = 0;
+        if (valid) pos = off[c] + (uint32_t)r;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (valid && r == 0) off[c] += (uint32_t)__builtin_popcountll(m);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (valid) {
+            order[pos] = (uint32_t)(i + lane);
+            cost[i + lane] = 0;
+        }
+    }
+}
+
+// scratch: ORDER_BLOCKS * ORDER_CLASSES uint32 (tile_order_scratch_bytes)
+size_t tile_order_scratch_bytes() { return (size_t)ORDER_BLOCKS * ORDER_CLASSES * sizeof(uint32_t); }
+hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int n, uint32_t *scratch, hipStream_t stream) {
+    hipLaunchKernelGGL(atmo_tile_hist_kernel, dim3(ORDER_BLOCKS), dim3(64), 0, stream, cost, scratch, n);
+    hipLaunchKernelGGL(atmo_tile_scan_kernel, dim3(1), dim3(256), 0, stream, scratch);
+    hipLaunchKernelGGL(atmo_tile_scatter_kernel, dim3(ORDER_BLOCKS), dim3(64), 0, stream, cost, scratch, order, n);
     return hipGetLastError();
 }
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ATMO_ABI_VERSION 2
+#define ATMO_ABI_VERSION 3
 
 typedef struct AtmoContext AtmoContext;
 
@@ -120,9 +120,11 @@ int atmo_get_param_f32(AtmoContext *ctx, const char *name, float *v, int n);
  * box filter Image.generate_mipmaps applies to L8 (noise_cubemap.gd:107,135).  Levels above 0 are only read in the
  * implicit-LOD sampler mode (atmo_set_sampler_lod).
  * The copy and the re-layout into the kernels' footprint layouts are enqueued on `stream` (hipStream_t, NULL = default
- * stream) and draws of this context on other streams wait for them; nothing waits on the host except a copy from
- * pageable host memory and the re-allocation when a texture changes size.  Updates of one context must not overlap
- * draws that are still reading the previous copy on ANOTHER stream (same-stream order is enough).
+ * stream).  Updates of one context take effect in call order whatever streams they arrive on (a later update is chained
+ * behind an earlier one's event), and draws on other streams wait for them (stream-side).  Nothing waits on the host
+ * except: a copy from pageable host memory; the re-allocation when a texture changes size; and an update that arrives
+ * on a stream OTHER than the one the context last drew on, which waits for the device first (draws may still be reading
+ * the bound copy there) -- send updates down the draw stream and stream order is all there is.
  */
 int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h, int d, int mips,
                      const void *data, int memory, void *stream);
@@ -137,7 +139,8 @@ int atmo_get_texture_size(AtmoContext *ctx, const char *name, int *w, int *h, in
  * fragment pipeline's derivatives are), transforms them to the selected face (Vulkan 1.3 cube-map derivative
  * transformation), lambda = log2(max(rho_x, rho_y)) clamped to the bound levels, and the sample is the linear mix of
  * the seamless bilinear samples of the two nearest levels.  Needs a mip chain (atmo_set_texture mips != 1); exact rule
- * in oracle/atmo_oracle.h.  The quad exchange of ray parameters uses DPP quad_perm moves.
+ * in oracle/atmo_oracle.h.  The two quad partners' rays are recomputed by every lane (not exchanged across lanes), so the
+ * picture does not depend on which pixels share a wavefront or on the launch rect.
  */
 int atmo_set_sampler_lod(AtmoContext *ctx, int mode);
 
@@ -207,15 +210,6 @@ int atmo_set_precision(AtmoContext *ctx, int mode);
 int atmo_set_host_double_precision(AtmoContext *ctx, int enable);
 
 /*
- * Launch shape (no reference counterpart): lanes per view ray.  1 = one wavefront lane per ray (64 rays per wave);
- * 2 = two adjacent lanes share a ray (32 rays per wave: each lane takes every second cloud sample / half of the view
- * samples, results cross by DPP) -- twice the waves for the same frame; the cloud march is the same bits, the
- * atmosphere sums agree within rounding.  It pays only for small launches dominated by a few very long waves
- * (clouds_high_rm at 1920x1080: -11 %), so 0 (default, "auto") currently means 1.
- */
-int atmo_set_lane_split(AtmoContext *ctx, int lanes_per_ray);
-
-/*
  * Launch order (no reference counterpart): with feedback on, every 8th draw (the first four back to back) records how
  * long each pixel tile's waves ran; a small sort kernel on a side stream turns those costs into a tile order, heaviest
  * tiles first (longest-processing-time-first list scheduling), and later draws pick it up once the host sees the sort
@@ -224,45 +218,12 @@ int atmo_set_lane_split(AtmoContext *ctx, int lanes_per_ray);
  * miss the planet, clear sky) into that drain: direct light 32x8 +9.7 %, clouds_high +5 %, clouds_high_rm +49 %
  * (its heaviest tiles are ~10x the mean), baked-LUT atmosphere +4..5 %; within +-1.5 % on frames whose tiles all weigh
  * the same (profiles/round2/ab_tile_feedback.txt).  The picture does not depend on the order.
- * -1 (default) = on; 0 = off; 1 = on.  Launches inside a HIP graph capture never use it.  The per-grid buffers are
- * allocated by the first launch of a grid size (synchronously); draws of one context are expected on one stream (moving
- * to another stream drains the old one once).
+ * -1 (default) = on; 0 = off; 1 = on.  Launches inside a HIP graph capture never use it.  A context keeps one feedback
+ * state per (launch grid, draw stream) it sees, up to four (split screen, stereo eyes, uneven row bands), each allocated by
+ * the first launch of its key; a fifth key recycles the least recently used state (which waits for that state's work),
+ * and a context that keeps producing new keys stops recycling and draws them in row-major order.
  */
 int atmo_set_tile_feedback(AtmoContext *ctx, int mode);
-
-/* Device time of `atmo_render` kernels measured with HIP events recorded around the launch on its own stream:
- * atmo_set_timing(ctx, k): k = 0 off, k >= 1 brackets every k-th launch (k > 1 keeps the ~5 us cost of recording two
- * events out of most steps); atmo_get_timing returns the number of bracketed launches and their total milliseconds
- * since enabling (it waits for them). */
-int atmo_set_timing(AtmoContext *ctx, int enable);
-int atmo_get_timing(AtmoContext *ctx, int *launches, double *total_ms);
-
-/*
- * Host-only helpers (no device, no context): the device layouts atmo_set_texture builds, exposed so they can be
- * checked without a GPU.  cubemap: 6*(n+1)^2 words, word (i,j) of a face = the 2x2 texels of the seamless-apron
- * padded face starting at padded (i,j), bytes 0..3 = (i,j),(i+1,j),(i,j+1),(i+1,j+1).  shape: n^3 words, word
- * (i,j,k) = T(i,j,k),T(i+1,j,k),T(i,j+1,k),T(i+1,j+1,k) with repeat wrap.  lut: (h+2) x (w+2) floats, clamp apron.
- */
-int atmo_host_layout_cubemap(const uint8_t *faces, int n, uint32_t *footprints_out);
-int atmo_host_layout_shape(const uint8_t *texels, int n, uint32_t *footprints_out);
-int atmo_host_layout_lut(const float *lut, int w, int h, float *apron_out);
-/* next mip level (n/2 per side, 6 faces) of a 6 x n^2 level: the 2x2 box (a + b + c + d + 2) >> 2 */
-int atmo_host_cubemap_mip(const uint8_t *level, int n, uint8_t *next_out);
-
-/* Diagnostics (no reference counterpart): copies the DEVICE layout of a bound texture (what the re-layout kernels of
- * atmo_set_texture wrote: LUT apron / shape footprints / cubemap footprints of all bound levels / blue-noise bytes) to
- * host memory, so it can be compared with atmo_host_layout_*.  out_host == NULL only reports the size in *bytes_out. */
-int atmo_read_texture_layout(AtmoContext *ctx, const char *name, void *out_host, size_t capacity_bytes, size_t *bytes_out, void *stream);
-
-/* Diagnostics (no reference counterpart): on the device, compares the kernels' cheap correctly-rounded sqrt and
- * divide-by-uniform helpers with the compiler's IEEE expansions over `count` consecutive float bit patterns
- * starting at `first_bits`, and reports the number of mismatches (must be 0). */
-int atmo_selftest_exact_math(AtmoContext *ctx, uint32_t first_bits, uint32_t count, float divisor,
-                             uint32_t *sqrt_mismatches, uint32_t *div_mismatches);
-
-/* Name of the kernel the most recent atmo_render of this context launched, "atmo_render_kernel<FLAGS, LSTEPS, SPLIT>"
- * (before the first launch: the one-lane-per-ray form), for matching rocprofv3 kernel traces. */
-const char *atmo_kernel_name(AtmoContext *ctx);
 
 /* Last error message of this context (or of the failed atmo_create when ctx == NULL). Never NULL. */
 const char *atmo_last_error_string(AtmoContext *ctx);

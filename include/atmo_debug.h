@@ -1,0 +1,64 @@
+/*
+ * atmo_debug.h -- experiment knobs and diagnostics of libatmo_hip.so.  NOT part of the surface a Godot host binds
+ * (that is include/atmo.h, whose entry points each replace a reference interface): nothing here has a counterpart in
+ * the reference.  Used by this repository's tests, bench.py and tools/; may change between ABI versions.
+ */
+#ifndef ATMO_DEBUG_H
+#define ATMO_DEBUG_H
+
+#include "atmo.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ATMO_EXPERIMENTAL 1
+
+/*
+ * Launch shape (no reference counterpart): lanes per view ray.  1 = one wavefront lane per ray (64 rays per wave);
+ * 2 = two adjacent lanes share a ray (32 rays per wave: each lane takes every second cloud sample / half of the view
+ * samples, results cross by DPP) -- twice the waves for the same frame; the cloud march is the same bits, the
+ * atmosphere sums agree within rounding.  It pays only for small launches dominated by a few very long waves
+ * (clouds_high_rm at 1920x1080: -11 %), so 0 (default, "auto") currently means 1.
+ */
+int atmo_set_lane_split(AtmoContext *ctx, int lanes_per_ray);
+
+/* Device time of `atmo_render` kernels measured with HIP events recorded around the launch on its own stream:
+ * atmo_set_timing(ctx, k): k = 0 off, k >= 1 brackets every k-th launch (k > 1 keeps the ~5 us cost of recording two
+ * events out of most steps); atmo_get_timing returns the number of bracketed launches and their total milliseconds
+ * since enabling (it waits for them). */
+int atmo_set_timing(AtmoContext *ctx, int every_kth);
+int atmo_get_timing(AtmoContext *ctx, int *launches, double *total_ms);
+
+/*
+ * Host-only helpers (no device, no context): the device layouts atmo_set_texture builds, exposed so they can be
+ * checked without a GPU.  cubemap: 6*(n+1)^2 words, word (i,j) of a face = the 2x2 texels of the seamless-apron
+ * padded face starting at padded (i,j), bytes 0..3 = (i,j),(i+1,j),(i,j+1),(i+1,j+1).  shape: n^3 words, word
+ * (i,j,k) = T(i,j,k),T(i+1,j,k),T(i,j+1,k),T(i+1,j+1,k) with repeat wrap.  lut: (h+2) x (w+2) floats, clamp apron.
+ */
+int atmo_host_layout_cubemap(const uint8_t *faces, int n, uint32_t *footprints_out);
+int atmo_host_layout_shape(const uint8_t *texels, int n, uint32_t *footprints_out);
+int atmo_host_layout_lut(const float *lut, int w, int h, float *apron_out);
+/* next mip level (n/2 per side, 6 faces) of a 6 x n^2 level: the 2x2 box (a + b + c + d + 2) >> 2 */
+int atmo_host_cubemap_mip(const uint8_t *level, int n, uint8_t *next_out);
+
+/* Diagnostics (no reference counterpart): copies the DEVICE layout of a bound texture (what the re-layout kernels of
+ * atmo_set_texture wrote: LUT apron / shape footprints / cubemap footprints of all bound levels / blue-noise bytes) to
+ * host memory, so it can be compared with atmo_host_layout_*.  out_host == NULL only reports the size in *bytes_out. */
+int atmo_read_texture_layout(AtmoContext *ctx, const char *name, void *out_host, size_t capacity_bytes, size_t *bytes_out, void *stream);
+
+/* Diagnostics (no reference counterpart): on the device, compares the kernels' cheap correctly-rounded sqrt and
+ * divide-by-uniform helpers with the compiler's IEEE expansions over `count` consecutive float bit patterns
+ * starting at `first_bits`, and reports the number of mismatches (must be 0). */
+int atmo_selftest_exact_math(AtmoContext *ctx, uint32_t first_bits, uint32_t count, float divisor,
+                             uint32_t *sqrt_mismatches, uint32_t *div_mismatches);
+
+/* Name of the kernel the most recent atmo_render of this context launched, "atmo_render_kernel<FLAGS, LSTEPS, SPLIT>"
+ * (before the first launch: the one-lane-per-ray form), for matching rocprofv3 kernel traces. */
+const char *atmo_kernel_name(AtmoContext *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* ATMO_DEBUG_H */
