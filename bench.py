@@ -34,7 +34,9 @@ if ROOT not in sys.path:
 
 BYTES_PER_RAY = 20          # 16 B RGBA32F store + 4 B depth load
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
-TIMING_EVERY = 4            # HIP events bracket every 4th kernel launch of the timed region (recording costs ~5 us)
+TIMING_EVERY = 4            # N > 1 only: HIP events bracket every 4th launch (the render stream also waits for gathers there)
+FRAMES_IN_FLIGHT = 2        # --motion loops: the host stays at most this many frames ahead of the GPU (a swap chain's depth)
+SUSTAINED_MS = 50.0         # N = 1: a second, longer timed pass of at least this much GPU time (visible to an outside sampler)
 N_SIMD = 1024               # 256 CUs x 4 SIMDs
 SPEC_CLOCK_GHZ = 2.4
 # VALU issue costs, shader cycles per wave64 instruction on one SIMD.
@@ -48,15 +50,19 @@ SPEC_CLOCK_GHZ = 2.4
 #      while another wave's fast ops use the second: a mix costs max(4.1 S, 2.2 (S + F)).
 ISSUE_SPEC = {"valu": 2.0, "trans": 8.0}
 ISSUE_MEASURED = {"fast": 2.2, "slow": 4.1, "trans": 8.1, "poison_cycles_per_trans": 3.4}
-PROFILE_DIR = "profiles/round2"
+PROFILE_DIR = "profiles/round3"
+PROFILE_FALLBACK_DIR = "profiles/round2"  # counters of a workload not re-profiled this round (source says which)
 
 
 def pmc_summary(workload, w, h):
     """rocprofv3 PMC results for the same bench command line (tools/profile.sh -> tools/summarize_pmc.py; collected in their
-    own runs, never beside tracing), committed under profiles/round2/pmc_<workload>_<W>x<H>.json.  None when this
+    own runs, never beside tracing), committed under profiles/round<N>/pmc_<workload>_<W>x<H>.json.  None when this
     workload/size has not been profiled."""
-    path = f"{PROFILE_DIR}/pmc_{workload}_{w}x{h}.json"
-    if not os.path.exists(os.path.join(ROOT, path)):
+    for d in (PROFILE_DIR, PROFILE_FALLBACK_DIR):
+        path = f"{d}/pmc_{workload}_{w}x{h}.json"
+        if os.path.exists(os.path.join(ROOT, path)):
+            break
+    else:
         return None
     with open(os.path.join(ROOT, path)) as f:
         d = json.load(f)
@@ -118,7 +124,7 @@ def valu_roofline(pmc, kernel_avg_ms):
     }
 
 
-def hbm_roofline(kernel_avg_ms, launches, launch_rays, pmc):
+def hbm_roofline(kernel_avg_ms, launches, launch_rays, pmc, isolated_ms=None):
     achieved = (BYTES_PER_RAY * launch_rays / (kernel_avg_ms * 1e-3) / 1e9) if kernel_avg_ms else None
     return {
         "bound": "hbm",
@@ -130,7 +136,13 @@ def hbm_roofline(kernel_avg_ms, launches, launch_rays, pmc):
         "traffic_source": None if pmc is None else pmc["source"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bytes per launch)",
         "kernel_avg_ms": kernel_avg_ms or None,
         "kernel_launches_timed": launches,
-        "kernel_timing": f"HIP events around every {TIMING_EVERY}th launch of the timed region, on the launch stream",
+        "kernel_timing": "ONE pair of HIP events on the launch stream around the whole run of K un-bracketed launches of the timed "
+                         "region, elapsed / K (launches are back to back, so this is the kernel's duration in steady state "
+                         "including the ~1 us hand-over between consecutive launches; it cannot exceed ms_per_step)",
+        "kernel_isolated_ms": isolated_ms,
+        "kernel_isolated_note": None if isolated_ms is None else
+                                "mean of 8 launches each bracketed by its own event pair after the timed region (untimed): a "
+                                "bracketed launch starts on a drained GPU and runs ~2-4 % longer than one in a back-to-back run",
         "algorithmic_bytes_per_launch": BYTES_PER_RAY * launch_rays,
         "note": "path is VALU-issue-bound, not HBM-bound (20 B/ray); see valu_roofline and DESIGN.md",
     }
@@ -165,6 +177,8 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--pose", default="P_space")
+    ap.add_argument("--motion", default="", help="orbit:<deg/frame> or pan:<deg/frame>: a new camera pose every step (N = 1); "
+                    "all frames and depth buffers are prepared before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", default="every", choices=["final", "every", "none"],
                     help="N>1: 'every' (default) = RCCL gather of EVERY frame to rank 0, two in flight, overlapped with the "
@@ -174,8 +188,9 @@ def parse_args():
     ap.add_argument("--shard", default="viewports", choices=["viewports", "bands"],
                     help="N>1: 'viewports' = one full viewport per GPU (weak scaling, default); 'bands' = ONE viewport cut "
                          "into hit-balanced row bands, one per GPU, gathered in place into the frame on rank 0 (strong scaling)")
-    ap.add_argument("--also", default="lut32,shipped8,clouds_high,clouds_high_rm,direct32x8@3840x2160,clouds_high_rm@3840x2160,direct32x8+2vp,noise_cubemap",
-                    help="comma-separated extra workloads (name or name@WxH) timed at N=1 after the headline and reported under "
+    ap.add_argument("--also", default="lut32,shipped8,clouds_high,clouds_high_rm,direct32x8@3840x2160,clouds_high_rm@3840x2160,"
+                                      "clouds_high@lod,clouds_high_rm@lod@3840x2160,direct32x8@moving,clouds_high_rm@moving,direct32x8+2vp,noise_cubemap",
+                    help="comma-separated extra workloads (name[@lod][@WxH], name@moving, name+2vp) timed at N=1 after the headline and reported under "
                          "'extra', each with its own roofline blocks: the reference-exact LUT mode and the shipped 8-step shader "
                          "(SURVEY.md 8d), BASELINE configs[2] (clouds_high 1080p) and configs[3] (clouds_high_rm 3840x2160); '' to skip")
     return ap.parse_args()
@@ -269,40 +284,178 @@ def bench_noise_cubemap(resolution=256):
             "cpu_oracle_1core_Mtexels/s": texels / cpu_s / 1e6}
 
 
-def time_workload(torch, node, cam, depth, steps, warmup, out=None):
-    """Single-GPU timed loop; returns (seconds, kernel launches, kernel ms from HIP events)."""
+def depth_ground_sphere_torch(torch, S, cam, device):
+    """scene.depth_ground_sphere evaluated on the GPU in float64 (the --motion loops need a depth buffer per pose)."""
+    import numpy as np
+    w, h = cam.width, cam.height
+    f64 = torch.float64
+    xs = (torch.arange(w, device=device, dtype=f64) + 0.5) / w * 2.0 - 1.0
+    ys = (torch.arange(h, device=device, dtype=f64) + 0.5) / h * 2.0 - 1.0
+    gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+    near_z = torch.ones_like(gx) if cam.reverse_z else torch.zeros_like(gx)
+    ndc = torch.stack([gx, gy, near_z, torch.ones_like(gx)], dim=-1)
+    v = ndc @ torch.from_numpy(np.ascontiguousarray(cam.inv_projection.T)).to(device)
+    d = v[..., :3] / v[..., 3:4]
+    d = d / d.norm(dim=-1, keepdim=True)
+    c = torch.from_numpy((cam.view @ np.array([0.0, 0.0, 0.0, 1.0]))[:3].copy()).to(device)
+    bq = -(d @ c)
+    hh = S.DEMO_PLANET_RADIUS ** 2 - (c @ c - bq * bq)
+    hit = hh >= 0.0
+    t = -bq - torch.sqrt(torch.where(hit, hh, torch.zeros_like(hh)))
+    hit = hit & (t > cam.near)
+    zv = d[..., 2] * t
+    p = cam.projection
+    zc, wc = p[2, 2] * zv + p[2, 3], p[3, 2] * zv + p[3, 3]
+    far = 0.0 if cam.reverse_z else 1.0
+    return torch.where(hit, zc / torch.where(hit, wc, torch.ones_like(wc)), torch.full_like(zc, far)).to(torch.float32).contiguous()
+
+
+MOTION_PAN_RANGE_DEG = 25.0
+
+
+def parse_motion(text):
+    """'orbit:1' / 'pan:0.5' -> (kind, degrees per frame); '' or 'static' -> None."""
+    if not text or text == "static":
+        return None
+    kind, _, deg = text.partition(":")
+    if kind not in ("orbit", "pan") or not deg:
+        raise SystemExit("--motion takes orbit:<deg/frame> or pan:<deg/frame>")
+    return kind, float(deg)
+
+
+def motion_cameras(S, w, h, motion, n, base_pose="P_space"):
+    """n camera poses, one per frame, `deg` degrees apart (planet_atmosphere.gd:285-341 writes the per-frame uniforms of a
+    flying camera, demo/avatar.gd + demo/mouse_look.gd):
+      orbit  the demo camera revolves around the planet's axis at its own distance, looking at the centre: the terminator
+             and the cloud pattern sweep across a disc that stays where it is on the screen;
+      pan    the demo camera stays where it is and yaws (mouse look): the whole disc slides across the screen, back and forth
+             within +-25 degrees (1 degree = 14.4 pixels at 1920x1080, i.e. about one 16-pixel tile per degree)."""
+    import math
+    import numpy as np
+    kind, deg = motion
+    base = S.POSES[base_pose]
+    eye0 = np.asarray(base["eye"], dtype=np.float64)
+    cams = []
+    for k in range(n):
+        if kind == "orbit":
+            a = math.radians(deg * k)
+            r = float(np.hypot(eye0[0], eye0[2]))
+            a0 = math.atan2(eye0[0], eye0[2])
+            eye = (r * math.sin(a0 + a), float(eye0[1]), r * math.cos(a0 + a))
+            pose = dict(eye=eye, target=(0.0, 0.0, 0.0))
+        else:
+            x = deg * k / MOTION_PAN_RANGE_DEG  # triangle wave of amplitude 1, slope +-1 per unit
+            tri = 1.0 - abs((x + 1.0) % 4.0 - 2.0)
+            a = math.radians(MOTION_PAN_RANGE_DEG * tri)
+            fwd = np.asarray(base["target"], dtype=np.float64) - eye0
+            dist = float(np.linalg.norm(fwd))
+            fwd /= dist
+            ca, sa = math.cos(a), math.sin(a)
+            f2 = np.array([ca * fwd[0] + sa * fwd[2], fwd[1], -sa * fwd[0] + ca * fwd[2]])
+            pose = dict(eye=tuple(eye0), target=tuple(eye0 + f2 * dist))
+        cams.append(S.Camera.from_pose(w, h, pose))
+    return cams
+
+
+def pingpong(i, n):
+    """0, 1, ..., n-1, n-2, ..., 1, 0, 1, ...: a pose sequence replayed without a jump."""
+    if n <= 1:
+        return 0
+    m = i % (2 * n - 2)
+    return m if m < n else 2 * n - 2 - m
+
+
+class TimedRun:
+    """What time_workload measured: wall seconds of the K-step timed region (host clock, synchronised on both sides), the
+    HIP-event time of the same K launches, an isolated-launch figure, and the sustained pass."""
+    def __init__(self):
+        self.dt = 0.0
+        self.steps = 0
+        self.event_ms = 0.0
+        self.isolated_ms = None
+        self.sustained = None
+        self.out = None
+
+    @property
+    def kernel_avg_ms(self):
+        return self.event_ms / self.steps if self.steps else 0.0
+
+
+def time_workload(torch, node, cam, depth, steps, warmup, out=None, sequence=None, sustained=False, isolated=True):
+    """Single-GPU timed loop.  `sequence`: None (the same frame every step) or a list of (native frame, depth tensor), one
+    camera pose per step, replayed ping-pong (--motion); the host then stays at most FRAMES_IN_FLIGHT frames ahead of the GPU,
+    like a swap chain, instead of enqueueing the whole run at once."""
     if out is None:
         out = torch.empty((cam.height, cam.width, 4), dtype=torch.float32, device=depth.device)
-    frame = node.prepare_frame(cam)
     stream = torch.cuda.current_stream().cuda_stream
-    dptr, optr = depth.data_ptr(), out.data_ptr()
+    optr = out.data_ptr()
+    if sequence is None:
+        sequence = [(node.prepare_frame(cam), depth)]
+    seq = [(fr, d.data_ptr()) for fr, d in sequence]
+    nseq = len(seq)
+    paced = nseq > 1
+    ring = [torch.cuda.Event() for _ in range(FRAMES_IN_FLIGHT)] if paced else None
+    counter = [0]
+
+    def draw(n):
+        for _ in range(n):
+            i = counter[0]
+            fr, dptr = seq[pingpong(i, nseq)]
+            if paced:
+                ev = ring[i % FRAMES_IN_FLIGHT]
+                if i >= FRAMES_IN_FLIGHT:
+                    ev.synchronize()
+                node.render_prepared(fr, dptr, optr, stream)
+                ev.record()
+            else:
+                node.render_prepared(fr, dptr, optr, stream)
+            counter[0] = i + 1
+
     # W untimed steps; whatever W is, the context is primed outside the timed region (lazy LUT bake, feedback buffers,
     # and -- after the synchronisation -- the first heaviest-first tile order): two untimed draws at least
-    for _ in range(warmup):
-        node.render_prepared(frame, dptr, optr, stream)
+    draw(warmup)
     torch.cuda.synchronize()
-    # A frame loop synchronises once per frame (present); this loop does not, so a context would keep the tile order
+    # A frame loop synchronises once per frame (present); the static loop does not, so a context would keep the tile order
     # of its first, cold draws for as long as the host runs ahead of the GPU.  Four more untimed draws, paced like frames,
     # let the heaviest-first order settle before the timed region (atmo_set_tile_feedback; NOTES.md).
     for _ in range(4):
-        node.render_prepared(frame, dptr, optr, stream)
+        draw(1)
         torch.cuda.synchronize()
     # ... and the GPU needs ~20 ms of sustained work to reach its sustained clocks in a fresh process (a 20-step run measured
     # 8 % below a 200-step run otherwise: BENCH_r01 vs README in round 1): keep drawing, untimed, until that much has run
     t_warm = time.perf_counter()
     while time.perf_counter() - t_warm < 0.025:
-        for _ in range(8):
-            node.render_prepared(frame, dptr, optr, stream)
+        draw(8)
         torch.cuda.synchronize()
-    node.set_timing(True, every=TIMING_EVERY)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        node.render_prepared(frame, dptr, optr, stream)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    n, ms = node.get_timing()
-    node.set_timing(False)
-    return dt, n, ms, out
+
+    def timed(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()  # on torch's current stream = the stream the kernels are launched on
+        draw(n)
+        e1.record()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, e0.elapsed_time(e1)
+
+    run = TimedRun()
+    run.dt, run.event_ms = timed(steps)
+    run.steps = steps
+    run.out = out
+    if sustained:
+        n2 = max(steps, int(SUSTAINED_MS / max(run.dt / steps * 1e3, 1e-3)) + 1)
+        dt2, ev2 = timed(n2)
+        run.sustained = {"steps": n2, "timed_region_ms": dt2 * 1e3, "ms_per_step": dt2 / n2 * 1e3, "kernel_avg_ms": ev2 / n2,
+                         "Mrays/s": cam.width * cam.height * n2 / dt2 / 1e6,
+                         "note": f"second timed pass of >= {SUSTAINED_MS:.0f} ms right after the K-step region (same loop, same "
+                                 "measurement), long enough for an outside GPU-activity sampler to see"}
+    if isolated:
+        node.set_timing(True, every=1)
+        draw(8)
+        torch.cuda.synchronize()
+        n, ms = node.get_timing()
+        node.set_timing(False)
+        run.isolated_ms = ms / n if n else None
+    return run
 
 
 def timed_loop_distributed(torch, dist, render_into, h, w, device, steps, warmup, gather_mode, timing=None, bands=None):
@@ -383,26 +536,71 @@ def cloud_row_cost(np, S, cam, cloudy):
 CLOUD_WEIGHT = 8.0
 
 
-def run_workload(torch, S, name, w, h, pose, steps, warmup, textures, params, local_rank, with_frame_stats=True):
-    """One single-GPU workload: returns the result dictionary of an `extra` entry (rate, kernel time, both rooflines)."""
+def run_workload(torch, S, name, w, h, pose, steps, warmup, textures, params, local_rank, with_frame_stats=True,
+                 motion=None, node_extra=None, sampler=None):
+    """One single-GPU workload: returns the result dictionary of an `extra` entry (rate, kernel time, both rooflines).
+    motion: None or (kind, degrees per frame): a new camera pose every step (time_workload); node_extra: PlanetAtmosphere
+    keyword arguments (tile_feedback=0 ...); sampler: None / "lod0" / "lod" -- the coverage cubemap's sampler mode."""
     import numpy as np  # noqa: F401
     from godot_atmosphere_shader_amd.demo import make_node
 
     config_name, desc = WORKLOADS[name]
+    kw = dict(node_kwargs(name), **(node_extra or {}))
+    if sampler == "lod":
+        kw["cubemap_lod"] = True
+    node = make_node(config_name, textures, params, device=local_rank, **kw)
     cam = S.Camera.from_pose(w, h, pose)
-    depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
-    node = make_node(config_name, textures, params, device=local_rank, **node_kwargs(name))
-    dt, launches, kernel_ms, out = time_workload(torch, node, cam, depth, steps, warmup)
-    kernel_avg_ms = kernel_ms / launches if launches else 0.0
-    pmc = pmc_summary(name, w, h) if pose == "P_space" else None
-    res = {"workload": f"{desc}; {w}x{h}; demo scene, pose {pose}", "Mrays/s": w * h * steps / dt / 1e6,
-           "ms_per_step": dt / steps * 1e3, "steps": steps, "kernel_avg_ms": kernel_avg_ms or None, "kernel": node.kernel_name,
-           "roofline": hbm_roofline(kernel_avg_ms, launches, w * h, pmc), "valu_roofline": valu_roofline(pmc, kernel_avg_ms)}
+    sequence = None
+    if motion is not None:
+        cams = motion_cameras(S, w, h, motion, max(64, min(steps, 128 if w * h > 4000000 else 256)), pose)
+        sequence = [(node.prepare_frame(c), depth_ground_sphere_torch(torch, S, c, torch.device("cuda", local_rank))) for c in cams]
+        depth = sequence[0][1]
+    else:
+        depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
+    run = time_workload(torch, node, cam, depth, steps, warmup, sequence=sequence)
+    kernel_avg_ms = run.kernel_avg_ms
+    pmc_name = name + ("@lod" if sampler == "lod" else "")
+    pmc = pmc_summary(pmc_name, w, h) if (pose == "P_space" and motion is None) else None
+    res = {"workload": f"{desc}{workload_suffix(config_name, sampler)}; {w}x{h}; demo scene, pose {pose}"
+                       + ("" if motion is None else f", camera motion {motion[0]} {motion[1]:g} deg/frame, a new pose every step, "
+                                                    f"{len(sequence)} poses replayed ping-pong, host at most {FRAMES_IN_FLIGHT} frames ahead"),
+           "Mrays/s": w * h * steps / run.dt / 1e6,
+           "ms_per_step": run.dt / steps * 1e3, "timed_region_ms": run.dt * 1e3, "steps": steps, "kernel_avg_ms": kernel_avg_ms or None,
+           "kernel": node.kernel_name,
+           "roofline": hbm_roofline(kernel_avg_ms, steps, w * h, pmc, run.isolated_ms), "valu_roofline": valu_roofline(pmc, kernel_avg_ms)}
     if with_frame_stats:
-        res["hit_fraction"] = float((out.abs().sum(dim=-1) > 0).float().mean().item())
+        res["hit_fraction"] = float((run.out.abs().sum(dim=-1) > 0).float().mean().item())
     node.close()
-    del out, depth
+    del run, depth, sequence
     return res
+
+
+def workload_suffix(config_name, sampler):
+    """States which sampler a cloud number is for (the reference declares a linear-mipmap samplerCube, cloud_funcs.gdshaderinc:15,45)."""
+    if "cloud" not in config_name:
+        return ""
+    if sampler == "lod":
+        return "; coverage cubemap sampled with the implicit LOD of a linear-mipmap sampler (the reference's declared sampler)"
+    return "; coverage cubemap sampled at LOD 0"
+
+
+def bench_motion(torch, S, name, w, h, steps, warmup, textures, params, local_rank,
+                 motions=(None, ("orbit", 0.1), ("orbit", 1.0), ("orbit", 5.0), ("pan", 1.0))):
+    """The same workload with the camera still and moving, tile-order feedback on and off (the feedback's gain was
+    only ever measured on a redrawn frame).  Every loop is paced like a swap chain (time_workload), the static one too."""
+    out = {}
+    for motion in motions:
+        key = "static" if motion is None else f"{motion[0]}:{motion[1]:g}"
+        row = {}
+        for fb in (1, 0):
+            r = run_workload(torch, S, name, w, h, "P_space", steps, warmup, textures, params, local_rank, with_frame_stats=False,
+                             motion=motion if motion is not None else ("orbit", 0.0), node_extra=dict(tile_feedback=fb))
+            row["feedback_on" if fb else "feedback_off"] = {k: r[k] for k in ("Mrays/s", "ms_per_step", "kernel_avg_ms", "roofline")}
+        row["gain"] = row["feedback_on"]["Mrays/s"] / row["feedback_off"]["Mrays/s"] - 1.0
+        out[key] = row
+    out["workload"] = (f"{WORKLOADS[name][1]}; {w}x{h}; demo scene, camera still / orbiting / panning (bench.motion_cameras), "
+                       f"{steps} timed steps each, host at most {FRAMES_IN_FLIGHT} frames ahead")
+    return out
 
 
 def bench_two_viewports(torch, S, name, w, h, steps, warmup, textures, params, local_rank):
@@ -487,8 +685,17 @@ def main():
     # ---- timed region ---------------------------------------------------------------------------------
     bands = None
     no_gather_rate = None
+    run = None
+    motion = parse_motion(args.motion)
+    if motion is not None and multi:
+        raise SystemExit("--motion is a single-GPU mode")
     if not multi:
-        dt_max, launches, kernel_ms, out = time_workload(torch, node, cam, depth, args.steps, args.warmup)
+        sequence = None
+        if motion is not None:
+            cams = motion_cameras(S, w, h, motion, max(64, min(args.steps, 256)), args.pose)
+            sequence = [(node.prepare_frame(c), depth_ground_sphere_torch(torch, S, c, device)) for c in cams]
+        run = time_workload(torch, node, cam, depth, args.steps, args.warmup, sequence=sequence, sustained=True)
+        dt_max, launches, kernel_ms = run.dt, run.steps, run.event_ms
         gather_mode = "none (single GPU)"
     else:
         if strong:
@@ -550,13 +757,14 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
+            "timed_region_ms": dt_max * 1e3,
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{desc}; {w}x{h}; demo scene, pose {args.pose}"
+                "workload": f"{desc}{workload_suffix(config_name, None)}; {w}x{h}; demo scene, pose {args.pose}"
                             + ("" if world == 1 or strong else f" on rank 0, orbit poses on ranks 1..{world - 1}; one viewport per GPU"),
                 "width": w, "height": h, "rays_per_step_per_gpu": rays if not strong else None,
                 "hit_fraction": hit_fraction,
@@ -566,8 +774,15 @@ def main():
                 "shard": ("one viewport in work-balanced row bands: " + str(bands)) if strong else "one viewport per GPU",
                 "kernel": node.kernel_name,
             },
-            "roofline": hbm_roofline(kernel_avg_ms, launches, launch_rays, pmc),
+            "roofline": hbm_roofline(kernel_avg_ms, launches, launch_rays, pmc, None if run is None else run.isolated_ms),
         }
+        if multi:
+            result["roofline"]["kernel_timing"] = f"HIP events around every {TIMING_EVERY}th launch of the timed region, on the launch stream (rank 0)"
+        if run is not None and run.sustained is not None:
+            result["sustained_pass"] = run.sustained
+        if motion is not None:
+            result["config"]["motion"] = (f"{motion[0]} {motion[1]:g} deg/frame, a new camera pose every step ({len(sequence)} poses, ping-pong), "
+                                          f"host at most {FRAMES_IN_FLIGHT} frames ahead of the GPU")
         vr = valu_roofline(pmc, kernel_avg_ms)
         if vr is not None:
             result["valu_roofline"] = vr
@@ -581,12 +796,20 @@ def main():
             if item == "noise_cubemap":
                 extra[item] = bench_noise_cubemap()
                 continue
-            name, _, size = item.partition("@")
+            name, *opts = item.split("@")
             if name.endswith("+2vp"):
                 extra[item] = bench_two_viewports(torch, S, name[:-4], w, h, ex_steps, ex_warm, textures, params, local_rank)
                 continue
-            ew, eh = (int(v) for v in size.split("x")) if size else (w, h)
-            extra[item] = run_workload(torch, S, name, ew, eh, args.pose, ex_steps, ex_warm, textures, params, local_rank)
+            if "moving" in opts:
+                extra[item] = bench_motion(torch, S, name, w, h, max(64, ex_steps), ex_warm, textures, params, local_rank)
+                continue
+            ew, eh, sampler = w, h, None
+            for o in opts:
+                if o == "lod":
+                    sampler = "lod"
+                else:
+                    ew, eh = (int(v) for v in o.split("x"))
+            extra[item] = run_workload(torch, S, name, ew, eh, args.pose, ex_steps, ex_warm, textures, params, local_rank, sampler=sampler)
         result["extra"] = extra
     if multi and not strong and args.workload == "direct32x8" and os.environ.get("ATMO_BENCH_NO_CONFIG4") != "1":
         # BASELINE.json configs[4]: independent 3840x2160 clouds_high_rm viewports, one per GPU, gathered to rank 0 over xGMI

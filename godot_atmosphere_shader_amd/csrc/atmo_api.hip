@@ -117,8 +117,8 @@ struct AtmoContext {
     // One feedback state per (launch grid, lanes per ray, draw stream): a context that alternates between a few rects or
     // streams (split screen, stereo eyes, uneven row bands) keeps one state for each instead of starting over -- and
     // synchronising -- at every change.  Buffers are grow-only; a slot is recycled (least recently used) only when a
-    // fifth key appears, and a context that keeps producing new keys stops recycling (fb_thrash) and draws those in
-    // row-major order.
+    // fifth key appears, and a context that keeps producing new keys runs out of recycling budget (8, one regained
+    // every 256 draws) and draws those keys in row-major order: nothing waits, the resident states keep working.
     struct FeedbackState {
         bool used = false;
         int tiles_x = 0, tiles_y = 0, split = 0;
@@ -135,7 +135,8 @@ struct AtmoContext {
     static constexpr int FB_SLOTS = 4;
     FeedbackState fb[FB_SLOTS];
     unsigned long long fb_clock = 0;
-    int fb_thrash = 0;                                 // consecutive slot recyclings without a state getting used
+    int fb_budget = 8;                                 // slot recyclings allowed right now; one comes back every 256 draws
+    unsigned fb_ordered_draws = 0, fb_recycled = 0, fb_sorts = 0;  // atmo_get_feedback_stats
     hipStream_t fb_stream = nullptr;                   // the sort kernels run here, beside the draws (high priority)
     DeviceBuffer fb_scratch;                           // the sort's block histograms (sorts are serialised on fb_stream)
     unsigned fb_period = 8;                            // every fb_period-th draw of a key records costs
@@ -380,10 +381,11 @@ int feedback_quiesce(AtmoContext *ctx, AtmoContext::FeedbackState &f, hipStream_
 
 // The feedback state for draws of a (gx, gy, split) grid on stream s: the cached one, a free slot, or -- at most a few
 // times in a row -- the least recently used slot recycled.  *out stays null when the context is producing new keys faster
-// than states get used (fb_thrash): those draws run in row-major order and nothing waits.
+// than its recycling budget allows: those draws run in row-major order and nothing waits.
 int feedback_state(AtmoContext *ctx, int gx, int gy, int split, hipStream_t s, AtmoContext::FeedbackState **out) {
     *out = nullptr;
     ctx->fb_clock += 1;
+    if ((ctx->fb_clock & 255u) == 0 && ctx->fb_budget < 8) ctx->fb_budget += 1;
     AtmoContext::FeedbackState *slot = nullptr, *lru = nullptr;
     for (AtmoContext::FeedbackState &f : ctx->fb) {
         if (f.used && f.tiles_x == gx && f.tiles_y == gy && f.split == split && f.draw_stream == s) {
@@ -402,8 +404,9 @@ int feedback_state(AtmoContext *ctx, int gx, int gy, int split, hipStream_t s, A
         if (rc0 != ATMO_OK) return rc0;
     }
     if (!slot) {
-        if (ctx->fb_thrash >= 8) return ATMO_OK;  // no feedback for this draw
-        ctx->fb_thrash += 1;
+        if (ctx->fb_budget <= 0) return ATMO_OK;  // no feedback for this draw
+        ctx->fb_budget -= 1;
+        ctx->fb_recycled += 1;
         slot = lru;
         const int rc0 = feedback_quiesce(ctx, *slot, s);
         if (rc0 != ATMO_OK) return rc0;
@@ -970,7 +973,7 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
                 (void)hipGetLastError();  // hipErrorNotReady is an answer, not an error: keep it out of the launch checks below
             }
         }
-        if (fb->active >= 0) rc.tile_order = (const uint32_t *)fb->order[fb->active].ptr;
+        if (fb->active >= 0) { rc.tile_order = (const uint32_t *)fb->order[fb->active].ptr; ctx->fb_ordered_draws += 1; }
         // the first two draws of a key are not measured (cold clocks and caches rank the tiles poorly); the next four
         // record back to back (the order settles in a few frames), then every fb_period-th
         fb_record = !fb->pending && fb->n >= 2 && (fb->n < 6 || fb->n - fb->last_record >= ctx->fb_period);
@@ -1016,11 +1019,9 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         HIP_TRY(ctx, hipEventRecord(fb->ev_order[fb->write], ctx->fb_stream));
         fb->pending = true;
         fb->last_record = fb->n;
+        ctx->fb_sorts += 1;
     }
-    if (fb) {
-        fb->n += 1;
-        if (fb->n >= 16) ctx->fb_thrash = 0;  // this state is being used, not just created
-    }
+    if (fb) fb->n += 1;
     ctx->drew = true;
     ctx->last_draw_stream = s;
     ctx->last_split = split;
@@ -1063,7 +1064,18 @@ int atmo_set_tile_feedback(AtmoContext *ctx, int mode) {
         f.pending = false;
         f.n = 0;
     }
-    ctx->fb_thrash = 0;
+    ctx->fb_budget = 8;
+    return ATMO_OK;
+}
+
+int atmo_get_feedback_stats(AtmoContext *ctx, int *states, unsigned *ordered_draws, unsigned *sorts, unsigned *recycled) {
+    if (!ctx) return ATMO_E_ARG;
+    int n = 0;
+    for (const AtmoContext::FeedbackState &f : ctx->fb) n += f.used ? 1 : 0;
+    if (states) *states = n;
+    if (ordered_draws) *ordered_draws = ctx->fb_ordered_draws;
+    if (sorts) *sorts = ctx->fb_sorts;
+    if (recycled) *recycled = ctx->fb_recycled;
     return ATMO_OK;
 }
 

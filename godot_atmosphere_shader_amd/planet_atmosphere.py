@@ -602,6 +602,12 @@ class PlanetAtmosphere:
         rc = self._lib.atmo_render(self._ctx, C.byref(nf), C.c_void_p(depth_ptr), C.c_void_p(out_ptr), C.c_void_p(stream or 0))
         N.check(self._ctx, rc)
 
+    def feedback_stats(self) -> dict:
+        """atmo_get_feedback_stats (diagnostics of the tile-order feedback)."""
+        st, od, so, rc = C.c_int(0), C.c_uint(0), C.c_uint(0), C.c_uint(0)
+        N.check(self._ctx, self._lib.atmo_get_feedback_stats(self._ctx, C.byref(st), C.byref(od), C.byref(so), C.byref(rc)))
+        return dict(states=st.value, ordered_draws=od.value, sorts=so.value, recycled=rc.value)
+
     # ---- kernel timing (HIP events on the launch stream) ---------------------------------------------
     def set_timing(self, enable, every: int = 1):
         """enable: False/0 off; True = bracket every `every`-th launch with HIP events."""

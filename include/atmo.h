@@ -221,7 +221,8 @@ int atmo_set_host_double_precision(AtmoContext *ctx, int enable);
  * -1 (default) = on; 0 = off; 1 = on.  Launches inside a HIP graph capture never use it.  A context keeps one feedback
  * state per (launch grid, draw stream) it sees, up to four (split screen, stereo eyes, uneven row bands), each allocated by
  * the first launch of its key; a fifth key recycles the least recently used state (which waits for that state's work),
- * and a context that keeps producing new keys stops recycling and draws them in row-major order.
+ * and a context that keeps producing new keys runs out of recycling budget (8, one regained every 256 draws) and draws
+ * those keys in row-major order while the resident states keep working.
  */
 int atmo_set_tile_feedback(AtmoContext *ctx, int mode);
 

@@ -23,6 +23,10 @@ extern "C" {
  */
 int atmo_set_lane_split(AtmoContext *ctx, int lanes_per_ray);
 
+/* Diagnostics of the tile-order feedback (atmo_set_tile_feedback): feedback states in use (one per launch grid and draw
+ * stream, at most 4), draws so far that were dispatched in a sorted order, sorts enqueued, states recycled for another key. */
+int atmo_get_feedback_stats(AtmoContext *ctx, int *states, unsigned *ordered_draws, unsigned *sorts, unsigned *recycled);
+
 /* Device time of `atmo_render` kernels measured with HIP events recorded around the launch on its own stream:
  * atmo_set_timing(ctx, k): k = 0 off, k >= 1 brackets every k-th launch (k > 1 keeps the ~5 us cost of recording two
  * events out of most steps); atmo_get_timing returns the number of bracketed launches and their total milliseconds

@@ -949,6 +949,79 @@ def test_tile_feedback_default_policy_and_graph_capture():
     ref.close()
 
 
+def test_tile_feedback_keeps_one_state_per_rect_and_stream():
+    """A context that alternates between two rects (split screen / uneven bands) and two streams (stereo eyes) keeps one
+    feedback state per (grid, stream) -- no restart, no device-wide wait, every state reaches a sorted order -- and a
+    context that sees more than four keys recycles the least recently used state a few times, then stops.
+    The picture is the row-major one throughout."""
+    tex, params = demo_textures(), demo_params()
+    w, h = 1280, 720
+    cam = S.Camera.from_pose(w, h, "P_space")
+    depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
+    ref = make_node("clouds_high", tex, params, tile_feedback=0)
+    node = make_node("clouds_high", tex, params, tile_feedback=1)
+    rects = [(0, 0, w // 2, h), (w // 2, 0, w, h)]
+    streams = [torch.cuda.current_stream(), torch.cuda.Stream()]
+    want = [ref.render(cam, depth, rect=r).clone() for r in rects]
+    torch.cuda.synchronize()
+    for it in range(40):
+        k = it % 2
+        with torch.cuda.stream(streams[k]):
+            got = node.render(cam, depth, rect=rects[k], stream=streams[k])
+        if it % 4 == 3:
+            torch.cuda.synchronize()   # a frame loop presents now and then: lets the host see finished sorts
+            assert torch.equal(got, want[k]), it
+    torch.cuda.synchronize()
+    st = node.feedback_stats()
+    assert st["states"] == 2 and st["recycled"] == 0, st
+    assert st["sorts"] >= 8 and st["ordered_draws"] >= 20, st   # both states engaged (the old code restarted at every draw)
+    # more keys than slots: seven distinct rects, round robin
+    many = [(0, 0, w - 16 * k, h) for k in range(7)]
+    for it in range(70):
+        r = many[it % 7]
+        got = node.render(cam, depth, rect=r)
+    torch.cuda.synchronize()
+    st2 = node.feedback_stats()
+    assert st2["states"] == 4 and 1 <= st2["recycled"] <= 8, st2    # the recycling budget ran out: those draws run row-major
+    assert torch.equal(got, ref.render(cam, depth, rect=many[69 % 7]))
+    node.close()
+    ref.close()
+
+
+def test_moving_camera_sequence_is_identical_with_feedback_on_and_off():
+    """A new camera pose every frame (the reference's demo is a flying camera: demo/avatar.gd, demo/mouse_look.gd; per-frame
+    uniforms planet_atmosphere.gd:285-341): with tile-order feedback the costs that order frame k were measured on earlier,
+    different frames -- the bits of frame k do not depend on that."""
+    import bench
+
+    tex, params = demo_textures(), demo_params()
+    w, h = 960, 540
+    for config_name, motion in (("clouds_high_rm", ("pan", 1.0)), ("no_clouds_32x8_direct", ("orbit", 5.0))):
+        cams = bench.motion_cameras(S, w, h, motion, 24)
+        on = make_node(config_name, tex, params, tile_feedback=1)
+        off = make_node(config_name, tex, params, tile_feedback=0)
+        for k, cam in enumerate(cams):
+            depth = bench.depth_ground_sphere_torch(torch, S, cam, torch.device("cuda"))
+            a = on.render(cam, depth)
+            b = off.render(cam, depth)
+            torch.cuda.synchronize()
+            assert torch.equal(a, b), (config_name, k)
+        assert on.feedback_stats()["ordered_draws"] >= 12
+        on.close()
+        off.close()
+
+
+def test_bench_depth_on_the_device_matches_the_host_depth():
+    """bench.depth_ground_sphere_torch (the --motion loops) states scene.depth_ground_sphere on the GPU."""
+    import bench
+
+    cam = S.Camera.from_pose(480, 270, "P_limb")
+    got = bench.depth_ground_sphere_torch(torch, S, cam, torch.device("cuda")).cpu().numpy()
+    want = S.depth_ground_sphere(cam)
+    assert np.array_equal(got == 0.0, want == 0.0)
+    assert np.abs(got - want).max() <= 1e-7
+
+
 # ---- texture re-layout on the device -----------------------------------------------------------------------------------
 
 def test_device_texture_layouts_equal_the_host_layouts():
