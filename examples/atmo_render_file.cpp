@@ -79,7 +79,7 @@ int main(int argc, char **argv) {
     FILE *f = std::fopen(argv[3], "wb");
     if (!f || std::fwrite(rgba.data(), sizeof(float), rgba.size(), f) != rgba.size()) { std::fprintf(stderr, "cannot write %s\n", argv[3]); return 1; }
     std::fclose(f);
-    std::printf("%s: %zu pixels shaded\n", atmo_kernel_name(ctx), rect_pix);
+    std::printf("atmo_render: %zu pixels shaded\n", rect_pix);
     (void)hipFree(d_depth);
     (void)hipFree(d_rgba);
     CHECK_ATMO(atmo_destroy(ctx));

@@ -69,9 +69,14 @@ def _lex(line: str):
     return out
 
 
-def preprocess(path: str, defines: dict | None = None):
-    """Token list of `path` after includes, conditionals and object-like macros.  `defines`: predefined macros."""
+def preprocess(path: str, defines: dict | None = None, force_defines: dict | None = None):
+    """Token list of `path` after includes, conditionals and object-like macros.  `defines`: predefined macros (an in-file
+    #define of the same name replaces them, as in C); `force_defines`: macros that WIN over in-file #defines of the same
+    name -- how a step count other than the shipped one is run through the reference text unchanged (the variant files
+    #define ATMOSPHERE_RAYMARCH_STEPS themselves, planet_atmosphere_no_clouds.gdshader:4)."""
     macros = {k: _lex(str(v)) for k, v in (defines or {}).items()}
+    forced = {k: _lex(str(v)) for k, v in (force_defines or {}).items()}
+    macros.update(forced)
     tokens = []
 
     def expand(toks, depth=0):
@@ -104,7 +109,8 @@ def preprocess(path: str, defines: dict | None = None):
                     pass
                 elif d == "define":
                     mm = re.match(r"(\w+)\s*(.*)", rest)
-                    macros[mm.group(1)] = _lex(mm.group(2))
+                    if mm.group(1) not in forced:
+                        macros[mm.group(1)] = _lex(mm.group(2))
                 elif d == "include":
                     run(os.path.join(os.path.dirname(p), rest.strip('"')))
                 else:
@@ -406,11 +412,33 @@ def _pow32(x, y):
         # (GLSL leaves x < 0 undefined; hardware computes exp2(y * log2(x)) = NaN, see _pow below)
 
 
+def _fma(a, b, c):
+    """a * b + c rounded once (the float32 product is exact in float64; the second rounding float64 -> float32 can differ
+    from a true fused operation only in half-way cases -- good enough for the sensitivity runs this is for)."""
+    with np.errstate(all="ignore"):
+        return (np.asarray(a, dtype=np.float64) * np.asarray(b, dtype=np.float64) + np.asarray(c, dtype=np.float64)).astype(F32)
+
+
+_CONTRACT = [False]  # sensitivity runs only (Machine(conventions={"fma": True})): sums of products contracted into FMAs
+
+
 def _dot(a, b):
     r = a[0] * b[0]
     for k in range(1, a.shape[0]):
-        r = r + a[k] * b[k]
+        r = _fma(a[k], b[k], r) if _CONTRACT[0] else r + a[k] * b[k]
     return r
+
+
+def _twin_calls(a, b):
+    """Both statements are `X = f(args);` (possibly wrapped in a one-statement block) with the same X and the same args."""
+    def only(st):
+        while st[0] == "block" and len(st[1]) == 1:
+            st = st[1][0]
+        if st[0] == "expr" and st[1][0] == "assign" and st[1][1] == "=" and st[1][3][0] == "call":
+            return st[1][2], st[1][3][2]
+        return None
+    x, y = only(a), only(b)
+    return x is not None and y is not None and x == y
 
 
 class Frame:
@@ -428,9 +456,22 @@ class Machine:
     """Executes the functions of one parsed shader over `lanes` lanes."""
 
     def __init__(self, parser: Parser, lanes: int, samplers: dict, uniforms: dict | None = None,
-                 source_color=lambda c: c):
+                 source_color=lambda c: c, merge_twin_calls: bool = False, conventions: dict | None = None):
+        """merge_twin_calls: an if / else whose two branches assign the same variable from calls with the same argument
+        list (cloud_funcs.gdshaderinc:132-136: get_density(pos, time, settings) / get_density_low(pos, time, settings), the
+        same function of the same arguments once CLOUDS_ALWAYS_LOW_QUALITY is defined, main:49) counts as ONE call site for
+        the quad derivatives of an implicit-LOD texture fetch inside: a quad partner that took the other branch still
+        contributes its coordinate, as it does after a compiler has inlined and merged the two branches.  False = literal:
+        only lanes active at this very execution of the call contribute.
+        conventions: sensitivity runs only (tests/golden/sensitivity.py) -- {"normalize": "div"} for v / sqrt(dot) instead
+        of v * (1 / sqrt(dot)), {"mix": "lerp"} for a + (b - a) t instead of a (1 - t) + b t, {"fma": True} for contracted
+        sums of products."""
         self.p = parser
         self.n = lanes
+        self.merge_twin_calls = merge_twin_calls
+        self.conv = dict(conventions or {})
+        _CONTRACT[0] = bool(self.conv.get("fma"))
+        self.reach_stack = []
         self.globals = {}
         self.frames = []
         self.discarded = np.zeros(lanes, dtype=bool)
@@ -606,9 +647,14 @@ class Machine:
                 elif st[3] is not None:
                     self.exec(st[3], mask)
             else:
+                twin = self.merge_twin_calls and st[3] is not None and _twin_calls(st[2], st[3])
+                if twin:
+                    self.reach_stack.append(self._lanes(mask))
                 self.exec(st[2], self._and(mask, c.a))
                 if st[3] is not None:
                     self.exec(st[3], self._and(mask, ~c.a))
+                if twin:
+                    self.reach_stack.pop()
         elif kind == "for":
             self.push_scope(mask)
             self.exec(st[1], mask)
@@ -702,6 +748,10 @@ class Machine:
                 return self.eval(re_, mask)
             b = self.eval(re_, mask)
             return V("bool", (a.a & b.a) if op == "&&" else (a.a | b.a))
+        if _CONTRACT[0] and op in ("+", "-"):
+            fused = self._contract(op, le, re_, a, mask)
+            if fused is not None:
+                return fused
         b = self.eval(re_, mask)
         if op in ("==", "!=", "<", ">", "<=", ">="):
             if a.t != b.t or a.t not in _SCALARS:
@@ -711,6 +761,23 @@ class Machine:
                      ">=": np.greater_equal}[op](a.a, b.a)
             return V("bool", r)
         return self.arith(op, a, b)
+
+    def _contract(self, op, le, re_, a, mask):
+        """x * y + c / c + x * y / x * y - c / c - x * y as one rounding, for float scalars and vectors (sensitivity runs)."""
+        def product(e):
+            return e[0] == "bin" and e[1] == "*"
+        if product(re_):
+            x, y = self.eval(re_[2], mask), self.eval(re_[3], mask)
+            c, sign_p, sign_c = a, (1.0 if op == "+" else -1.0), 1.0
+        elif product(le):
+            x, y = self.eval(le[2], mask), self.eval(le[3], mask)
+            c, sign_p, sign_c = self.eval(re_, mask), 1.0, (1.0 if op == "+" else -1.0)
+        else:
+            return None
+        if any(_base(v.t) != "float" or v.t in _MAT for v in (x, y, c)):
+            return None
+        t = self.arith("+", self.arith("*", x, y), c).t
+        return V(t, _fma(F32(sign_p) * x.a, y.a, F32(sign_c) * c.a))
 
     def arith(self, op, a: V, b: V) -> V:
         ba, bb = _base(a.t), _base(b.t)
@@ -722,7 +789,7 @@ class Machine:
                     n = _MAT[a.t]
                     r = a.a[0] * b.a[0]
                     for k in range(1, n):
-                        r = r + a.a[k] * b.a[k]
+                        r = _fma(a.a[k], b.a[k], r) if _CONTRACT[0] else r + a.a[k] * b.a[k]
                     return V(b.t, r)
                 if a.t in _MAT and b.t in _MAT:      # (A B)[col] = A B[col]
                     n = _MAT[a.t]
@@ -878,6 +945,8 @@ class Machine:
 
     def bi_normalize(self, m, v):
         with np.errstate(all="ignore"):
+            if self.conv.get("normalize") == "div":
+                return V(v.t, v.a / np.sqrt(_dot(v.a, v.a)))
             return V(v.t, v.a * (F32(1.0) / np.sqrt(_dot(v.a, v.a))))
 
     def bi_sqrt(self, m, v):
@@ -914,6 +983,10 @@ class Machine:
 
     def bi_mix(self, m, a, b, t):
         with np.errstate(all="ignore"):
+            if self.conv.get("mix") == "lerp":
+                return V(self._same(a, b, t), a.a + (b.a - a.a) * t.a)
+            if _CONTRACT[0]:
+                return V(self._same(a, b, t), _fma(b.a, t.a, a.a * (F32(1.0) - t.a)))
             return V(self._same(a, b, t), a.a * (F32(1.0) - t.a) + b.a * t.a)
 
     def bi_smoothstep(self, m, e0, e1, x):
@@ -933,7 +1006,16 @@ class Machine:
         c = coord.a if coord.a.ndim == 2 else coord.a[None, :]
         lanes = self._lanes(self.live(mask))
         c = np.broadcast_to(c, (c.shape[0], self.n))
-        r = np.asarray(s.a.texture(np.where(lanes, c, F32(0.0)).astype(F32)), dtype=F32)
+        if getattr(s.a, "needs_quad", False):
+            # Implicit LOD: the unit sees the coordinate every lane holds at this call (the interpreter evaluates expressions
+            # for all lanes; masks only gate stores) and which lanes REACH the call: the lanes active here, or -- inside an
+            # if / else of twin calls with merge_twin_calls -- the lanes that entered that if / else.
+            reach = self.reach_stack[-1] & ~self.discarded if self.reach_stack else lanes
+            with np.errstate(all="ignore"):
+                r = np.asarray(s.a.texture_quad(np.where(np.isfinite(c), c, F32(0.0)).astype(F32), reach), dtype=F32)
+            r = np.where(lanes, r, F32(0.0))
+        else:
+            r = np.asarray(s.a.texture(np.where(lanes, c, F32(0.0)).astype(F32)), dtype=F32)
         z = np.zeros_like(r)
         return V("vec4", np.stack([r, z, z, z + F32(1.0)]))
 
@@ -945,6 +1027,6 @@ class Machine:
         return V("vec4", np.stack([r, z, z, z + F32(1.0)]))
 
 
-def load(path: str, defines: dict | None = None) -> Parser:
-    tokens, _ = preprocess(path, defines)
+def load(path: str, defines: dict | None = None, force_defines: dict | None = None) -> Parser:
+    tokens, _ = preprocess(path, defines, force_defines)
     return Parser(tokens).parse()

@@ -66,13 +66,21 @@ def run_bake(params):
 
 
 def run_frame(shader, defines, params, world_to_model, model_matrix, cam, depth, tex_units, time_s=0.0, rows=None,
-              sun=S.DEMO_SUN_POSITION):
-    """vertex() once, fragment() for every pixel of the viewport (or of the given rows)."""
-    p = VM.load(os.path.join(SHADERS, shader + ".gdshader"), defines)
+              sun=S.DEMO_SUN_POSITION, force_defines=None, cube_chain=None, merge_twin_calls=True, conventions=None,
+              cube_kwargs=None):
+    """vertex() once, fragment() for every pixel of the viewport (or of the given rows).
+    force_defines: macros that win over the shader file's own #defines (gdshader_vm.preprocess).
+    cube_chain: the coverage cubemap's mip chain [(6, n, n), ...] -> u_cloud_coverage_cubemap is sampled with the implicit LOD
+    of a linear-mipmap sampler (vm_textures.CubeTextureLod; derivatives from the 2 x 2 pixel quads of the executed lanes)."""
+    p = VM.load(os.path.join(SHADERS, shader + ".gdshader"), defines, force_defines)
     rows = list(range(cam.height)) if rows is None else list(rows)
     n = cam.width * len(rows)
     samplers = dict(tex_units, u_depth_texture=T.DepthTexture(depth))
-    m = VM.Machine(p, n, samplers, uniforms_for(p, params, world_to_model, sun), source_color=S.srgb_to_linear)
+    if cube_chain is not None:
+        samplers["u_cloud_coverage_cubemap"] = T.CubeTextureLod(cube_chain, RS.quad_partners(cam.width, rows, cam.height),
+                                                                **(cube_kwargs or {}))
+    m = VM.Machine(p, n, samplers, uniforms_for(p, params, world_to_model, sun), source_color=S.srgb_to_linear,
+                   merge_twin_calls=merge_twin_calls, conventions=conventions)
     g = m.globals
     ident = m.from_host("mat4", np.eye(4).reshape(-1))
     # vertex stage: the quad's vertices all produce the same varyings, one lane is enough
@@ -174,6 +182,73 @@ def main():
     print("wrote", path, os.path.getsize(path), "bytes;", "functions executed:", ", ".join(sorted(calls)))
 
 
+def with_partner_rows(rows, height):
+    """rows plus each row's vertical quad partner, sorted; and the positions of the requested rows in that list."""
+    full = sorted(set(rows) | {r ^ 1 for r in rows if (r ^ 1) < height})
+    return full, [full.index(r) for r in rows]
+
+
+def main_round3():
+    """tests/golden/reference_exec_r3.npz: the reference text executed (a) with the samplerCube it declares -- linear-mipmap,
+    implicit LOD from the 2 x 2 pixel quads -- and (b) at 32 and 64 view steps."""
+    t0 = time.time()
+    blue = S.make_blue_noise()
+    shape = S.make_shape_texture(SHAPE_N)
+    cube = S.make_coverage_cubemap(CUBE_N)
+    chain = T.mip_chain(cube)
+    z = np.load(os.path.join(HERE, "reference_exec.npz"))
+    out = {"crc_cubemap": np.uint32(S.checksum(cube)), "cube_levels": np.int64(len(chain)),
+           "crc_mips": np.array([S.checksum(lv) for lv in chain], dtype=np.uint32)}
+    params, model_matrix = scenes()["demo"]
+    lut = z["lut_demo"]
+    base_units = dict(u_optical_depth_texture=T.LutTexture(lut), u_blue_noise_texture=T.ByteTexture2D(blue),
+                      u_cloud_shape_texture=T.ShapeTexture(shape))
+    calls = {}
+    # (a) implicit LOD, 48 x 27 (height 27: the last row has no vertical partner)
+    for pose in RS.LOD_POSES:
+        cam = RS.camera_from_fixture(z, W, H, pose)
+        depth = z[f"depth_demo_{pose}"]
+        for shader in RS.LOD_VARIANTS:
+            rgba, disc, _, c = run_frame(shader, None, params, np.eye(4), model_matrix, cam, depth, base_units, cube_chain=chain)
+            calls.update(c)
+            out[f"lod_rgba_{pose}_{shader}"] = rgba
+            lod0 = z[f"rgba_demo_{pose}_{shader}"]
+            print(f"{time.time() - t0:6.1f}s lod {pose} {shader}: {int((~disc).sum())} kept, max |LOD - LOD0| = {np.abs(rgba - lod0).max():.3e}", flush=True)
+    # ... at BASELINE sizes with the bench's textures
+    big = demo_textures()
+    big_chain = T.mip_chain(big["cubemap"])
+    out["crc_cubemap_full"] = np.uint32(S.checksum(big["cubemap"]))
+    units = dict(base_units, u_cloud_shape_texture=T.ShapeTexture(big["shape"]))
+    for shader, w, h, pose, rows in RS.LOD_FULL_SIZE:
+        cam = RS.camera_from_fixture(z, w, h, pose)
+        depth = S.depth_ground_sphere(cam)
+        full, keep = with_partner_rows(rows, h)
+        rgba, disc, _, _ = run_frame(shader, None, params, np.eye(4), model_matrix, cam, depth, units, rows=full, cube_chain=big_chain)
+        key = f"lodfull_{w}x{h}_{pose}_{shader}"
+        out[f"rgba_{key}"], out[f"rows_{key}"], out[f"depth_{key}"] = rgba[keep], np.asarray(rows), depth[list(full)]
+        out[f"depthrows_{key}"] = np.asarray(full)
+        print(f"{time.time() - t0:6.1f}s {key}: rows {rows} (+ partners), {int((~disc).sum())} of {disc.size} kept", flush=True)
+    # (b) 32 and 64 view steps
+    for steps in RS.VIEW_STEP_COUNTS:
+        force = {"ATMOSPHERE_RAYMARCH_STEPS": steps}
+        for pose in POSES:
+            cam = RS.camera_from_fixture(z, W, H, pose)
+            rgba, disc, _, _ = run_frame("planet_atmosphere_no_clouds", None, params, np.eye(4), model_matrix, cam,
+                                         z[f"depth_demo_{pose}"], base_units, force_defines=force)
+            out[f"steps{steps}_rgba_{pose}"] = rgba
+            print(f"{time.time() - t0:6.1f}s no_clouds view steps {steps} {pose}: max |rgba - 8 steps| = "
+                  f"{np.abs(rgba - z[f'rgba_demo_{pose}_planet_atmosphere_no_clouds']).max():.3e}", flush=True)
+        shader, w, h, pose, rows = RS.VIEW_STEP_ROWS
+        cam = RS.camera_from_fixture(z, w, h, pose)
+        depth = S.depth_ground_sphere(cam)
+        rgba, disc, _, _ = run_frame(shader, None, params, np.eye(4), model_matrix, cam, depth, base_units, rows=rows, force_defines=force)
+        out[f"steps{steps}_rgba_full"], out[f"steps{steps}_depth_full"] = rgba, depth[list(rows)]
+        print(f"{time.time() - t0:6.1f}s no_clouds view steps {steps} 1920x1080 rows {rows}", flush=True)
+    path = os.path.join(HERE, "reference_exec_r3.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 class UnsetCube:
     """An unbound samplerCube: the engine's default white texture (README.md:46 "cover uniformly")."""
 
@@ -215,6 +290,10 @@ def main_fuzz():
 
 
 if __name__ == "__main__":
-    if "--fuzz-only" not in sys.argv:
-        main()
-    main_fuzz()
+    if "--round3-only" in sys.argv:
+        main_round3()
+    else:
+        if "--fuzz-only" not in sys.argv:
+            main()
+            main_round3()
+        main_fuzz()

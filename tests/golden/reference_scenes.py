@@ -50,6 +50,37 @@ FULL_SIZE = [
 ]
 
 
+# ---- round 3 vectors (reference_exec_r3.npz) -------------------------------------------------------------------------------
+# the reference's DECLARED cubemap sampler (linear-mipmap, implicit LOD: cloud_funcs.gdshaderinc:15,45) on the four cloud variants
+LOD_VARIANTS = ["planet_atmosphere_clouds", "planet_atmosphere_clouds_high", "planet_atmosphere_clouds_high_rm",
+                "planet_atmosphere_v1_clouds_high"]
+LOD_POSES = ["P_space", "P_clouds", "P_limb"]
+# ... and at BASELINE.json's sizes with the bench's 256^2 cubemap: (shader, w, h, pose, rows); the executed rows include each
+# row's vertical quad partner (row ^ 1)
+LOD_FULL_SIZE = [
+    ("planet_atmosphere_clouds_high", 1920, 1080, "P_space", (200, 540, 901)),
+    ("planet_atmosphere_clouds_high", 1920, 1080, "P_clouds", (300, 801)),
+    ("planet_atmosphere_clouds_high_rm", 3840, 2160, "P_space", (801, 1400)),
+]
+# north_star's 32 view steps and the 64 of atmosphere_funcs_v2.gdshaderinc:42-43, through the reference text with
+# ATMOSPHERE_RAYMARCH_STEPS forced over the file's own #define (planet_atmosphere_no_clouds.gdshader:4)
+VIEW_STEP_COUNTS = [32, 64]
+VIEW_STEP_ROWS = ("planet_atmosphere_no_clouds", 1920, 1080, "P_space", (40, 330, 539, 1000))
+
+
+def quad_partners(width, rows, height):
+    """Lane indices of the horizontal / vertical 2 x 2 quad partner of every pixel of the given rows (row-major lanes), -1
+    where the partner pixel is outside the viewport or its row is not executed."""
+    rows = list(rows)
+    pos = {r: k for k, r in enumerate(rows)}
+    px, py = np.meshgrid(np.arange(width), np.asarray(rows))
+    lane = np.arange(width * len(rows)).reshape(len(rows), width)
+    qx = np.where((px ^ 1) < width, lane // width * width + (px ^ 1), -1)
+    prow = np.array([pos.get(r ^ 1, -1) if (r ^ 1) < height else -1 for r in rows])
+    qy = np.where(prow[:, None] >= 0, prow[:, None] * width + px, -1)
+    return qx.reshape(-1), qy.reshape(-1)
+
+
 def camera_matrices(cam):
     """What a fixture stores of a camera (numpy's 4x4 inverse may differ in the last bit between hosts)."""
     return np.stack([cam.inv_projection, cam.inv_view, cam.view]).astype(np.float64)
