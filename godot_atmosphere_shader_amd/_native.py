@@ -27,7 +27,7 @@ CORE_SYMBOLS = (
 # every symbol include/atmo_debug.h declares: experiment knobs and diagnostics (tests, bench.py, tools/)
 DEBUG_SYMBOLS = (
     "atmo_set_lane_split", "atmo_get_feedback_stats", "atmo_set_timing", "atmo_get_timing", "atmo_host_layout_cubemap", "atmo_host_layout_shape",
-    "atmo_host_layout_lut", "atmo_host_cubemap_mip", "atmo_read_texture_layout", "atmo_selftest_exact_math", "atmo_kernel_name",
+    "atmo_host_layout_lut", "atmo_host_cubemap_mip", "atmo_read_texture_layout", "atmo_selftest_exact_math", "atmo_debug_marched_optical_depth", "atmo_kernel_name",
 )
 EXPORTED_SYMBOLS = CORE_SYMBOLS + DEBUG_SYMBOLS
 
@@ -100,6 +100,7 @@ def load() -> C.CDLL:
         "atmo_set_timing": (ip, [vp, ip]),
         "atmo_get_timing": (ip, [vp, C.POINTER(ip), C.POINTER(C.c_double)]),
         "atmo_selftest_exact_math": (ip, [vp, C.c_uint32, C.c_uint32, C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+        "atmo_debug_marched_optical_depth": (ip, [vp, ip, vp, vp, ip, vp]),
         "atmo_host_layout_cubemap": (ip, [vp, ip, vp]),
         "atmo_host_layout_shape": (ip, [vp, ip, vp]),
         "atmo_host_layout_lut": (ip, [vp, ip, ip, vp]),

@@ -1123,6 +1123,25 @@ int atmo_selftest_exact_math(AtmoContext *ctx, uint32_t first_bits, uint32_t cou
     return ATMO_OK;
 }
 
+int atmo_debug_marched_optical_depth(AtmoContext *ctx, int n, const float *pos_xyz, const float *dir_xyz, int light_steps, float *out) {
+    if (!ctx) return ATMO_E_ARG;
+    if (n < 1 || !pos_xyz || !dir_xyz || !out || light_steps < 1 || light_steps > 4096)
+        return fail(ctx, ATMO_E_ARG, "atmo_debug_marched_optical_depth: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)n * 3 * sizeof(float);
+    float *d = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d, 2 * bytes + (size_t)n * sizeof(float)));
+    float *dpos = d, *ddir = d + (size_t)n * 3, *dout = d + (size_t)n * 6;
+    hipError_t e = hipMemcpy(dpos, pos_xyz, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ddir, dir_xyz, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = atmo::launch_light_probe(dpos, ddir, n, ctx->p.u_planet_radius, ctx->p.u_atmosphere_height, ctx->p.u_density,
+                                                      light_steps, dout, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return hip_fail(ctx, e, "atmo_debug_marched_optical_depth");
+    return ATMO_OK;
+}
+
 const char *atmo_kernel_name(AtmoContext *ctx) {
     if (!ctx) return "";
     return atmo::render_kernel_name(ctx->last_flags >= 0 ? ctx->last_flags : ctx->flags, ctx->light_steps, ctx->last_split);

@@ -107,6 +107,8 @@ hipError_t launch_cube_mip(const uint8_t *level, int n, uint8_t *next, hipStream
 void render_grid(const RenderConsts &rc, int split, int *tiles_x, int *tiles_y);
 hipError_t launch_noise_cubemap(const NoiseCubemapConsts &nc, hipStream_t stream);
 const char *render_kernel_name(int flags, int light_steps, int split);
+hipError_t launch_light_probe(const float *pos, const float *dir, int n, float planet_radius, float atmosphere_height, float density,
+                              int light_steps, float *out, hipStream_t stream);
 hipError_t launch_selftest(uint32_t first_bits, uint32_t count, float c, float rc, unsigned int *mismatch_dev, hipStream_t stream);
 
 }  // namespace atmo

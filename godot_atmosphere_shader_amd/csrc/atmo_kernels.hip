@@ -465,6 +465,101 @@ __device__ __forceinline__ float cube_sample_lod(const RenderConsts &rc, V3 d, b
     return v0 * (1.0f - fr) + v1 * fr;
 }
 
+// The direct light march of one view sample (ATMO_LIGHT_DIRECT; SURVEY.md 8d "N view x M light steps"): the quantity the LUT
+// tabulates -- get_optical_depth of optical_depth.gdshader:17-31 over the chord of :56-65 -- from the sample at squared radius
+// r2 (position relative to the planet centre), bdot = dot(position, sun_dir), y3 = the sample's own (1 - height ratio)^3.
+// One definition for march_atmosphere and for the probe kernel behind atmo_debug_marched_optical_depth.
+struct LightMarchConsts {
+    float ninv_h, c1, dens2, ratm2, inv_light_steps;
+    int light_steps;
+};
+template <int LSTEPS>
+__device__ __forceinline__ float sun_od_direct(const LightMarchConsts &k, float r2, float bdot, float y3, float sq_pre) {
+#pragma clang fp contract(fast)
+    const float ninv_h = k.ninv_h, c1 = k.c1, dens2 = k.dens2, ratm2 = k.ratm2, inv_light_steps = k.inv_light_steps;
+    const int light_steps = k.light_steps;
+    (void)sq_pre;
+    // chord from the sample to the outer sphere along the sun direction, then a left Riemann sum.
+    // x1 - max(x0, 0) with x0 = -b - sq, x1 = sq - b  ==  min(x1 - x0, x1) = min(2 sq, sq - b)
+    const float hh = ratm2 - (r2 - bdot * bdot);
+#if ATMO_TRANS_CLUSTER >= 2
+    const float sq = sq_pre;
+#else
+    const float sq = hw_sqrt(fmaxf(hh, 0.0f));
+#endif
+#if ATMO_CHORD_MAX
+    // inside the outer sphere the forward exit distance is >= 0; hh < 0 (rounding at the shell) gives sq = 0 and
+    // min(0, -b), which the max folds to the reference's 0
+    const float ray_len = fmaxf(fminf(sq + sq, sq - bdot), 0.0f);
+#else
+    const float ray_len = (hh < 0.0f) ? 0.0f : fminf(sq + sq, sq - bdot);
+#endif
+    const float lstep = ray_len * inv_light_steps;
+    float acc = y3;  // sample 0 sits on the view sample itself
+    if (LSTEPS == 8 && (ATMO_TRANS_CLUSTER || ATMO_LIGHT_PK)) {
+        const float lb = lstep * (bdot + bdot), l2 = lstep * lstep;
+        float q[8], rr[8];
+#if ATMO_LIGHT_PK
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 l2v = {l2, l2}, lbv = {lb, lb}, r2v = {r2, r2};
+        const f2 j01 = {0.0f, 1.0f}, j23 = {2.0f, 3.0f}, j45 = {4.0f, 5.0f}, j67 = {6.0f, 7.0f};
+        const f2 s01 = {0.0f, 1.0f}, s23 = {4.0f, 9.0f}, s45 = {16.0f, 25.0f}, s67 = {36.0f, 49.0f};
+        auto quad = [&](f2 jj, f2 ss) { return __builtin_elementwise_fma(ss, l2v, __builtin_elementwise_fma(jj, lbv, r2v)); };
+        const f2 q01 = quad(j01, s01), q23 = quad(j23, s23), q45 = quad(j45, s45), q67 = quad(j67, s67);
+        q[0] = q01.x; q[1] = q01.y; q[2] = q23.x; q[3] = q23.y; q[4] = q45.x; q[5] = q45.y; q[6] = q67.x; q[7] = q67.y;
+#else
+#pragma unroll
+        for (int j = 1; j < 8; ++j) q[j] = fmaf((float)(j * j), l2, fmaf((float)j, lb, r2));
+#endif
+#if ATMO_TRANS_CLUSTER
+        asm volatile("v_sqrt_f32 %0, %7\n\tv_sqrt_f32 %1, %8\n\tv_sqrt_f32 %2, %9\n\tv_sqrt_f32 %3, %10\n\t"
+                     "v_sqrt_f32 %4, %11\n\tv_sqrt_f32 %5, %12\n\tv_sqrt_f32 %6, %13\n\ts_nop 0"
+                     : "=&v"(rr[1]), "=&v"(rr[2]), "=&v"(rr[3]), "=&v"(rr[4]), "=&v"(rr[5]), "=&v"(rr[6]), "=&v"(rr[7])
+                     : "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]));
+#else
+#pragma unroll
+        for (int j = 1; j < 8; ++j) rr[j] = hw_sqrt(q[j]);
+#endif
+#if ATMO_LIGHT_PK
+        const f2 nh = {ninv_h, ninv_h}, c1v = {c1, c1}, zero = {0.0f, 0.0f}, one = {1.0f, 1.0f};
+        auto dens = [&](f2 r) {
+            f2 y = __builtin_elementwise_fma(r, nh, c1v);
+            y = __builtin_elementwise_min(__builtin_elementwise_max(y, zero), one);
+            return y * y * y;
+        };
+        const f2 d23 = dens(f2{rr[2], rr[3]}), d45 = dens(f2{rr[4], rr[5]}), d67 = dens(f2{rr[6], rr[7]});
+        const float y1 = sat(fmaf(rr[1], ninv_h, c1));
+        const f2 sum = d23 + d45 + d67;
+        acc = fmaf(y1 * y1, y1, acc) + (sum.x + sum.y);
+#else
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            const float yy = sat(fmaf(rr[j], ninv_h, c1));
+            acc = fmaf(yy * yy, yy, acc);
+        }
+#endif
+    } else if (LSTEPS > 0) {
+        // |o + j*l*sun|^2 = r2 + j*(l*2b) + j^2*(l*l), |sun| = 1: two FMAs per sample
+        const float lb = lstep * (bdot + bdot), l2 = lstep * lstep;
+#pragma unroll
+        for (int j = 1; j < (LSTEPS > 0 ? LSTEPS : 1); ++j) {
+            const float rr = hw_sqrt(fmaf((float)(j * j), l2, fmaf((float)j, lb, r2)));
+            const float yy = sat(fmaf(rr, ninv_h, c1));
+            acc = fmaf(yy * yy, yy, acc);
+        }
+    } else {
+        const float b2 = bdot + bdot;
+        float sl = lstep;
+        for (int j = 1; j < light_steps; ++j) {
+            const float rr = hw_sqrt(fmaf(sl, sl + b2, r2));
+            const float yy = sat(fmaf(rr, ninv_h, c1));
+            acc = fmaf(yy * yy, yy, acc);
+            sl += lstep;
+        }
+    }
+    return acc * lstep * dens2;
+}
+
 // ---- compute_atmosphere_v2 -----------------------------------------------------------------------
 // Returns RGBA.  Well-conditioned: fused arithmetic + hardware transcendentals throughout.
 //   * alpha: the reference's recurrence alpha += (1-exp(-d))*(1-alpha) is 1 - prod(exp(-d_i))
@@ -492,6 +587,7 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
     const float ratm2 = rc.atmosphere_radius * rc.atmosphere_radius;
     const int light_steps = LSTEPS > 0 ? LSTEPS : rc.light_steps;
     const float inv_light_steps = LSTEPS > 0 ? 1.0f / (float)(LSTEPS > 0 ? LSTEPS : 1) : hw_rcp((float)light_steps);
+    const LightMarchConsts lmc = {ninv_h, c1, dens2, ratm2, inv_light_steps, light_steps};
     const float half_w = 0.5f * (float)rc.lut_w, x_off = half_w - 0.5f;
     const float lut_hf = (float)rc.lut_h, y_off = lut_hf - 0.5f;
 
@@ -525,85 +621,11 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
 
         float sun_od;
         if (DIRECT) {
-            // chord from the sample to the outer sphere along the sun direction, then a left Riemann sum.
-            // x1 - max(x0, 0) with x0 = -b - sq, x1 = sq - b  ==  min(x1 - x0, x1) = min(2 sq, sq - b)
-            const float hh = ratm2 - (r2 - bdot * bdot);
 #if ATMO_TRANS_CLUSTER >= 2
-            const float sq = sq_pre;
+            sun_od = sun_od_direct<LSTEPS>(lmc, r2, bdot, y3, sq_pre);
 #else
-            const float sq = hw_sqrt(fmaxf(hh, 0.0f));
+            sun_od = sun_od_direct<LSTEPS>(lmc, r2, bdot, y3, 0.0f);
 #endif
-#if ATMO_CHORD_MAX
-            // inside the outer sphere the forward exit distance is >= 0; hh < 0 (rounding at the shell) gives sq = 0 and
-            // min(0, -b), which the max folds to the reference's 0
-            const float ray_len = fmaxf(fminf(sq + sq, sq - bdot), 0.0f);
-#else
-            const float ray_len = (hh < 0.0f) ? 0.0f : fminf(sq + sq, sq - bdot);
-#endif
-            const float lstep = ray_len * inv_light_steps;
-            float acc = y3;  // sample 0 sits on the view sample itself
-            if (LSTEPS == 8 && (ATMO_TRANS_CLUSTER || ATMO_LIGHT_PK)) {
-                const float lb = lstep * (bdot + bdot), l2 = lstep * lstep;
-                float q[8], rr[8];
-#if ATMO_LIGHT_PK
-                typedef float f2 __attribute__((ext_vector_type(2)));
-                const f2 l2v = {l2, l2}, lbv = {lb, lb}, r2v = {r2, r2};
-                const f2 j01 = {0.0f, 1.0f}, j23 = {2.0f, 3.0f}, j45 = {4.0f, 5.0f}, j67 = {6.0f, 7.0f};
-                const f2 s01 = {0.0f, 1.0f}, s23 = {4.0f, 9.0f}, s45 = {16.0f, 25.0f}, s67 = {36.0f, 49.0f};
-                auto quad = [&](f2 jj, f2 ss) { return __builtin_elementwise_fma(ss, l2v, __builtin_elementwise_fma(jj, lbv, r2v)); };
-                const f2 q01 = quad(j01, s01), q23 = quad(j23, s23), q45 = quad(j45, s45), q67 = quad(j67, s67);
-                q[0] = q01.x; q[1] = q01.y; q[2] = q23.x; q[3] = q23.y; q[4] = q45.x; q[5] = q45.y; q[6] = q67.x; q[7] = q67.y;
-#else
-#pragma unroll
-                for (int j = 1; j < 8; ++j) q[j] = fmaf((float)(j * j), l2, fmaf((float)j, lb, r2));
-#endif
-#if ATMO_TRANS_CLUSTER
-                asm volatile("v_sqrt_f32 %0, %7\n\tv_sqrt_f32 %1, %8\n\tv_sqrt_f32 %2, %9\n\tv_sqrt_f32 %3, %10\n\t"
-                             "v_sqrt_f32 %4, %11\n\tv_sqrt_f32 %5, %12\n\tv_sqrt_f32 %6, %13\n\ts_nop 0"
-                             : "=&v"(rr[1]), "=&v"(rr[2]), "=&v"(rr[3]), "=&v"(rr[4]), "=&v"(rr[5]), "=&v"(rr[6]), "=&v"(rr[7])
-                             : "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]));
-#else
-#pragma unroll
-                for (int j = 1; j < 8; ++j) rr[j] = hw_sqrt(q[j]);
-#endif
-#if ATMO_LIGHT_PK
-                const f2 nh = {ninv_h, ninv_h}, c1v = {c1, c1}, zero = {0.0f, 0.0f}, one = {1.0f, 1.0f};
-                auto dens = [&](f2 r) {
-                    f2 y = __builtin_elementwise_fma(r, nh, c1v);
-                    y = __builtin_elementwise_min(__builtin_elementwise_max(y, zero), one);
-                    return y * y * y;
-                };
-                const f2 d23 = dens(f2{rr[2], rr[3]}), d45 = dens(f2{rr[4], rr[5]}), d67 = dens(f2{rr[6], rr[7]});
-                const float y1 = sat(fmaf(rr[1], ninv_h, c1));
-                const f2 sum = d23 + d45 + d67;
-                acc = fmaf(y1 * y1, y1, acc) + (sum.x + sum.y);
-#else
-#pragma unroll
-                for (int j = 1; j < 8; ++j) {
-                    const float yy = sat(fmaf(rr[j], ninv_h, c1));
-                    acc = fmaf(yy * yy, yy, acc);
-                }
-#endif
-            } else if (LSTEPS > 0) {
-                // |o + j*l*sun|^2 = r2 + j*(l*2b) + j^2*(l*l), |sun| = 1: two FMAs per sample
-                const float lb = lstep * (bdot + bdot), l2 = lstep * lstep;
-#pragma unroll
-                for (int j = 1; j < (LSTEPS > 0 ? LSTEPS : 1); ++j) {
-                    const float rr = hw_sqrt(fmaf((float)(j * j), l2, fmaf((float)j, lb, r2)));
-                    const float yy = sat(fmaf(rr, ninv_h, c1));
-                    acc = fmaf(yy * yy, yy, acc);
-                }
-            } else {
-                const float b2 = bdot + bdot;
-                float sl = lstep;
-                for (int j = 1; j < light_steps; ++j) {
-                    const float rr = hw_sqrt(fmaf(sl, sl + b2, r2));
-                    const float yy = sat(fmaf(rr, ninv_h, c1));
-                    acc = fmaf(yy * yy, yy, acc);
-                    sl += lstep;
-                }
-            }
-            sun_od = acc * lstep * dens2;
         } else {
             // uv = (0.5 + 0.5*cos, height_ratio) -> texel space
             const float x = fmaf(bdot * inv_r, half_w, x_off);
@@ -1633,6 +1655,46 @@ __global__ __launch_bounds__(256) void atmo_noise_cubemap_kernel(const NoiseCube
 hipError_t launch_noise_cubemap(const NoiseCubemapConsts &nc, hipStream_t stream) {
     dim3 grid((nc.resolution + 63) / 64, (nc.resolution + 3) / 4, 6);
     hipLaunchKernelGGL(atmo_noise_cubemap_kernel, grid, dim3(256), 0, stream, nc);
+    return hipGetLastError();
+}
+
+// ---- probe of the direct light march (atmo_debug_marched_optical_depth) ----------------------------------------------------
+// Evaluates sun_od_direct -- the very function march_atmosphere<DIRECT> inlines -- for n given sample positions (relative to the
+// planet centre) and sun directions, so the kernel's light march can be held against the reference's LUT texels, which
+// tabulate the same integral at its texel-centre geometry (optical_depth.gdshader:45-65).  Same set-up arithmetic as the
+// head of march_atmosphere's loop body.
+__global__ __launch_bounds__(256) void atmo_light_probe_kernel(const float *__restrict__ pos, const float *__restrict__ dir, int n,
+                                                               float planet_radius, float atmosphere_height, float density, int light_steps,
+                                                               float *__restrict__ out) {
+#pragma clang fp contract(fast)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float inv_h = hw_rcp(atmosphere_height);
+    LightMarchConsts k;
+    k.ninv_h = -inv_h;
+    k.c1 = fmaf(planet_radius, inv_h, 1.0f);
+    k.dens2 = density * density;
+    const float ratm = planet_radius + atmosphere_height;
+    k.ratm2 = ratm * ratm;
+    k.light_steps = light_steps;
+    k.inv_light_steps = hw_rcp((float)light_steps);
+    const float ox = pos[3 * i], oy = pos[3 * i + 1], oz = pos[3 * i + 2];
+    const float sx = dir[3 * i], sy = dir[3 * i + 1], sz = dir[3 * i + 2];
+    const float r2 = ox * ox + oy * oy + oz * oz;
+    const float bdot = ox * sx + oy * sy + oz * sz;
+    const float r = hw_sqrt(r2);
+    const float y = sat(fmaf(r, k.ninv_h, k.c1));
+    float sq_pre = 0.0f;
+#if ATMO_TRANS_CLUSTER >= 2
+    sq_pre = hw_sqrt(fmaxf(k.ratm2 - (r2 - bdot * bdot), 0.0f));
+#endif
+    out[i] = light_steps == 8 ? sun_od_direct<8>(k, r2, bdot, y * y * y, sq_pre) : sun_od_direct<0>(k, r2, bdot, y * y * y, sq_pre);
+}
+
+hipError_t launch_light_probe(const float *pos, const float *dir, int n, float planet_radius, float atmosphere_height, float density,
+                              int light_steps, float *out, hipStream_t stream) {
+    hipLaunchKernelGGL(atmo_light_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pos, dir, n, planet_radius, atmosphere_height,
+                       density, light_steps, out);
     return hipGetLastError();
 }
 

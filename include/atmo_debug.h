@@ -57,6 +57,12 @@ int atmo_read_texture_layout(AtmoContext *ctx, const char *name, void *out_host,
 int atmo_selftest_exact_math(AtmoContext *ctx, uint32_t first_bits, uint32_t count, float divisor,
                              uint32_t *sqrt_mismatches, uint32_t *div_mismatches);
 
+/* Diagnostics (no reference counterpart): runs the kernels' direct light march (ATMO_LIGHT_DIRECT; the device function the render
+ * kernel inlines) for n sample positions -- xyz relative to the planet centre -- and unit sun directions, host arrays in,
+ * host array out, with the context's u_planet_radius / u_atmosphere_height / u_density.  With light_steps = 64 at the LUT's
+ * texel-centre geometry (shaders/optical_depth.gdshader:45-65) this is the integral the reference bakes into that texel. */
+int atmo_debug_marched_optical_depth(AtmoContext *ctx, int n, const float *pos_xyz, const float *dir_xyz, int light_steps, float *out);
+
 /* Name of the kernel the most recent atmo_render of this context launched, "atmo_render_kernel<FLAGS, LSTEPS, SPLIT>"
  * (before the first launch: the one-lane-per-ray form), for matching rocprofv3 kernel traces. */
 const char *atmo_kernel_name(AtmoContext *ctx);

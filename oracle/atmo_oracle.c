@@ -1025,6 +1025,19 @@ REAL SFX(oracle_get_atmosphere_density)(float planet_radius, float atmosphere_he
     return get_atmosphere_density(&c, height);
 }
 
+/* the direct light march (get_marched_optical_depth) for n samples: pos3 / dir3 arrays, planet centre at the origin */
+void SFX(oracle_marched_optical_depth)(float planet_radius, float atmosphere_height, float density, int n, const REAL *pos3,
+                                       const REAL *dir3, int steps, REAL *out) {
+    OracleParams p;
+    memset(&p, 0, sizeof(p));
+    p.u_planet_radius = planet_radius; p.u_atmosphere_height = atmosphere_height; p.u_density = density;
+    Ctx c;
+    ctx_init(&c, &p, NULL, NULL);
+    for (int i = 0; i < n; ++i)
+        out[i] = get_marched_optical_depth(&c, v3(pos3[3 * i], pos3[3 * i + 1], pos3[3 * i + 2]),
+                                           v3(dir3[3 * i], dir3[3 * i + 1], dir3[3 * i + 2]), v3(K(0.0), K(0.0), K(0.0)), steps);
+}
+
 void SFX(oracle_blend_colors)(const REAL *self4, const REAL *over4, REAL *out4) {
     vec4 s = {self4[0], self4[1], self4[2], self4[3]}, o = {over4[0], over4[1], over4[2], over4[3]};
     vec4 r = blend_colors(s, o);

@@ -163,6 +163,7 @@ class Oracle:
         f("oracle_ray_sphere", None, [RP, R, RP, RP, RP])
         f("oracle_get_atmosphere_density", R, [C.c_float, C.c_float, C.c_float, R])
         f("oracle_blend_colors", None, [RP, RP, RP])
+        f("oracle_marched_optical_depth", None, [C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p])
         f("oracle_sample_lut", R, [C.POINTER(OracleTextures), R, R])
         f("oracle_sample_shape", R, [C.POINTER(OracleTextures), RP])
         f("oracle_sample_cube", R, [C.POINTER(OracleTextures), RP])
@@ -295,6 +296,16 @@ class Oracle:
         out = np.empty((h, w), dtype=np.float32)
         self._oracle_bake_optical_depth(planet_radius, atmosphere_height, density, w, h, steps,
                                         out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def marched_optical_depth(self, planet_radius, atmosphere_height, density, pos, direction, steps):
+        """get_marched_optical_depth (the direct light mode's sun-ray integral) for (n, 3) positions relative to the planet
+        centre and (n, 3) unit directions."""
+        pos = np.ascontiguousarray(pos, dtype=self.np_real)
+        direction = np.ascontiguousarray(direction, dtype=self.np_real)
+        out = np.empty(pos.shape[0], dtype=self.np_real)
+        self._oracle_marched_optical_depth(planet_radius, atmosphere_height, density, pos.shape[0], pos.ctypes.data_as(C.c_void_p),
+                                           direction.ctypes.data_as(C.c_void_p), steps, out.ctypes.data_as(C.c_void_p))
         return out
 
     def _vec(self, v):

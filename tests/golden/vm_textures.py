@@ -12,6 +12,14 @@ def _mix(a, b, t):
     return a * (F32(1.0) - t) + b * t
 
 
+def _quantize(f, bits):
+    """Sensitivity runs only: a filter weight held to `bits` fractional bits, as texture units do (0 = exact float32)."""
+    if not bits:
+        return f
+    q = F32(1 << bits)
+    return (np.floor(f * q + F32(0.5)) / q).astype(F32)
+
+
 def _floor_int(x):
     with np.errstate(all="ignore"):
         f = np.floor(x)
@@ -22,15 +30,16 @@ def _floor_int(x):
 class LutTexture:
     """sampler2D, repeat_disable, linear: the optical-depth LUT (R32F), clamp to edge, texel centres at (i + 0.5) / N."""
 
-    def __init__(self, lut):
+    def __init__(self, lut, quantize_bits=0):
         self.t = np.ascontiguousarray(lut, dtype=F32)
+        self.q = quantize_bits
 
     def texture(self, c):
         h, w = self.t.shape
         x, y = c[0] * F32(w) - F32(0.5), c[1] * F32(h) - F32(0.5)
         xf, xi = _floor_int(x)
         yf, yi = _floor_int(y)
-        fx, fy = x - xf, y - yf
+        fx, fy = _quantize(x - xf, self.q), _quantize(y - yf, self.q)
         i0, i1 = np.clip(xi, 0, w - 1), np.clip(xi + 1, 0, w - 1)
         j0, j1 = np.clip(yi, 0, h - 1), np.clip(yi + 1, 0, h - 1)
         t = self.t
@@ -64,14 +73,15 @@ class ByteTexture2D:
 class ShapeTexture:
     """sampler3D, repeat_enable, linear over an R8 volume indexed [z, y, x]: trilinear, mix order x, y, z."""
 
-    def __init__(self, texels):
+    def __init__(self, texels, quantize_bits=0):
         self.t = np.ascontiguousarray(texels, dtype=np.uint8)
+        self.q = quantize_bits
 
     def texture(self, c):
         n = self.t.shape[0]
         q = [c[k] * F32(n) - F32(0.5) for k in range(3)]
         fl = [_floor_int(v) for v in q]
-        f = [q[k] - fl[k][0] for k in range(3)]
+        f = [_quantize(q[k] - fl[k][0], self.q) for k in range(3)]
         i0 = [fl[k][1] % n for k in range(3)]
         i1 = [(fl[k][1] + 1) % n for k in range(3)]
 
@@ -171,10 +181,7 @@ def _bilinear_seamless(padded, face, s, t, quantize_bits=0):
     u, v = s * F32(n) - F32(0.5), t * F32(n) - F32(0.5)
     uf, ui = _floor_int(u)
     vf, vi = _floor_int(v)
-    fx, fy = (u - uf).astype(F32), (v - vf).astype(F32)
-    if quantize_bits:  # sensitivity runs only: filter weights held to a fixed-point fraction, as texture units do
-        q = F32(1 << quantize_bits)
-        fx, fy = (np.floor(fx * q + F32(0.5)) / q).astype(F32), (np.floor(fy * q + F32(0.5)) / q).astype(F32)
+    fx, fy = _quantize((u - uf).astype(F32), quantize_bits), _quantize((v - vf).astype(F32), quantize_bits)
     i0, j0 = np.clip(ui, -1, n - 1), np.clip(vi, -1, n - 1)
 
     def s8(i, j):
@@ -250,7 +257,7 @@ class CubeTextureLod:
                     dt = ((dtc * ma - tc * dma) * inv).astype(F32)
                     r2 = ((ds * ds + dt * dt) * n2).astype(F32)
                 rho2 = np.where(ok, np.fmax(rho2, r2), rho2)
-            lam = np.where(rho2 > 0, F32(0.5) * np.log2(np.where(rho2 > 0, rho2, F32(1.0))).astype(F32), F32(0.0)).astype(F32)
+            lam = np.where(rho2 > 0, F32(0.5) * np.log2(np.where(rho2 > 0, rho2, F32(1.0)).astype(np.float64)).astype(F32), F32(0.0)).astype(F32)  # log2 rounded once
         lam = np.fmin(np.fmax(lam, F32(0.0)), F32(nl - 1))
         lf = np.floor(lam)
         lo = lf.astype(np.int64)
