@@ -124,6 +124,12 @@ struct AtmoContext {
         int tiles_x = 0, tiles_y = 0, split = 0;
         hipStream_t draw_stream = nullptr;
         DeviceBuffer cost, order[2];   // one cost buffer; two orders: the one in use and the one being sorted
+        DeviceBuffer dil[2];           // scratch of the cost-map dilation (moving camera)
+        AtmoFrame prev_frame;          // the previous draw's camera: screen-space motion estimate
+        bool have_prev = false;
+        float motion_px = 0.0f;        // pixels per frame the picture's features move (peak-held estimate)
+        float order_reach_px[2] = {0.0f, 0.0f};  // how far features may have moved for order[k] to stay conservative
+        unsigned order_born[2] = {0, 0};         // n of the recording draw order[k] was sorted from
         unsigned n = 0;                // draws of this key so far
         unsigned last_record = 0;      // n of the last draw that recorded costs
         int active = -1;               // order[active] is complete and in use; -1: row-major order
@@ -367,6 +373,53 @@ int dev_reserve(AtmoContext *ctx, DeviceBuffer &b, size_t bytes) {
     return dev_alloc(ctx, b, bytes);
 }
 
+// How far, in pixels, the picture's features move between two consecutive frames: the planet's centre and six points of its
+// surface (fixed in world space: the planet turns slowly, the camera flies) projected with both cameras, the largest
+// displacement among those in front of both.  Scheduling only -- the pixels never depend on it -- so a plain symmetric
+// perspective is assumed for the projection (inv_p[0], inv_p[5] = the tangents of the half field of view).
+float feedback_motion_px(const AtmoFrame &a, const AtmoFrame &b, float radius) {
+    auto to_world = [](const AtmoFrame &f, const float *v, float *w) {
+        const float *M = f.inv_view_matrix;
+        for (int r = 0; r < 3; ++r) w[r] = M[r] * v[0] + M[4 + r] * v[1] + M[8 + r] * v[2] + M[12 + r];
+    };
+    auto to_pixel = [](const AtmoFrame &f, const float *w, float *px) {
+        const float *M = f.inv_view_matrix;  // rigid: view = R^T (w - t)
+        const float d[3] = {w[0] - M[12], w[1] - M[13], w[2] - M[14]};
+        const float vx = M[0] * d[0] + M[1] * d[1] + M[2] * d[2];
+        const float vy = M[4] * d[0] + M[5] * d[1] + M[6] * d[2];
+        const float vz = M[8] * d[0] + M[9] * d[1] + M[10] * d[2];
+        if (!(vz < -1e-6f)) return false;
+        const float tx = f.inv_projection_matrix[0], ty = f.inv_projection_matrix[5];
+        if (tx == 0.0f || ty == 0.0f) return false;
+        px[0] = (0.5f + 0.5f * (vx / -vz) / tx) * (float)f.viewport_w;
+        px[1] = (0.5f + 0.5f * (vy / -vz) / ty) * (float)f.viewport_h;
+        return true;
+    };
+    float c[3];
+    to_world(a, a.planet_center_viewspace, c);
+    float worst = 0.0f;
+    bool any = false;
+    for (int k = 0; k < 7; ++k) {
+        float w[3] = {c[0], c[1], c[2]};
+        if (k > 0) w[(k - 1) >> 1] += ((k - 1) & 1) ? -radius : radius;
+        float pa[2], pb[2];
+        if (!to_pixel(a, w, pa) || !to_pixel(b, w, pb)) continue;
+        const float dx = pa[0] - pb[0], dy = pa[1] - pb[1];
+        const float d = std::sqrt(dx * dx + dy * dy);
+        if (d == d) { worst = std::fmax(worst, d); any = true; }
+    }
+    if (!any) {  // nothing of the planet in front of the camera: the camera's own turn, in pixels
+        const float *A = a.inv_view_matrix, *B = b.inv_view_matrix;
+        float tr = 0.0f;
+        for (int cidx = 0; cidx < 3; ++cidx)
+            for (int r = 0; r < 3; ++r) tr += A[cidx * 4 + r] * B[cidx * 4 + r];
+        const float cosang = std::fmin(std::fmax(0.5f * (tr - 1.0f), -1.0f), 1.0f);
+        const float ty = std::fabs(a.inv_projection_matrix[5]);
+        worst = std::acos(cosang) * (ty > 0.0f ? 0.5f * (float)a.viewport_h / ty : (float)a.viewport_h);
+    }
+    return worst;
+}
+
 // Waits until nothing on the device can still touch the buffers of feedback state `f` (its pending sort; draws on its
 // stream reading an order).  Only needed when the slot is recycled for another key or its buffers must grow.
 int feedback_quiesce(AtmoContext *ctx, AtmoContext::FeedbackState &f, hipStream_t new_stream) {
@@ -416,6 +469,7 @@ int feedback_state(AtmoContext *ctx, int gx, int gy, int split, hipStream_t s, A
     // (an unused slot is quiet by construction -- never used, or quiesced when it was released -- so growing may free)
     int rc1 = dev_reserve(ctx, f.cost, bytes);
     for (int k = 0; k < 2 && rc1 == ATMO_OK; ++k) rc1 = dev_reserve(ctx, f.order[k], bytes);
+    for (int k = 0; k < 2 && rc1 == ATMO_OK; ++k) rc1 = dev_reserve(ctx, f.dil[k], bytes);
     if (rc1 != ATMO_OK) { f.used = false; return rc1; }
     if (!f.ev_draw) {
         HIP_TRY(ctx, hipEventCreateWithFlags(&f.ev_draw, hipEventDisableTiming));
@@ -430,6 +484,8 @@ int feedback_state(AtmoContext *ctx, int gx, int gy, int split, hipStream_t s, A
     f.active = -1;
     f.write = 0;
     f.pending = false;
+    f.have_prev = false;
+    f.motion_px = 0.0f;
     f.last_use = ctx->fb_clock;
     *out = &f;
     return ATMO_OK;
@@ -531,6 +587,7 @@ int atmo_destroy(AtmoContext *ctx) {
         for (int k = 0; k < 2; ++k) {
             if (f.ev_order[k]) (void)hipEventDestroy(f.ev_order[k]);
             dev_free(f.order[k]);
+            dev_free(f.dil[k]);
         }
         dev_free(f.cost);
     }
@@ -963,7 +1020,24 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         const int rc1 = feedback_state(ctx, gx, gy, split, s, &fb);
         if (rc1 != ATMO_OK) return rc1;
     }
+    // A moving camera (planet_atmosphere.gd:285-341 writes new matrices every frame; demo/avatar.gd, demo/mouse_look.gd): an order
+    // is used fb_lag frames after the costs it was sorted from were measured.  The host predicts how far the picture's features
+    // move in that time; the sort dilates the cost map by that distance, so a tile counts as cheap only if everything within
+    // reach of it was cheap (atmo_tile_dilate_kernel); costs are recorded every 2nd draw instead of every fb_period-th while
+    // the camera moves; and an order whose reach the motion has outrun is not used (row-major instead).
+    constexpr float FB_STILL_PX = 0.5f, FB_MAX_REACH_PX = 160.0f;
+    int dil_rx = 0, dil_ry = 0;
+    float reach_px = 0.0f;
     if (fb) {
+        if (fb->have_prev) {
+            const float m = feedback_motion_px(*frame, fb->prev_frame, ctx->p.u_planet_radius);
+            fb->motion_px = std::fmax(m, 0.75f * fb->motion_px);  // peak hold: one still frame does not end a camera move
+            if (fb->motion_px < 0.01f) fb->motion_px = 0.0f;
+        }
+        fb->prev_frame = *frame;
+        fb->have_prev = true;
+        const bool moving = fb->motion_px > FB_STILL_PX;
+        const unsigned period = moving ? (ctx->fb_period < 2u ? ctx->fb_period : 2u) : ctx->fb_period;
         if (fb->pending) {
             if (hipEventQuery(fb->ev_order[fb->write]) == hipSuccess) {
                 fb->active = fb->write;  // complete: no stream-side wait needed
@@ -973,11 +1047,25 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
                 (void)hipGetLastError();  // hipErrorNotReady is an answer, not an error: keep it out of the launch checks below
             }
         }
-        if (fb->active >= 0) { rc.tile_order = (const uint32_t *)fb->order[fb->active].ptr; ctx->fb_ordered_draws += 1; }
+        if (fb->active >= 0) {
+            // still conservative?  features have moved about motion_px * (frames since the costs were measured)
+            const float moved = fb->motion_px * (float)(fb->n - fb->order_born[fb->active]);
+            if (moved <= fb->order_reach_px[fb->active] + 8.0f) {
+                rc.tile_order = (const uint32_t *)fb->order[fb->active].ptr;
+                ctx->fb_ordered_draws += 1;
+            }
+        }
         // the first two draws of a key are not measured (cold clocks and caches rank the tiles poorly); the next four
-        // record back to back (the order settles in a few frames), then every fb_period-th
-        fb_record = !fb->pending && fb->n >= 2 && (fb->n < 6 || fb->n - fb->last_record >= ctx->fb_period);
-        if (fb_record) rc.tile_cost = (uint32_t *)fb->cost.ptr;
+        // record back to back (the order settles in a few frames), then every period-th
+        fb_record = !fb->pending && fb->n >= 2 && (fb->n < 6 || fb->n - fb->last_record >= period);
+        if (fb_record) {
+            rc.tile_cost = (uint32_t *)fb->cost.ptr;
+            // the order sorted from this draw is in use from about 2 frames later until the next one takes over
+            reach_px = moving ? std::fmin(fb->motion_px * (float)(period + 4u), FB_MAX_REACH_PX) : 0.0f;
+            const int tile_h = (rc.y1 - rc.y0 + gy - 1) / gy;  // pixel rows per tile of this launch (8, or 4 with two lanes per ray)
+            dil_rx = reach_px > 0.0f ? (int)std::ceil(reach_px / 16.0f) : 0;
+            dil_ry = reach_px > 0.0f ? (int)std::ceil(reach_px / (float)(tile_h > 0 ? tile_h : 8)) : 0;
+        }
     }
     // kernel timing brackets the draw kernel alone (the tile-order kernel runs beside the previous draw).  The event pair
     // is owned by a guard until it is handed to ctx->pending, so no error path leaks it.
@@ -1014,8 +1102,10 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         // order[write] was last read by draws enqueued on `s` before this one, so the event orders the write too.
         HIP_TRY(ctx, hipEventRecord(fb->ev_draw, s));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->fb_stream, fb->ev_draw, 0));
-        HIP_TRY(ctx, atmo::launch_tile_order((uint32_t *)fb->cost.ptr, (uint32_t *)fb->order[fb->write].ptr, gx * gy,
-                                             (uint32_t *)ctx->fb_scratch.ptr, ctx->fb_stream));
+        HIP_TRY(ctx, atmo::launch_tile_order((uint32_t *)fb->cost.ptr, (uint32_t *)fb->order[fb->write].ptr, gx, gy, dil_rx, dil_ry,
+                                             (uint32_t *)fb->dil[0].ptr, (uint32_t *)fb->dil[1].ptr, (uint32_t *)ctx->fb_scratch.ptr, ctx->fb_stream));
+        fb->order_reach_px[fb->write] = reach_px;
+        fb->order_born[fb->write] = fb->n;
         HIP_TRY(ctx, hipEventRecord(fb->ev_order[fb->write], ctx->fb_stream));
         fb->pending = true;
         fb->last_record = fb->n;

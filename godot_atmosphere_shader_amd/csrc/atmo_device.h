@@ -97,7 +97,8 @@ enum KernelFlags : int { KF_CLOUDS = 1, KF_CLOUD_LIGHT_RM = 2, KF_LIGHT_DIRECT =
 
 hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream_t stream);
 hipError_t launch_bake(const BakeConsts &bc, hipStream_t stream);
-hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int n, uint32_t *scratch, hipStream_t stream);
+hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int tiles_x, int tiles_y, int rx, int ry, uint32_t *tmp1, uint32_t *tmp2,
+                             uint32_t *scratch, hipStream_t stream);
 size_t tile_order_scratch_bytes();
 hipError_t launch_layout_lut(const float *lut, int w, int h, float *out, hipStream_t stream);
 hipError_t launch_lut_footprints(const float *apron, int w, int h, float *out4, hipStream_t stream);

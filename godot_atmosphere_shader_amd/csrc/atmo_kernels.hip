@@ -1464,8 +1464,8 @@ __global__ __launch_bounds__(256) void atmo_tile_scan_kernel(uint32_t *__restric
     }
 }
 
-__global__ __launch_bounds__(64) void atmo_tile_scatter_kernel(uint32_t *__restrict__ cost, const uint32_t *__restrict__ base,
-                                                               uint32_t *__restrict__ order, int n) {
+__global__ __launch_bounds__(64) void atmo_tile_scatter_kernel(const uint32_t *key, uint32_t *cost,  /* key == cost without dilation */
+                                                               const uint32_t *__restrict__ base, uint32_t *__restrict__ order, int n) {
     __shared__ uint32_t off[ORDER_CLASSES];
     const int lane = threadIdx.x, chunk = (n + ORDER_BLOCKS - 1) / ORDER_BLOCKS;
     const int i0 = min((int)blockIdx.x * chunk, n), i1 = min(i0 + chunk, n);
@@ -1473,7 +1473,7 @@ __global__ __launch_bounds__(64) void atmo_tile_scatter_kernel(uint32_t *__restr
     __syncthreads();
     for (int i = i0; i < i1; i += 64) {
         const bool valid = i + lane < i1;
-        const uint32_t c = valid ? tile_cost_class(cost[i + lane]) : 0u;
+        const uint32_t c = valid ? tile_cost_class(key[i + lane]) : 0u;
         const unsigned long long m = match_class(c, valid);
         const int r = lanes_below(m);
         uint32_t pos = 0;
@@ -1483,17 +1483,49 @@ __global__ __launch_bounds__(64) void atmo_tile_scatter_kernel(uint32_t *__restr
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (valid) {
             order[pos] = (uint32_t)(i + lane);
-            cost[i + lane] = 0;
+            cost[i + lane] = 0;   // ready for the next recording draw
         }
     }
 }
 
-// scratch: ORDER_BLOCKS * ORDER_CLASSES uint32 (tile_order_scratch_bytes)
+// Dilation of the cost map for a MOVING camera (separable max filter, radius rx / ry tiles): the order a sort produces is
+// used a few frames later, when every feature of the cost map -- the planet's limb, the terminator, a cloud bank -- has
+// moved on by up to the distance the host predicts from the camera matrices (atmo_api.hip, feedback_motion_px).  A tile that
+// was cheap but lies within that distance of an expensive one may be expensive by then, and one such tile dispatched at
+// the very end of a draw costs its whole duration as tail (measured: panning at 1 degree per frame turned the +48 % of
+// clouds_high_rm into -6.5 %, profiles/round3/ab_tile_feedback_motion.txt).  The max filter makes the cost the sort sees an
+// upper bound of what the tile can cost after the move: only tiles that are SURELY still cheap go last.
+__global__ __launch_bounds__(256) void atmo_tile_dilate_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int tiles_x, int tiles_y,
+                                                               int rx, int ry) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= tiles_x * tiles_y) return;
+    const int y = i / tiles_x, x = i - y * tiles_x;
+    uint32_t m = 0;
+    for (int d = -ry; d <= ry; ++d) {
+        const int yy = y + d;
+        if (yy < 0 || yy >= tiles_y) continue;
+        for (int e = -rx; e <= rx; ++e) {
+            const int xx = x + e;
+            if (xx >= 0 && xx < tiles_x) m = max(m, in[yy * tiles_x + xx]);
+        }
+    }
+    out[i] = m;
+}
+
+// scratch: ORDER_BLOCKS * ORDER_CLASSES uint32 (tile_order_scratch_bytes); tmp1 / tmp2: n uint32 each, used when rx | ry > 0
 size_t tile_order_scratch_bytes() { return (size_t)ORDER_BLOCKS * ORDER_CLASSES * sizeof(uint32_t); }
-hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int n, uint32_t *scratch, hipStream_t stream) {
-    hipLaunchKernelGGL(atmo_tile_hist_kernel, dim3(ORDER_BLOCKS), dim3(64), 0, stream, cost, scratch, n);
+hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int tiles_x, int tiles_y, int rx, int ry, uint32_t *tmp1, uint32_t *tmp2,
+                             uint32_t *scratch, hipStream_t stream) {
+    const int n = tiles_x * tiles_y;
+    const uint32_t *key = cost;
+    if (rx > 0 || ry > 0) {  // separable: rows, then columns
+        hipLaunchKernelGGL(atmo_tile_dilate_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cost, tmp1, tiles_x, tiles_y, rx, 0);
+        hipLaunchKernelGGL(atmo_tile_dilate_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, tmp1, tmp2, tiles_x, tiles_y, 0, ry);
+        key = tmp2;
+    }
+    hipLaunchKernelGGL(atmo_tile_hist_kernel, dim3(ORDER_BLOCKS), dim3(64), 0, stream, key, scratch, n);
     hipLaunchKernelGGL(atmo_tile_scan_kernel, dim3(1), dim3(256), 0, stream, scratch);
-    hipLaunchKernelGGL(atmo_tile_scatter_kernel, dim3(ORDER_BLOCKS), dim3(64), 0, stream, cost, scratch, order, n);
+    hipLaunchKernelGGL(atmo_tile_scatter_kernel, dim3(ORDER_BLOCKS), dim3(64), 0, stream, key, cost, scratch, order, n);
     return hipGetLastError();
 }
 
