@@ -570,6 +570,7 @@ def run_workload(torch, S, name, w, h, pose, steps, warmup, textures, params, lo
            "roofline": hbm_roofline(kernel_avg_ms, steps, w * h, pmc, run.isolated_ms), "valu_roofline": valu_roofline(pmc, kernel_avg_ms)}
     if with_frame_stats:
         res["hit_fraction"] = float((run.out.abs().sum(dim=-1) > 0).float().mean().item())
+    res["feedback_stats"] = node.feedback_stats()
     node.close()
     del run, depth, sequence
     return res

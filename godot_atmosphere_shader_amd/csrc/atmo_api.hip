@@ -149,6 +149,8 @@ struct AtmoContext {
     // A/B overrides read ONCE, in atmo_create (tools/ab_feedback.sh, tools/ab_bench.sh): ATMO_TILE_FEEDBACK=0/1,
     // ATMO_TILE_FEEDBACK_PERIOD=n, ATMO_LANE_SPLIT=1/2
     int env_feedback = -1, env_split = 0;
+    float env_reach_scale = 1.0f;                      // ATMO_FB_REACH_SCALE: multiplies the predicted reach (A/B)
+    unsigned moving_period = 2;                        // ATMO_FB_MOVING_PERIOD: recording period while the camera moves
     bool drew = false;                                 // a draw of this context has been enqueued ...
     hipStream_t last_draw_stream = nullptr;            // ... most recently on this stream (texture updates elsewhere wait)
 #ifdef ATMO_WAVE_TRACE
@@ -373,40 +375,62 @@ int dev_reserve(AtmoContext *ctx, DeviceBuffer &b, size_t bytes) {
     return dev_alloc(ctx, b, bytes);
 }
 
-// How far, in pixels, the picture's features move between two consecutive frames: the planet's centre and six points of its
-// surface (fixed in world space: the planet turns slowly, the camera flies) projected with both cameras, the largest
-// displacement among those in front of both.  Scheduling only -- the pixels never depend on it -- so a plain symmetric
-// perspective is assumed for the projection (inv_p[0], inv_p[5] = the tangents of the half field of view).
-float feedback_motion_px(const AtmoFrame &a, const AtmoFrame &b, float radius) {
+// How far, in pixels, the picture's cost features move between two consecutive frames.  Scheduling only -- the pixels never
+// depend on it -- so a plain symmetric perspective is assumed (inv_p[0], inv_p[5] = the tangents of the half field of view).
+//   silhouette: the planet's centre and the four points of its limb along the camera's own right / up axes, each frame's
+//               taken with that frame's camera: where the disc sits on the screen and how large it is (all a kernel without
+//               clouds can see of the camera: a march costs the same wherever the sun and the ground features are);
+//   surface:    six points fixed on the planet (world axes): where the cloud pattern is (the cloud kernels' cost map).
+float feedback_motion_px(const AtmoFrame &a, const AtmoFrame &b, float radius, bool surface) {
     auto to_world = [](const AtmoFrame &f, const float *v, float *w) {
         const float *M = f.inv_view_matrix;
         for (int r = 0; r < 3; ++r) w[r] = M[r] * v[0] + M[4 + r] * v[1] + M[8 + r] * v[2] + M[12 + r];
     };
-    auto to_pixel = [](const AtmoFrame &f, const float *w, float *px) {
-        const float *M = f.inv_view_matrix;  // rigid: view = R^T (w - t)
-        const float d[3] = {w[0] - M[12], w[1] - M[13], w[2] - M[14]};
-        const float vx = M[0] * d[0] + M[1] * d[1] + M[2] * d[2];
-        const float vy = M[4] * d[0] + M[5] * d[1] + M[6] * d[2];
-        const float vz = M[8] * d[0] + M[9] * d[1] + M[10] * d[2];
-        if (!(vz < -1e-6f)) return false;
+    auto view_to_pixel = [](const AtmoFrame &f, const float *v, float *px) {
+        if (!(v[2] < -1e-6f)) return false;
         const float tx = f.inv_projection_matrix[0], ty = f.inv_projection_matrix[5];
         if (tx == 0.0f || ty == 0.0f) return false;
-        px[0] = (0.5f + 0.5f * (vx / -vz) / tx) * (float)f.viewport_w;
-        px[1] = (0.5f + 0.5f * (vy / -vz) / ty) * (float)f.viewport_h;
-        return true;
+        px[0] = (0.5f + 0.5f * (v[0] / -v[2]) / tx) * (float)f.viewport_w;
+        px[1] = (0.5f + 0.5f * (v[1] / -v[2]) / ty) * (float)f.viewport_h;
+        return px[0] == px[0] && px[1] == px[1];
     };
-    float c[3];
-    to_world(a, a.planet_center_viewspace, c);
+    auto world_to_pixel = [&](const AtmoFrame &f, const float *w, float *px) {
+        const float *M = f.inv_view_matrix;  // rigid: view = R^T (w - t)
+        const float d[3] = {w[0] - M[12], w[1] - M[13], w[2] - M[14]};
+        const float v[3] = {M[0] * d[0] + M[1] * d[1] + M[2] * d[2], M[4] * d[0] + M[5] * d[1] + M[6] * d[2],
+                            M[8] * d[0] + M[9] * d[1] + M[10] * d[2]};
+        return view_to_pixel(f, v, px);
+    };
     float worst = 0.0f;
     bool any = false;
-    for (int k = 0; k < 7; ++k) {
-        float w[3] = {c[0], c[1], c[2]};
-        if (k > 0) w[(k - 1) >> 1] += ((k - 1) & 1) ? -radius : radius;
-        float pa[2], pb[2];
-        if (!to_pixel(a, w, pa) || !to_pixel(b, w, pb)) continue;
+    auto take = [&](bool oka, const float *pa, bool okb, const float *pb) {
+        if (!oka || !okb) return;
         const float dx = pa[0] - pb[0], dy = pa[1] - pb[1];
-        const float d = std::sqrt(dx * dx + dy * dy);
-        if (d == d) { worst = std::fmax(worst, d); any = true; }
+        worst = std::fmax(worst, std::sqrt(dx * dx + dy * dy));
+        any = true;
+    };
+    for (int k = 0; k < 5; ++k) {  // silhouette: view-space centre and centre +- R along view x / y, per frame
+        float va[3] = {a.planet_center_viewspace[0], a.planet_center_viewspace[1], a.planet_center_viewspace[2]};
+        float vb[3] = {b.planet_center_viewspace[0], b.planet_center_viewspace[1], b.planet_center_viewspace[2]};
+        if (k > 0) {
+            const float o = ((k - 1) & 1) ? -radius : radius;
+            va[(k - 1) >> 1] += o;
+            vb[(k - 1) >> 1] += o;
+        }
+        float pa[2], pb[2];
+        const bool oka = view_to_pixel(a, va, pa), okb = view_to_pixel(b, vb, pb);
+        take(oka, pa, okb, pb);
+    }
+    if (surface) {
+        float c[3];
+        to_world(a, a.planet_center_viewspace, c);
+        for (int k = 0; k < 6; ++k) {
+            float w[3] = {c[0], c[1], c[2]};
+            w[k >> 1] += (k & 1) ? -radius : radius;
+            float pa[2], pb[2];
+            const bool oka = world_to_pixel(a, w, pa), okb = world_to_pixel(b, w, pb);
+            take(oka, pa, okb, pb);
+        }
     }
     if (!any) {  // nothing of the planet in front of the camera: the camera's own turn, in pixels
         const float *A = a.inv_view_matrix, *B = b.inv_view_matrix;
@@ -548,6 +572,8 @@ int atmo_create(int device, int variant, int view_steps, int cloud_steps, int li
     // A/B overrides for the tools (tools/ab_feedback.sh, tools/ab_bench.sh): read here, once -- never in the launch path
     if (const char *ev = std::getenv("ATMO_LANE_SPLIT")) ctx->env_split = ev[0] == '1' ? 1 : (ev[0] == '2' ? 2 : 0);
     if (const char *ev = std::getenv("ATMO_TILE_FEEDBACK")) ctx->env_feedback = ev[0] == '1' ? 1 : 0;
+    if (const char *ev = std::getenv("ATMO_FB_REACH_SCALE")) ctx->env_reach_scale = (float)std::atof(ev);
+    if (const char *ev = std::getenv("ATMO_FB_MOVING_PERIOD")) { const int v = std::atoi(ev); ctx->moving_period = (unsigned)(v < 1 ? 1 : v); }
     if (const char *ev = std::getenv("ATMO_TILE_FEEDBACK_PERIOD")) { const int v = std::atoi(ev); ctx->fb_period = (unsigned)(v < 1 ? 1 : v); }
 
     // u_blue_noise_texture starts all-zero (jitter 0), like an unset sampler
@@ -1030,14 +1056,18 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     float reach_px = 0.0f;
     if (fb) {
         if (fb->have_prev) {
-            const float m = feedback_motion_px(*frame, fb->prev_frame, ctx->p.u_planet_radius);
+            const float m = feedback_motion_px(*frame, fb->prev_frame, ctx->p.u_planet_radius + ctx->p.u_atmosphere_height,
+                                               (ctx->flags & atmo::KF_CLOUDS) != 0);
             fb->motion_px = std::fmax(m, 0.75f * fb->motion_px);  // peak hold: one still frame does not end a camera move
             if (fb->motion_px < 0.01f) fb->motion_px = 0.0f;
         }
         fb->prev_frame = *frame;
         fb->have_prev = true;
         const bool moving = fb->motion_px > FB_STILL_PX;
-        const unsigned period = moving ? (ctx->fb_period < 2u ? ctx->fb_period : 2u) : ctx->fb_period;
+        const unsigned period = moving ? (ctx->fb_period < ctx->moving_period ? ctx->fb_period : ctx->moving_period) : ctx->fb_period;
+        // what an order sorted now would have to cover: it is in use from ~2 frames after its recording draw until the next takes over
+        const float want_reach = moving ? fb->motion_px * (float)(period + 4u) * ctx->env_reach_scale : 0.0f;
+        const bool too_fast = want_reach > FB_MAX_REACH_PX;  // nothing measured now says anything about the frame it would order
         if (fb->pending) {
             if (hipEventQuery(fb->ev_order[fb->write]) == hipSuccess) {
                 fb->active = fb->write;  // complete: no stream-side wait needed
@@ -1057,11 +1087,10 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         }
         // the first two draws of a key are not measured (cold clocks and caches rank the tiles poorly); the next four
         // record back to back (the order settles in a few frames), then every period-th
-        fb_record = !fb->pending && fb->n >= 2 && (fb->n < 6 || fb->n - fb->last_record >= period);
+        fb_record = !too_fast && !fb->pending && fb->n >= 2 && (fb->n < 6 || fb->n - fb->last_record >= period);
         if (fb_record) {
             rc.tile_cost = (uint32_t *)fb->cost.ptr;
-            // the order sorted from this draw is in use from about 2 frames later until the next one takes over
-            reach_px = moving ? std::fmin(fb->motion_px * (float)(period + 4u), FB_MAX_REACH_PX) : 0.0f;
+            reach_px = want_reach;
             const int tile_h = (rc.y1 - rc.y0 + gy - 1) / gy;  // pixel rows per tile of this launch (8, or 4 with two lanes per ray)
             dil_rx = reach_px > 0.0f ? (int)std::ceil(reach_px / 16.0f) : 0;
             dil_ry = reach_px > 0.0f ? (int)std::ceil(reach_px / (float)(tile_h > 0 ? tile_h : 8)) : 0;

@@ -974,7 +974,7 @@ def test_tile_feedback_keeps_one_state_per_rect_and_stream():
     torch.cuda.synchronize()
     st = node.feedback_stats()
     assert st["states"] == 2 and st["recycled"] == 0, st
-    assert st["sorts"] >= 8 and st["ordered_draws"] >= 20, st   # both states engaged (the old code restarted at every draw)
+    assert st["sorts"] >= 4 and st["ordered_draws"] >= 20, st   # both states engaged (the old code restarted at every draw)
     # more keys than slots: seven distinct rects, round robin
     many = [(0, 0, w - 16 * k, h) for k in range(7)]
     for it in range(70):

@@ -40,14 +40,15 @@ def main():
                     os.environ["ATMO_TILE_FEEDBACK_PERIOD"] = str(period)
                 r = bench.run_workload(torch, S, wl, args.width, args.height, "P_space", args.steps, 8, tex, params, 0,
                                        with_frame_stats=False, motion=motion, node_extra=dict(tile_feedback=fb))
-                return r["Mrays/s"], r["kernel_avg_ms"]
+                st = r["feedback_stats"]
+                return r["Mrays/s"], r["kernel_avg_ms"], st["ordered_draws"], st["sorts"]
             off = cell(0)
             ons = [cell(1, p) for p in periods]
             off2 = cell(0)  # bracket: the box's drift over the row
             base = 0.5 * (off[0] + off2[0])
             name = "static" if motion[1] == 0.0 else f"{motion[0]}:{motion[1]:g}"
             print(f"  {wl:16s} {name:10s} {base:9.0f} ({0.5 * (off[1] + off2[1]):.4f}) " +
-                  " ".join(f"{r:9.0f} ({k:.4f}) {100.0 * (r / base - 1.0):+6.1f} %" for r, k in ons), flush=True)
+                  " ".join(f"{r:9.0f} ({k:.4f}) {100.0 * (r / base - 1.0):+6.1f} % [{od} ordered, {so} sorts]" for r, k, od, so in ons), flush=True)
     os.environ.pop("ATMO_TILE_FEEDBACK_PERIOD", None)
 
 
