@@ -130,6 +130,10 @@ struct AtmoContext {
         float motion_px = 0.0f;        // pixels per frame the picture's features move (peak-held estimate)
         float order_reach_px[2] = {0.0f, 0.0f};  // how far features may have moved for order[k] to stay conservative
         unsigned order_born[2] = {0, 0};         // n of the recording draw order[k] was sorted from
+        // in-stream mode (moving camera, long frames): the sort runs on the draw stream right behind every draw, so the
+        // next draw is ordered by THIS frame's costs; no host queries, one frame of lag
+        DeviceBuffer is_order, is_scratch;
+        unsigned is_last_n = ~0u;                // n of the draw behind which the last in-stream sort was enqueued
         unsigned n = 0;                // draws of this key so far
         unsigned last_record = 0;      // n of the last draw that recorded costs
         int active = -1;               // order[active] is complete and in use; -1: row-major order
@@ -151,6 +155,7 @@ struct AtmoContext {
     int env_feedback = -1, env_split = 0;
     float env_reach_scale = 1.0f;                      // ATMO_FB_REACH_SCALE: multiplies the predicted reach (A/B)
     unsigned moving_period = 2;                        // ATMO_FB_MOVING_PERIOD: recording period while the camera moves
+    int instream = 1;                                  // ATMO_FB_INSTREAM=0: never sort on the draw stream (A/B)
     bool drew = false;                                 // a draw of this context has been enqueued ...
     hipStream_t last_draw_stream = nullptr;            // ... most recently on this stream (texture updates elsewhere wait)
 #ifdef ATMO_WAVE_TRACE
@@ -329,6 +334,8 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
     rc.cube = (const uint32_t *)ctx->cube.ptr; rc.cube_n = ctx->cube_n;
     rc.cube_levels = ctx->cube_levels;
     rc.cube_level_off = (const uint32_t *)ctx->cube_level_off.ptr;
+    rc.cube_bytes = (uint32_t)ctx->cube.bytes;
+    rc.cube_lod_fast = (ctx->cube_n >= 1 && ctx->cube_n <= 1024 && (ctx->cube_n & (ctx->cube_n - 1)) == 0) ? 1 : 0;
     rc.depth = depth;
     rc.out = (float4 *)rgba;
     rc.out_pitch = f->x1 - f->x0;
@@ -494,6 +501,8 @@ int feedback_state(AtmoContext *ctx, int gx, int gy, int split, hipStream_t s, A
     int rc1 = dev_reserve(ctx, f.cost, bytes);
     for (int k = 0; k < 2 && rc1 == ATMO_OK; ++k) rc1 = dev_reserve(ctx, f.order[k], bytes);
     for (int k = 0; k < 2 && rc1 == ATMO_OK; ++k) rc1 = dev_reserve(ctx, f.dil[k], bytes);
+    if (rc1 == ATMO_OK) rc1 = dev_reserve(ctx, f.is_order, bytes);
+    if (rc1 == ATMO_OK) rc1 = dev_reserve(ctx, f.is_scratch, atmo::tile_order_scratch_bytes());
     if (rc1 != ATMO_OK) { f.used = false; return rc1; }
     if (!f.ev_draw) {
         HIP_TRY(ctx, hipEventCreateWithFlags(&f.ev_draw, hipEventDisableTiming));
@@ -510,6 +519,7 @@ int feedback_state(AtmoContext *ctx, int gx, int gy, int split, hipStream_t s, A
     f.pending = false;
     f.have_prev = false;
     f.motion_px = 0.0f;
+    f.is_last_n = ~0u;
     f.last_use = ctx->fb_clock;
     *out = &f;
     return ATMO_OK;
@@ -572,6 +582,7 @@ int atmo_create(int device, int variant, int view_steps, int cloud_steps, int li
     // A/B overrides for the tools (tools/ab_feedback.sh, tools/ab_bench.sh): read here, once -- never in the launch path
     if (const char *ev = std::getenv("ATMO_LANE_SPLIT")) ctx->env_split = ev[0] == '1' ? 1 : (ev[0] == '2' ? 2 : 0);
     if (const char *ev = std::getenv("ATMO_TILE_FEEDBACK")) ctx->env_feedback = ev[0] == '1' ? 1 : 0;
+    if (const char *ev = std::getenv("ATMO_FB_INSTREAM")) ctx->instream = ev[0] == '1' ? 1 : 0;
     if (const char *ev = std::getenv("ATMO_FB_REACH_SCALE")) ctx->env_reach_scale = (float)std::atof(ev);
     if (const char *ev = std::getenv("ATMO_FB_MOVING_PERIOD")) { const int v = std::atoi(ev); ctx->moving_period = (unsigned)(v < 1 ? 1 : v); }
     if (const char *ev = std::getenv("ATMO_TILE_FEEDBACK_PERIOD")) { const int v = std::atoi(ev); ctx->fb_period = (unsigned)(v < 1 ? 1 : v); }
@@ -615,6 +626,8 @@ int atmo_destroy(AtmoContext *ctx) {
             dev_free(f.order[k]);
             dev_free(f.dil[k]);
         }
+        dev_free(f.is_order);
+        dev_free(f.is_scratch);
         dev_free(f.cost);
     }
     dev_free(ctx->fb_scratch);
@@ -1022,9 +1035,9 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     int split = choose_split(ctx, frame);
     int flags = ctx->flags;
     if (ctx->sampler_lod && (flags & atmo::KF_CLOUDS) && ctx->cube.ptr && ctx->cube_levels > 1) {
-        // implicit cubemap LOD: needs a mip chain; available for the precise cloud kernels with the reference's LUT light
-        if (!(flags & atmo::KF_PRECISE) || (flags & atmo::KF_LIGHT_DIRECT))
-            return fail(ctx, ATMO_E_STATE, "atmo_render: the implicit cubemap LOD (atmo_set_sampler_lod 1) needs the precise cloud mode and the LUT light mode");
+        // implicit cubemap LOD: needs a mip chain; available for the precise cloud kernels (either light mode), one lane per ray
+        if (!(flags & atmo::KF_PRECISE))
+            return fail(ctx, ATMO_E_STATE, "atmo_render: the implicit cubemap LOD (atmo_set_sampler_lod 1) needs the precise cloud mode (atmo_set_precision 1)");
         flags |= atmo::KF_CUBE_LOD;
         split = 1;
     }
@@ -1040,7 +1053,7 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     }
     // Every fb_period-th draw records the wave durations per tile; a sort on the side stream turns them into the next
     // order, which later draws pick up once a host-side event query says it is complete: no draw ever waits for a sort.
-    bool fb_record = false;
+    bool fb_record = false, fb_instream = false;
     AtmoContext::FeedbackState *fb = nullptr;
     if (feedback) {
         const int rc1 = feedback_state(ctx, gx, gy, split, s, &fb);
@@ -1077,23 +1090,41 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
                 (void)hipGetLastError();  // hipErrorNotReady is an answer, not an error: keep it out of the launch checks below
             }
         }
-        if (fb->active >= 0) {
-            // still conservative?  features have moved about motion_px * (frames since the costs were measured)
-            const float moved = fb->motion_px * (float)(fb->n - fb->order_born[fb->active]);
-            if (moved <= fb->order_reach_px[fb->active] + 8.0f) {
-                rc.tile_order = (const uint32_t *)fb->order[fb->active].ptr;
+        // In-stream mode: while the camera moves, the kernels with long frames (the cloud variants: 0.2-1.3 ms) sort on the DRAW
+        // stream, right behind every draw.  The next draw is then ordered by this frame's costs -- one frame of lag instead of
+        // four to six, so the dilation stays at a tile or two and the order keeps its meaning -- at the price of ~10 us of
+        // sort kernels on the critical path per frame (which the short frames of the cloudless kernels could not pay).
+        const float is_reach = fb->motion_px * 2.0f * ctx->env_reach_scale;  // one frame of lag and one of margin
+        fb_instream = ctx->instream && moving && (flags & atmo::KF_CLOUDS) && !fb->pending && is_reach <= FB_MAX_REACH_PX;
+        const int tile_h = (rc.y1 - rc.y0 + gy - 1) / gy;  // pixel rows per tile of this launch (8, or 4 with two lanes per ray)
+        if (fb_instream) {
+            if (fb->is_last_n + 1u == fb->n) {  // the sort behind the previous draw of this key wrote is_order
+                rc.tile_order = (const uint32_t *)fb->is_order.ptr;
                 ctx->fb_ordered_draws += 1;
             }
-        }
-        // the first two draws of a key are not measured (cold clocks and caches rank the tiles poorly); the next four
-        // record back to back (the order settles in a few frames), then every period-th
-        fb_record = !too_fast && !fb->pending && fb->n >= 2 && (fb->n < 6 || fb->n - fb->last_record >= period);
-        if (fb_record) {
             rc.tile_cost = (uint32_t *)fb->cost.ptr;
-            reach_px = want_reach;
-            const int tile_h = (rc.y1 - rc.y0 + gy - 1) / gy;  // pixel rows per tile of this launch (8, or 4 with two lanes per ray)
-            dil_rx = reach_px > 0.0f ? (int)std::ceil(reach_px / 16.0f) : 0;
-            dil_ry = reach_px > 0.0f ? (int)std::ceil(reach_px / (float)(tile_h > 0 ? tile_h : 8)) : 0;
+            reach_px = is_reach;
+            dil_rx = (int)std::ceil(reach_px / 16.0f);
+            dil_ry = (int)std::ceil(reach_px / (float)(tile_h > 0 ? tile_h : 8));
+            fb->active = -1;  // whatever the side stream sorted last belongs to an older picture
+        } else {
+            if (fb->active >= 0) {
+                // still conservative?  features have moved about motion_px * (frames since the costs were measured)
+                const float moved = fb->motion_px * (float)(fb->n - fb->order_born[fb->active]);
+                if (moved <= fb->order_reach_px[fb->active] + 8.0f) {
+                    rc.tile_order = (const uint32_t *)fb->order[fb->active].ptr;
+                    ctx->fb_ordered_draws += 1;
+                }
+            }
+            // the first two draws of a key are not measured (cold clocks and caches rank the tiles poorly); the next four
+            // record back to back (the order settles in a few frames), then every period-th
+            fb_record = !too_fast && !fb->pending && fb->n >= 2 && (fb->n < 6 || fb->n - fb->last_record >= period);
+            if (fb_record) {
+                rc.tile_cost = (uint32_t *)fb->cost.ptr;
+                reach_px = want_reach;
+                dil_rx = reach_px > 0.0f ? (int)std::ceil(reach_px / 16.0f) : 0;
+                dil_ry = reach_px > 0.0f ? (int)std::ceil(reach_px / (float)(tile_h > 0 ? tile_h : 8)) : 0;
+            }
         }
     }
     // kernel timing brackets the draw kernel alone (the tile-order kernel runs beside the previous draw).  The event pair
@@ -1149,6 +1180,13 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         HIP_TRY(ctx, hipEventRecord(ev.e1, s));
         ctx->pending.emplace_back(ev.e0, ev.e1);
         ev.e0 = ev.e1 = nullptr;  // ownership moved
+    }
+    if (fb_instream) {  // behind the draw (and behind the timing bracket, which is the draw kernel's alone)
+        HIP_TRY(ctx, atmo::launch_tile_order((uint32_t *)fb->cost.ptr, (uint32_t *)fb->is_order.ptr, gx, gy, dil_rx, dil_ry,
+                                             (uint32_t *)fb->dil[0].ptr, (uint32_t *)fb->dil[1].ptr, (uint32_t *)fb->is_scratch.ptr, s));
+        fb->is_last_n = fb->n - 1;
+        fb->last_record = fb->n - 1;
+        ctx->fb_sorts += 1;
     }
     return ATMO_OK;
 }

@@ -60,6 +60,8 @@ struct RenderConsts {
     int32_t cube_n;
     int32_t cube_levels;             // mip levels bound; level l = (cube_n >> l)-sided faces, footprints at cube + cube_level_off[l]
     const uint32_t *cube_level_off;  // device array of 16 element offsets
+    uint32_t cube_bytes;             // bytes of the packed footprint chain (buffer-load bound)
+    int32_t cube_lod_fast;           // 1: cube_n is a power of two <= 1024 (closed-form level offsets, fp32 addressing)
     // --- per-pixel streams
     const float *depth;      // h rows of w
     float4 *out;             // plain: (y1-y0) rows of (x1-x0); composite: the h x w scene colour buffer, blended in place

@@ -465,6 +465,72 @@ __device__ __forceinline__ float cube_sample_lod(const RenderConsts &rc, V3 d, b
     return v0 * (1.0f - fr) + v1 * fr;
 }
 
+// ---- the same sampler on the fast path (round 3): power-of-two faces up to 1024 texels ------------------------------------------
+// What the general form above spends and this one does not: five IEEE divisions per sample (here: one v_rcp + two Markstein
+// steps shared by s and t -- the IEEE quotients, as in cube_sample<true> -- and plain v_rcp for the derivatives, whose
+// relative error of 1e-7 moves lambda by 1e-7), face selection by compares (here: v_cubeid/sc/tc/ma), flat loads with
+// integer address chains and a global load of the level offset (here: one buffer gather per level at a byte offset formed in
+// fp32; the level's base follows from the geometric series of the packed chain).  Bit-for-bit the same s, t, texels and
+// filters as the general form; lambda agrees to a few ulp.
+__device__ __forceinline__ float cube_level_sample_fast(__amdgpu_buffer_rsrc_t rs, float fid, float q1s, float q1t, float nf, float c0, int lo) {
+    // level `lo`: faces of nl = n >> lo texels, footprints (nl + 1)^2 per face, packed behind the levels below it:
+    //   words before level l = 6 sum_{k<l} (n_k + 1)^2 = 8 n^2 - 8 nl^2 + 24 n - 24 nl + 6 l        (n a power of two)
+    const float nl = __builtin_amdgcn_ldexpf(nf, -lo);
+    const float hn = 0.5f * nl;
+    const float x = __builtin_fmaf(q1s, hn, -0.5f), y = __builtin_fmaf(q1t, hn, -0.5f);  // ((q + 1) * 0.5) * nl - 0.5: the scalings are exact
+    const float xf = floorf(x), yf = floorf(y);
+    const float fx = x - xf, fy = y - yf;
+    const float nm1 = nl - 1.0f, s4 = 4.0f * nl + 4.0f;
+    const float ic = __builtin_amdgcn_fmed3f(xf, -1.0f, nm1), jc = __builtin_amdgcn_fmed3f(yf, -1.0f, nm1);
+    // byte offsets: every term and partial sum is a multiple of 4 below 2^26 (33.6 MB for the whole chain at n = 1024): exact
+    const float base = __builtin_fmaf(-32.0f * nl, nl, __builtin_fmaf(-96.0f, nl, __builtin_fmaf(24.0f, (float)lo, c0)));
+    const float in_level = __builtin_fmaf(fid, s4 * (nl + 1.0f), __builtin_fmaf(jc, s4, __builtin_fmaf(ic, 4.0f, s4 + 4.0f)));
+    const uint32_t w = buf_u32(rs, (uint32_t)(base + in_level));
+    return bilinear_unorm8_exact(w, fx, fy);
+}
+
+__device__ __forceinline__ float cube_lod_rho2(bool isz, bool isy, bool pos, float sc, float tc, float ma, V3 d, bool valid, V3 q, float n2, float rho2) {
+#pragma clang fp contract(fast)
+    const V3 dv = {q.x - d.x, q.y - d.y, q.z - d.z};
+    float dsc, dtc, dma;
+    cube_frame(isz, isy, pos, dv, dsc, dtc, dma);
+    const float ma2 = ma + dma;
+    const float inv = 0.5f * hw_rcp(ma * ma2);
+    const float ds = (dsc * ma - sc * dma) * inv, dt = (dtc * ma - tc * dma) * inv;
+    const float r2 = (ds * ds + dt * dt) * n2;
+    return (valid && ma2 > 0.0f) ? fmaxf(rho2, r2) : rho2;
+}
+
+__device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3 d, bool vx, V3 dx, bool vy, V3 dy) {
+    const float fid = __builtin_amdgcn_cubeid(d.x, d.y, d.z);
+    const float sc = __builtin_amdgcn_cubesc(d.x, d.y, d.z);
+    const float tc = __builtin_amdgcn_cubetc(d.x, d.y, d.z);
+    const float ma2x = __builtin_amdgcn_cubema(d.x, d.y, d.z);  // 2 * the signed major component
+    const float ma = 0.5f * fabsf(ma2x);
+    const float r = hw_rcp(ma);
+    float qs = sc * r, qt = tc * r;
+    qs = __builtin_fmaf(__builtin_fmaf(-qs, ma, sc), r, qs);
+    qt = __builtin_fmaf(__builtin_fmaf(-qt, ma, tc), r, qt);
+    qs = __builtin_fmaf(__builtin_fmaf(-qs, ma, sc), r, qs);
+    qt = __builtin_fmaf(__builtin_fmaf(-qt, ma, tc), r, qt);
+    const bool isz = fid >= 4.0f, isy = !isz && fid >= 2.0f, pos = ma2x >= 0.0f;
+    const float nf = (float)rc.cube_n, n2 = nf * nf;
+    float rho2 = 0.0f;
+    rho2 = cube_lod_rho2(isz, isy, pos, sc, tc, ma, d, vx, dx, n2, rho2);
+    rho2 = cube_lod_rho2(isz, isy, pos, sc, tc, ma, d, vy, dy, n2, rho2);
+    float lambda = rho2 > 0.0f ? 0.5f * __builtin_amdgcn_logf(rho2) : 0.0f;  // v_log_f32 = log2
+    lambda = fminf(fmaxf(lambda, 0.0f), (float)(rc.cube_levels - 1));
+    const float lf = floorf(lambda), fr = lambda - lf;
+    const int lo = (int)lf;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(rc.cube, rc.cube_bytes);
+    const float c0 = __builtin_fmaf(32.0f * nf, nf, 96.0f * nf);
+    const float q1s = qs + 1.0f, q1t = qt + 1.0f;
+    const float v0 = cube_level_sample_fast(rs, fid, q1s, q1t, nf, c0, lo);
+    if (lo + 1 >= rc.cube_levels || fr == 0.0f) return v0;
+    const float v1 = cube_level_sample_fast(rs, fid, q1s, q1t, nf, c0, lo + 1);
+    return v0 * (1.0f - fr) + v1 * fr;
+}
+
 // The direct light march of one view sample (ATMO_LIGHT_DIRECT; SURVEY.md 8d "N view x M light steps"): the quantity the LUT
 // tabulates -- get_optical_depth of optical_depth.gdshader:17-31 over the chord of :56-65 -- from the sample at squared radius
 // r2 (position relative to the planet centre), bdot = dot(position, sun_dir), y3 = the sample's own (1 - height ratio)^3.
@@ -771,7 +837,8 @@ __device__ __forceinline__ float cloud_density_precise(const RenderConsts &rc, f
         const float qz = rc.cov_rot[1] * px + rc.cov_rot[3] * pz;
         if (LOD) {
             auto rot = [&](V3 q) { return V3{rc.cov_rot[0] * q.x + rc.cov_rot[2] * q.z, q.y, rc.cov_rot[1] * q.x + rc.cov_rot[3] * q.z}; };
-            coverage = cube_sample_lod(rc, V3{qx, py, qz}, nb->vx, rot(nb->px), nb->vy, rot(nb->py));
+            if (rc.cube_lod_fast) coverage = cube_sample_lod_fast(rc, V3{qx, py, qz}, nb->vx, rot(nb->px), nb->vy, rot(nb->py));
+            else coverage = cube_sample_lod(rc, V3{qx, py, qz}, nb->vx, rot(nb->px), nb->vy, rot(nb->py));
         } else {
             coverage = cube_sample<true>(rc.cube, rc.cube_n, qx, py, qz);
         }
@@ -991,15 +1058,18 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
 #ifndef ATMO_RM_QUEUE
 #define ATMO_RM_QUEUE 1
 #endif
+// With the implicit cubemap LOD an entry also carries the sample positions of the two quad partners (the light taps of a queued
+// sample difference THEIR tap positions: 6 more words) and, in bits 10-11 of the slot word, whether each partner marches.
 constexpr int RMQ_CHUNK = 16, RMQ_CAP = 128;
-constexpr int RMQ_WORDS_PER_WAVE = 5 * RMQ_CAP + RMQ_CHUNK * 64;
+constexpr int rmq_words_per_wave(bool lod) { return (lod ? 11 : 5) * RMQ_CAP + RMQ_CHUNK * 64; }
 
-template <bool PRECISE>
+template <bool PRECISE, bool LOD = false>
 __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, V3 dir_m, float t_begin, float t_end, float jitter,
-                                                        float *__restrict__ lds) {
+                                                        float *__restrict__ lds, const MarchRay *nbray = nullptr) {
     float *qx = lds, *qy = lds + RMQ_CAP, *qz = lds + 2 * RMQ_CAP, *qh = lds + 3 * RMQ_CAP;
     uint32_t *qs = reinterpret_cast<uint32_t *>(lds + 4 * RMQ_CAP);
-    float *slot = lds + 5 * RMQ_CAP;
+    float *qn = lds + 5 * RMQ_CAP;  // LOD: partner positions, 6 arrays of RMQ_CAP
+    float *slot = lds + (LOD ? 11 : 5) * RMQ_CAP;
     const int lane = threadIdx.x & 63;
     const unsigned long long active = __builtin_amdgcn_ballot_w64(true);  // the lanes of this wave that march
     auto rank_in = [&](unsigned long long m) {
@@ -1018,14 +1088,27 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
     float total_transmittance = 1.0f, total_light = 0.0f, one_minus_alpha = 1.0f;
     const float scale_step = rc.cloud_density_scale * step_len;
     const float neg_scale_step_log2e = -scale_step * LOG2E;
+    QuadNb nb;
+    if (LOD) {
+        nb.vx = nbray[0].valid; nb.vy = nbray[1].valid;
+        nb.px = V3{nbray[0].px, nbray[0].py, nbray[0].pz};
+        nb.py = V3{nbray[1].px, nbray[1].py, nbray[1].pz};
+    }
 
     auto light_batch = [&](int avail) {  // phase B: lane `rank` lights queue entry qhead + rank
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (rank < avail) {
             const int e = (qhead + rank) & (RMQ_CAP - 1);
             const float ex = qx[e], ey = qy[e], ez = qz[e], eh = qh[e];
-            const uint32_t sl = qs[e];
-            const float light = light_raymarched<PRECISE>(rc, ex, ey, ez, eh, sx, sy, sz);
+            uint32_t sl = qs[e];
+            QuadNb enb;
+            if (LOD) {
+                enb.vx = (sl >> 10) & 1u; enb.vy = (sl >> 11) & 1u;
+                enb.px = V3{qn[e], qn[RMQ_CAP + e], qn[2 * RMQ_CAP + e]};
+                enb.py = V3{qn[3 * RMQ_CAP + e], qn[4 * RMQ_CAP + e], qn[5 * RMQ_CAP + e]};
+                sl &= 1023u;
+            }
+            const float light = light_raymarched<PRECISE, LOD>(rc, ex, ey, ez, eh, sx, sy, sz, LOD ? &enb : nullptr);
             slot[sl] = light * slot[sl];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1037,7 +1120,7 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
         for (int k = 0; k < cn; ++k) {
             float r, hr;
             cloud_height(rc, px, py, pz, r, hr);
-            const float density = cloud_density<true, PRECISE>(rc, px, py, pz, hr);
+            const float density = cloud_density<true, PRECISE, LOD>(rc, px, py, pz, hr, LOD ? &nb : nullptr);
             const bool lit = density > 0.0f;
             float w = 0.0f;
             if (lit) {
@@ -1057,13 +1140,23 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
                 const int e = (qcount + rank_in(lm)) & (RMQ_CAP - 1);
                 const uint32_t sl = (uint32_t)(k * 64 + lane);
                 qx[e] = px; qy[e] = py; qz[e] = pz; qh[e] = hr;
-                qs[e] = sl;
+                if (LOD) {
+                    qn[e] = nb.px.x; qn[RMQ_CAP + e] = nb.px.y; qn[2 * RMQ_CAP + e] = nb.px.z;
+                    qn[3 * RMQ_CAP + e] = nb.py.x; qn[4 * RMQ_CAP + e] = nb.py.y; qn[5 * RMQ_CAP + e] = nb.py.z;
+                    qs[e] = sl | (nb.vx ? 1024u : 0u) | (nb.vy ? 2048u : 0u);
+                } else {
+                    qs[e] = sl;
+                }
                 slot[sl] = w;
                 lit_bits |= 1u << k;
             }
             qcount += __builtin_popcountll(lm);
             // exact: pos += ray_dir * step_len
             px = px + ddx; py = py + ddy; pz = pz + ddz;
+            if (LOD) {  // the quad partners advance along their own rays
+                nb.px = V3{nb.px.x + nbray[0].ddx, nb.px.y + nbray[0].ddy, nb.px.z + nbray[0].ddz};
+                nb.py = V3{nb.py.x + nbray[1].ddx, nb.py.y + nbray[1].ddy, nb.py.z + nbray[1].ddz};
+            }
             // a full batch is waiting -- or the chunk ends and its slots are read next: drain (one partial batch at most)
             const bool last = k == cn - 1;
             while (qcount - qhead >= batch || (last && qcount > qhead)) {  // single call site: one copy of the 6-tap block
@@ -1265,9 +1358,9 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
                     nbray[1] = pixel_march_ray(rc, px, py ^ 1);
                 }
                 float2 rr;
-                if constexpr (RM && !LOD && SPLIT == 1 && ATMO_RM_QUEUE != 0) {
-                    __shared__ float rmq[(TILE_W * TILE_H / 64) * RMQ_WORDS_PER_WAVE];
-                    rr = march_clouds_rm_queue<PRECISE>(rc, dir_m, c0, c1, jitter, rmq + wave * RMQ_WORDS_PER_WAVE);
+                if constexpr (RM && SPLIT == 1 && ATMO_RM_QUEUE != 0) {
+                    __shared__ float rmq[(TILE_W * TILE_H / 64) * rmq_words_per_wave(LOD)];
+                    rr = march_clouds_rm_queue<PRECISE, LOD>(rc, dir_m, c0, c1, jitter, rmq + wave * rmq_words_per_wave(LOD), nbray);
                 } else {
                     rr = march_clouds<RM, PRECISE, SPLIT, LOD>(rc, dir_m, c0, c1, jitter, half, nbray);
                 }
@@ -1796,10 +1889,17 @@ hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream
         return launch_direct<KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT>(rc, split, stream);
     case KF_PRECISE | KF_LITE: return launch_t<KF_PRECISE | KF_LITE, 0>(rc, split, stream);
     case KF_PRECISE | KF_LITE | KF_CLOUDS: return launch_t<KF_PRECISE | KF_LITE | KF_CLOUDS, 0>(rc, split, stream);
-    // implicit cubemap LOD (atmo_set_sampler_lod 1): precise cloud kernels with LUT light, one lane per ray
+    // implicit cubemap LOD (atmo_set_sampler_lod 1): precise cloud kernels, one lane per ray
     case KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS: return launch_s<KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS, 0, 1>(rc, stream);
     case KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM: return launch_s<KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM, 0, 1>(rc, stream);
     case KF_CUBE_LOD | KF_PRECISE | KF_LITE | KF_CLOUDS: return launch_s<KF_CUBE_LOD | KF_PRECISE | KF_LITE | KF_CLOUDS, 0, 1>(rc, stream);
+    // ... and with the direct light march of the atmosphere (one lane per ray; the two-lanes-per-ray launch shape has no LOD form)
+    case KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT:
+        return rc.light_steps == 8 ? launch_s<KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT, 8, 1>(rc, stream)
+                                   : launch_s<KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT, 0, 1>(rc, stream);
+    case KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT:
+        return rc.light_steps == 8 ? launch_s<KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT, 8, 1>(rc, stream)
+                                   : launch_s<KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT, 0, 1>(rc, stream);
     default: return hipErrorInvalidValue;
     }
 }
