@@ -336,6 +336,15 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
     rc.cube_level_off = (const uint32_t *)ctx->cube_level_off.ptr;
     rc.cube_bytes = (uint32_t)ctx->cube.bytes;
     rc.cube_lod_fast = (ctx->cube_n >= 1 && ctx->cube_n <= 1024 && (ctx->cube_n & (ctx->cube_n - 1)) == 0) ? 1 : 0;
+    {   // sure-miss test (shade_pixel): usable when the view-ray direction does not depend on the depth sample (x, y, z rows of
+        // inv_projection have no depth column: every perspective and orthographic-free Godot camera) and the camera is well
+        // outside the shell, so that the 0.2 % margin dwarfs fp32 rounding of h = R^2 - |c|^2 + (c.d)^2 (a few 1e-7 |c|^2)
+        const float *Pm = f->inv_projection_matrix;
+        const double cc = (double)rc.center[0] * rc.center[0] + (double)rc.center[1] * rc.center[1] + (double)rc.center[2] * rc.center[2];
+        const double k = cc - (double)rc.atmosphere_radius * rc.atmosphere_radius;
+        const bool depth_free = Pm[8] == 0.0f && Pm[9] == 0.0f && Pm[10] == 0.0f;
+        rc.miss_k = (depth_free && k > 0.01 * cc && std::isfinite(k)) ? (float)(k * (1.0 - 1e-3) * (1.0 - 1e-3)) : 0.0f;
+    }
     rc.depth = depth;
     rc.out = (float4 *)rgba;
     rc.out_pitch = f->x1 - f->x0;
@@ -1064,7 +1073,7 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     // move in that time; the sort dilates the cost map by that distance, so a tile counts as cheap only if everything within
     // reach of it was cheap (atmo_tile_dilate_kernel); costs are recorded every 2nd draw instead of every fb_period-th while
     // the camera moves; and an order whose reach the motion has outrun is not used (row-major instead).
-    constexpr float FB_STILL_PX = 0.5f, FB_MAX_REACH_PX = 160.0f;
+    constexpr float FB_STILL_PX = 0.5f, FB_MAX_REACH_PX = 160.0f, FB_INSTREAM_PX = 3.0f;
     int dil_rx = 0, dil_ry = 0;
     float reach_px = 0.0f;
     if (fb) {
@@ -1090,12 +1099,15 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
                 (void)hipGetLastError();  // hipErrorNotReady is an answer, not an error: keep it out of the launch checks below
             }
         }
-        // In-stream mode: while the camera moves, the kernels with long frames (the cloud variants: 0.2-1.3 ms) sort on the DRAW
-        // stream, right behind every draw.  The next draw is then ordered by this frame's costs -- one frame of lag instead of
-        // four to six, so the dilation stays at a tile or two and the order keeps its meaning -- at the price of ~10 us of
-        // sort kernels on the critical path per frame (which the short frames of the cloudless kernels could not pay).
+        // In-stream mode: while the camera moves by more than a few pixels per frame, the kernels whose cost map is worth it
+        // (raymarched cloud light: the heaviest tiles cost 10x the mean, frames of 0.4-1.3 ms, +48 % from the order on a still
+        // camera) sort on the DRAW stream, right behind every draw.  The next draw is then ordered by this frame's costs -- one
+        // frame of lag instead of four to six, so the dilation stays at a tile or two and the order keeps its meaning -- at the
+        // price of ~10 us of sort kernels on the critical path per frame.  Measured (profiles/round3/ab_tile_feedback_motion.txt):
+        // clouds_high_rm panning 1 degree per frame +20 % in-stream against +7 % with the side-stream sort, but 35 % against 37 %
+        // at 0.1 degree per frame; clouds_high (0.18 ms frames, +7 % at best) loses 7 % in-stream: side stream only.
         const float is_reach = fb->motion_px * 2.0f * ctx->env_reach_scale;  // one frame of lag and one of margin
-        fb_instream = ctx->instream && moving && (flags & atmo::KF_CLOUDS) && !fb->pending && is_reach <= FB_MAX_REACH_PX;
+        fb_instream = ctx->instream && fb->motion_px >= FB_INSTREAM_PX && (flags & atmo::KF_CLOUD_LIGHT_RM) && !fb->pending && is_reach <= FB_MAX_REACH_PX;
         const int tile_h = (rc.y1 - rc.y0 + gy - 1) / gy;  // pixel rows per tile of this launch (8, or 4 with two lanes per ray)
         if (fb_instream) {
             if (fb->is_last_n + 1u == fb->n) {  // the sort behind the previous draw of this key wrote is_order

@@ -77,6 +77,8 @@ struct RenderConsts {
 #endif
     // --- exact short division of the pixel coordinates (pixel_coord in atmo_kernels.hip)
     float rcp_vw, rcp_vh;           // [host] RN(1 / vw), RN(1 / vh)
+    // --- sure-miss test in front of the exact prologue (shade_pixel)
+    float miss_k;                   // [host] (|c|^2 - R_atm^2) (1 - 1e-3)^2 when the test is usable, else 0
 };
 
 struct BakeConsts {

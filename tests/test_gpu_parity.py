@@ -1123,9 +1123,9 @@ def test_parity_implicit_cubemap_lod(oracle32, config_name):
     assert changed > 1e-3   # the mode does change the picture at these pixel footprints
 
 
-def test_implicit_lod_needs_a_chain_and_the_precise_lut_kernels(oracle32):
-    """Without mip levels the LOD mode is the LOD-0 sampler; with the fast cloud mode or the direct light mode it is
-    refused (ATMO_E_STATE) instead of silently sampling level 0."""
+def test_implicit_lod_needs_a_chain_and_the_precise_kernels(oracle32):
+    """Without mip levels the LOD mode is the LOD-0 sampler; with the fast cloud mode it is refused (ATMO_E_STATE) instead of
+    silently sampling level 0; with the direct light march of the atmosphere it runs (round 3) and matches the oracle."""
     from godot_atmosphere_shader_amd import _native as N
 
     tex, params = demo_textures(cube_n=64, shape_n=16), demo_params()
@@ -1138,7 +1138,15 @@ def test_implicit_lod_needs_a_chain_and_the_precise_lut_kernels(oracle32):
     assert b.kernel_name.startswith("atmo_render_kernel<17,")
     a.close()
     b.close()
-    for kw in (dict(precise_clouds=False), dict(light_mode="direct", light_steps=4)):
+    for rm in (0, 1):
+        node = make_node("clouds_high_rm" if rm else "clouds_high", tex, params, cubemap_lod=True, light_mode="direct", light_steps=8)
+        got = _gpu_render(node, cam, depth)
+        assert int(node.kernel_name.split("<")[1].split(",")[0]) == 32 + 16 + 4 + 1 + 2 * rm
+        node.close()
+        cfg = dict(view_steps=8, cloud_steps=64, cloud_light_rm=rm, light_steps=8, cube_lod=1)
+        want, _ = oracle32.render(params, dict(tex, cubemap=oracle32.cubemap_mip_chain(tex["cubemap"])), cfg, demo_frame(cam), depth, nthreads=8)
+        assert np.abs(got - want).max() <= TOL
+    for kw in (dict(precise_clouds=False),):
         node = make_node("clouds_high", tex, params, cubemap_lod=True, **kw)
         with pytest.raises(N.AtmoError) as e:
             _gpu_render(node, cam, depth)
