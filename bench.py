@@ -180,11 +180,15 @@ def parse_args():
     ap.add_argument("--motion", default="", help="orbit:<deg/frame> or pan:<deg/frame>: a new camera pose every step (N = 1); "
                     "all frames and depth buffers are prepared before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", default="every", choices=["final", "every", "none"],
+    ap.add_argument("--band-cost", default="measured", choices=["measured", "analytic"],
+                    help="--shard bands: cut the viewport by MEASURED per-row costs (rank 0 draws the frame once through "
+                         "atmo_measure_tile_costs and broadcasts the cuts; default) or by the analytic estimate cloud_row_cost")
+    ap.add_argument("--gather", default="every", choices=["final", "none-then-final", "every", "none"],
                     help="N>1: 'every' (default) = RCCL gather of EVERY frame to rank 0, two in flight, overlapped with the "
-                         "next render (root ingress over xGMI then sets the step time); 'final' = one gather of every rank's "
-                         "last frame inside the timed region; 'none' = no collective.  The no-gather rate is measured in a "
-                         "second loop and reported as config.mrays_per_s_no_gather either way (SURVEY.md 8e asks for both).")
+                         "next render (root ingress over xGMI then sets the step time); 'final' (= 'none-then-final', north_star's "
+                         "\"final RCCL gather\") = frames stay where they were rendered, one gather of every rank's last frame "
+                         "inside the timed region; 'none' = no collective.  Whatever the mode, the other two rates are measured in "
+                         "further loops and reported as config.mrays_per_s_no_gather / _final_gather (SURVEY.md 8e asks for both).")
     ap.add_argument("--shard", default="viewports", choices=["viewports", "bands"],
                     help="N>1: 'viewports' = one full viewport per GPU (weak scaling, default); 'bands' = ONE viewport cut "
                          "into hit-balanced row bands, one per GPU, gathered in place into the frame on rank 0 (strong scaling)")
@@ -647,6 +651,8 @@ def bench_two_viewports(torch, S, name, w, h, steps, warmup, textures, params, l
 
 def main():
     args = parse_args()
+    if args.gather == "none-then-final":
+        args.gather = "final"
     import numpy as np
     import torch
 
@@ -700,9 +706,22 @@ def main():
         gather_mode = "none (single GPU)"
     else:
         if strong:
-            # ONE frame in row bands balanced by the estimated work per row (shell hits, cloud-shell hits weighted)
+            # ONE frame in row bands of equal WORK.  Measured: rank 0 draws the whole frame once and reads back what every tile
+            # cost (atmo_measure_tile_costs), sums per pixel row, cuts, and broadcasts the cuts (every rank must use the same);
+            # analytic (--band-cost analytic): shell hits per row, cloud-shell hits weighted (cloud_row_cost).
             from godot_atmosphere_shader_amd.sharding import balanced_row_bands, band_rect
-            bands = balanced_row_bands(cloud_row_cost(np, S, cam, "cloud" in config_name), world)
+            if args.band_cost == "measured":
+                cuts = torch.zeros(world + 1, dtype=torch.int64, device=device)
+                if rank == 0:
+                    for _ in range(3):  # clocks and caches warm; the last measurement counts
+                        row_cost = node.measure_row_costs(cam, depth)
+                    b = balanced_row_bands(row_cost, world)
+                    cuts.copy_(torch.tensor([b[0][0]] + [x[1] for x in b], dtype=torch.int64))
+                dist.broadcast(cuts, src=0)
+                c = [int(v) for v in cuts.tolist()]
+                bands = [(c[k], c[k + 1]) for k in range(world)]
+            else:
+                bands = balanced_row_bands(cloud_row_cost(np, S, cam, "cloud" in config_name), world)
             frame = node.prepare_frame(cam, rect=band_rect(w, bands[rank]))
         else:
             frame = node.prepare_frame(cam)
@@ -731,11 +750,17 @@ def main():
         gather_mode = {"none": "no collective",
                        "final": "one RCCL gather of each rank's last frame to rank 0, inside the timed region",
                        "every": "RCCL gather of every frame to rank 0, 2 frames in flight, inside the timed region"}[args.gather]
+        # the rates WITHOUT the gather and with only the FINAL gather next to the headline mode's (same loop)
+        final_gather_rate = None
+        scale = 1 if strong else world
         if args.gather != "none":
-            # the rate WITHOUT the gather next to the rate with it (same loop, no collective)
             dt_ng, _, _ = timed_loop_distributed(torch, dist, render_into, h, w, device, args.steps, max(2, args.warmup // 4),
                                                  "none", None, bands=bands)
-            no_gather_rate = (1 if strong else world) * rays * args.steps / dt_ng / 1e6
+            no_gather_rate = scale * rays * args.steps / dt_ng / 1e6
+        if args.gather != "final":
+            dt_fg, _, _ = timed_loop_distributed(torch, dist, render_into, h, w, device, args.steps, max(2, args.warmup // 4),
+                                                 "final", None, bands=bands)
+            final_gather_rate = scale * rays * args.steps / dt_fg / 1e6
 
     result = None
     if rank == 0:
@@ -772,7 +797,8 @@ def main():
                 "mrays_per_s_hit_only": value * hit_fraction,
                 "gather": gather_mode,
                 "mrays_per_s_no_gather": no_gather_rate,
-                "shard": ("one viewport in work-balanced row bands: " + str(bands)) if strong else "one viewport per GPU",
+                "mrays_per_s_final_gather": (value if args.gather == "final" else final_gather_rate) if multi else None,
+                "shard": (f"one viewport in row bands of equal {args.band_cost} cost: " + str(bands)) if strong else "one viewport per GPU",
                 "kernel": node.kernel_name,
             },
             "roofline": hbm_roofline(kernel_avg_ms, launches, launch_rays, pmc, None if run is None else run.isolated_ms),

@@ -156,6 +156,7 @@ struct AtmoContext {
     float env_reach_scale = 1.0f;                      // ATMO_FB_REACH_SCALE: multiplies the predicted reach (A/B)
     unsigned moving_period = 2;                        // ATMO_FB_MOVING_PERIOD: recording period while the camera moves
     int instream = 1;                                  // ATMO_FB_INSTREAM=0: never sort on the draw stream (A/B)
+    uint32_t *measure_cost = nullptr;                  // atmo_measure_tile_costs: the next draw records here
     bool drew = false;                                 // a draw of this context has been enqueued ...
     hipStream_t last_draw_stream = nullptr;            // ... most recently on this stream (texture updates elsewhere wait)
 #ifdef ATMO_WAVE_TRACE
@@ -1006,6 +1007,48 @@ int atmo_render_composite(AtmoContext *ctx, const AtmoFrame *frame, const float 
     return render_impl(ctx, frame, depth_dev, scene_rgba_dev, stream, true);
 }
 
+int atmo_measure_tile_costs(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, void *stream,
+                            uint32_t *cost_host, int capacity_tiles, int *tiles_x, int *tiles_y, int *tile_w, int *tile_h) {
+    if (!ctx) return ATMO_E_ARG;
+    if (!frame) return fail(ctx, ATMO_E_ARG, "atmo_measure_tile_costs: null frame");
+    if (frame->x1 <= frame->x0 || frame->y1 <= frame->y0) return fail(ctx, ATMO_E_ARG, "atmo_measure_tile_costs: empty rect");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // the grid this rect is drawn with (same choice as render_impl)
+    atmo::RenderConsts probe;
+    std::memset(&probe, 0, sizeof(probe));
+    probe.x0 = frame->x0; probe.y0 = frame->y0; probe.x1 = frame->x1; probe.y1 = frame->y1;
+    const int split = (ctx->sampler_lod && (ctx->flags & atmo::KF_CLOUDS) && ctx->cube.ptr && ctx->cube_levels > 1) ? 1 : choose_split(ctx, frame);
+    int gx = 0, gy = 0;
+    atmo::render_grid(probe, split, &gx, &gy);
+    if (tiles_x) *tiles_x = gx;
+    if (tiles_y) *tiles_y = gy;
+    if (tile_w) *tile_w = 16;
+    if (tile_h) *tile_h = split == 2 ? 4 : 8;
+    if (!cost_host) return ATMO_OK;
+    if (capacity_tiles < gx * gy) return fail(ctx, ATMO_E_ARG, "atmo_measure_tile_costs: cost buffer too small (call with cost_host = NULL for the grid)");
+    uint32_t *d = nullptr;
+    const size_t bytes = (size_t)gx * gy * sizeof(uint32_t);
+    HIP_TRY(ctx, hipMalloc(&d, bytes));
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(d, 0, bytes, s);
+    int rc = ATMO_OK;
+    if (e != hipSuccess) rc = hip_fail(ctx, e, "hipMemsetAsync");
+    if (rc == ATMO_OK) {
+        ctx->measure_cost = d;  // render_impl: record into this buffer, row-major order, no feedback bookkeeping
+        rc = render_impl(ctx, frame, depth_dev, rgba_dev, stream, false);
+        ctx->measure_cost = nullptr;
+    }
+    if (rc == ATMO_OK) {
+        e = hipMemcpyAsync(cost_host, d, bytes, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = hip_fail(ctx, e, "atmo_measure_tile_costs");
+    } else {
+        (void)hipStreamSynchronize(s);
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
 static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, void *stream, bool composite) {
     if (!ctx) return ATMO_E_ARG;
     if (!frame) return fail(ctx, ATMO_E_ARG, "atmo_render: null frame");
@@ -1055,6 +1098,7 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     rc.tiles_x = gx;
     // default (-1): on for every variant since the sort no longer costs the draws anything (profiles/round2/ab_tile_feedback.txt)
     bool feedback = ctx->env_feedback >= 0 ? ctx->env_feedback != 0 : ctx->tile_feedback != 0;
+    if (ctx->measure_cost) feedback = false;  // a measuring draw: plain row-major launch that records into the caller's buffer
     if (feedback && (long long)gx * gy < 512) feedback = false;  // tiny launches: nothing to schedule
     if (feedback) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -1139,6 +1183,7 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
             }
         }
     }
+    if (ctx->measure_cost) rc.tile_cost = ctx->measure_cost;
     // kernel timing brackets the draw kernel alone (the tile-order kernel runs beside the previous draw).  The event pair
     // is owned by a guard until it is handed to ctx->pending, so no error path leaks it.
     struct EventPair {

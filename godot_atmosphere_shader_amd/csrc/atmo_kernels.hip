@@ -157,8 +157,11 @@ __device__ __forceinline__ float exact_div_uniform(float a, float c, float rc) {
 #ifndef ATMO_FAST_MISS
 #define ATMO_FAST_MISS 1
 #endif
+#ifndef ATMO_WORLD_DIV3  // 1: the three world.xyz / world.w quotients share one reciprocal in the DIET kernels (world_div3)
+#define ATMO_WORLD_DIV3 1
+#endif
 #ifndef ATMO_FAST_MISS_MASK
-#define ATMO_FAST_MISS_MASK 0xff
+#define ATMO_FAST_MISS_MASK 0x05  // baked-LUT atmosphere with and without clouds: -1.4 % / -0.7 %; the direct-light kernels lose 11 % (!), v1 1.5 %
 #endif
 // Both forms give the same bits; which one a kernel variant uses is a measured choice (profiles/round2/ab_prologue.txt:
 // the short forms gain 3-4 % on the baked-LUT atmosphere kernels and cost the direct-light and the raymarched-cloud-light
@@ -170,6 +173,24 @@ __device__ __forceinline__ float pixel_coord(float a, float n, float rcp_n) {
     if (!DIET) return ieee_div(a, n);
     const float q0 = a * rcp_n;
     return __builtin_fmaf(__builtin_fmaf(-q0, n, a), rcp_n, q0);
+}
+// world.xyz / world.w (main:134-135): three IEEE quotients by the SAME divisor.  Short form: one IEEE reciprocal RN(1 / w) and
+// two Markstein corrections per quotient (exact_div_uniform: correctly rounded given a correctly rounded reciprocal; swept on
+// the device for every significand against a / c, tests/test_gpu_parity.py::test_exact_math_selftest) -- 1 division + 15 FMAs
+// instead of 3 divisions.  Used when |w| is an ordinary number (2^-100 .. 2^100: w = 0 or inf, a far plane at infinity, takes the
+// IEEE path and keeps its inf / NaN semantics); a numerator in (0, 2^-100) could come out 1 ulp off (its FMA residual
+// underflows) -- a world coordinate below 1e-30.
+template <bool DIET = true>
+__device__ __forceinline__ void world_div3(float wx, float wy, float wz, float ww, float &x, float &y, float &z) {
+    const float aw = fabsf(ww);
+    if (DIET && aw >= 7.8886090522101181e-31f && aw <= 1.2676506002282294e30f) {
+        const float rw = ieee_div(1.0f, ww);
+        x = exact_div_uniform(wx, ww, rw);
+        y = exact_div_uniform(wy, ww, rw);
+        z = exact_div_uniform(wz, ww, rw);
+    } else {
+        x = ieee_div(wx, ww); y = ieee_div(wy, ww); z = ieee_div(wz, ww);
+    }
 }
 template <bool DIET = true>
 __device__ __forceinline__ float blue_noise_value(uint8_t b);
@@ -1226,7 +1247,8 @@ __device__ __forceinline__ PixelRay pixel_ray(const RenderConsts &rc, int px, in
     const float wy = Vm[1] * vx + Vm[5] * vy + Vm[9] * vz + Vm[13] * vw;
     const float wz = Vm[2] * vx + Vm[6] * vy + Vm[10] * vz + Vm[14] * vw;
     const float ww = Vm[3] * vx + Vm[7] * vy + Vm[11] * vz + Vm[15] * vw;
-    const float pwx = ieee_div(wx, ww), pwy = ieee_div(wy, ww), pwz = ieee_div(wz, ww);
+    float pwx, pwy, pwz;
+    world_div3(wx, wy, wz, ww, pwx, pwy, pwz);
     const float ddx = rc.cam_pos_world[0] - pwx, ddy = rc.cam_pos_world[1] - pwy, ddz = rc.cam_pos_world[2] - pwz;
     float linear_depth = prologue_sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
 
@@ -1356,7 +1378,8 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
     const float wy = Vm[1] * vx + Vm[5] * vy + Vm[9] * vz + Vm[13] * vw;
     const float wz = Vm[2] * vx + Vm[6] * vy + Vm[10] * vz + Vm[14] * vw;
     const float ww = Vm[3] * vx + Vm[7] * vy + Vm[11] * vz + Vm[15] * vw;
-    const float pwx = ieee_div(wx, ww), pwy = ieee_div(wy, ww), pwz = ieee_div(wz, ww);
+    float pwx, pwy, pwz;
+    world_div3<DIET && ATMO_WORLD_DIV3>(wx, wy, wz, ww, pwx, pwy, pwz);
     const float ddx = rc.cam_pos_world[0] - pwx, ddy = rc.cam_pos_world[1] - pwy, ddz = rc.cam_pos_world[2] - pwz;
     float linear_depth = prologue_sqrt<DIET>(ddx * ddx + ddy * ddy + ddz * ddz);
 

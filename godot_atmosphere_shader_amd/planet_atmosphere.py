@@ -602,6 +602,30 @@ class PlanetAtmosphere:
         rc = self._lib.atmo_render(self._ctx, C.byref(nf), C.c_void_p(depth_ptr), C.c_void_p(out_ptr), C.c_void_p(stream or 0))
         N.check(self._ctx, rc)
 
+    def measure_row_costs(self, camera, depth, rect=None, stream=None, time: float = 0.0):
+        """Measured cost of every pixel row of `rect` (default: the whole viewport): one draw through atmo_measure_tile_costs,
+        each tile's cost (longest wavefront, shader cycles) spread over its pixel rows and summed along the row.  Feed it to
+        sharding.balanced_row_bands to cut a viewport into row bands of equal WORK for several GPUs."""
+        import torch
+
+        frame = self.make_frame(camera, time, rect)
+        x0, y0, x1, y1 = frame["rect"]
+        nf = _to_native_frame(frame)
+        if stream is None:
+            stream = torch.cuda.current_stream(depth.device).cuda_stream
+        elif hasattr(stream, "cuda_stream"):
+            stream = stream.cuda_stream
+        self._bake_if_needed(stream)
+        scratch = torch.empty((y1 - y0, x1 - x0, 4), dtype=torch.float32, device=depth.device)
+        gx, gy, tw, th = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        args = (self._ctx, C.byref(nf), C.c_void_p(depth.data_ptr()), C.c_void_p(scratch.data_ptr()), C.c_void_p(stream or 0))
+        N.check(self._ctx, self._lib.atmo_measure_tile_costs(*args, None, 0, C.byref(gx), C.byref(gy), C.byref(tw), C.byref(th)))
+        cost = np.zeros((gy.value, gx.value), dtype=np.uint32)
+        N.check(self._ctx, self._lib.atmo_measure_tile_costs(*args, cost.ctypes.data_as(C.c_void_p), cost.size, C.byref(gx), C.byref(gy),
+                                                            C.byref(tw), C.byref(th)))
+        rows = np.repeat(cost.astype(np.float64).sum(axis=1) / th.value, th.value)[: y1 - y0]
+        return rows
+
     def feedback_stats(self) -> dict:
         """atmo_get_feedback_stats (diagnostics of the tile-order feedback)."""
         st, od, so, rc = C.c_int(0), C.c_uint(0), C.c_uint(0), C.c_uint(0)

@@ -94,12 +94,30 @@ class FrameGather:
                              for _ in range(self.depth)]
                 self.frames = [torch.empty((height, width, 4), dtype=torch.float32, device=device) for _ in range(self.depth)]
 
+    def _root_slot(self, slot: int):
+        """On the root: the part of the receive buffer its own contribution lands in -- rendering straight into it makes the
+        root's share of the gather a no-op (dist.gather copies tensor -> gather_list[dst] on the root only when they differ;
+        a root that rendered into a separate send buffer paid one device-to-device copy of its whole frame per gather:
+        15.4 against 22.2 Grays/s on a 1-rank group in round 2).  None where the layouts differ (unequal bands are padded)."""
+        if self.rank != self.dst:
+            return None
+        r = self.recv[slot]
+        if self.bands is None:
+            return r[self.rank]
+        if self.equal:
+            b = self.bands[self.rank]
+            return r[b[0]:b[1]]
+        return None
+
     def next_send_buffer(self):
         """Buffer to render the next contribution into.  Waits (stream-side) for the gather that last used it."""
         slot = self._slot
         while len(self._inflight) >= self.depth:
             work, _ = self._inflight.pop(0)
             work.wait()
+        own = self._root_slot(slot)
+        if own is not None:
+            return own, slot
         buf = self.send[slot]
         if self.bands is not None:
             rows = self.bands[self.rank][1] - self.bands[self.rank][0]
@@ -111,13 +129,18 @@ class FrameGather:
         current stream)."""
         dist = self.dist
         gather_list = None
+        tensor = self.send[slot]
         if self.rank == self.dst:
             r = self.recv[slot]
             if self.bands is not None and self.equal:
                 gather_list = [r[b[0]:b[1]] for b in self.bands]
             else:
                 gather_list = [r[k] for k in range(self.world)]
-        work = dist.gather(self.send[slot], gather_list, dst=self.dst, group=self.group, async_op=True)
+            own = self._root_slot(slot)
+            if own is not None:
+                tensor = own                   # rendered in place ...
+                gather_list[self.rank] = own   # ... and the very same tensor object: the root's self-copy is skipped
+        work = dist.gather(tensor, gather_list, dst=self.dst, group=self.group, async_op=True)
         self._inflight.append((work, slot))
         self._slot = (slot + 1) % self.depth
         return work

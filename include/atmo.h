@@ -187,6 +187,16 @@ int atmo_render(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev
 int atmo_render_composite(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *scene_rgba_dev, void *stream);
 
 /*
+ * Sharding aid (no reference counterpart: the reference is single-GPU): draws the rect like atmo_render and
+ * returns what every pixel tile of that draw cost -- the longest of its wavefronts, in shader cycles, row-major over the
+ * launch grid (tiles_x x tiles_y tiles of tile_w x tile_h pixels, the last column / row clipped by the rect).  A host that
+ * cuts one viewport into row bands for several GPUs sums these per row and cuts at equal cost (sharding.balanced_row_bands)
+ * instead of guessing from geometry.  cost_host == NULL only reports the grid.  Waits for the draw (a set-up call).
+ */
+int atmo_measure_tile_costs(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, void *stream,
+                            uint32_t *cost_host, int capacity_tiles, int *tiles_x, int *tiles_y, int *tile_w, int *tile_h);
+
+/*
  * Numerical mode of the cloud kernels and of the v1 ("lite") atmosphere (no reference counterpart; the v2 atmosphere has a
  * single form).
  * 1 (default, precise): the whole cloud density expression, both texture filters included, is evaluated in the

@@ -209,6 +209,71 @@ def test_bench_distributed_timed_loop_world_size_4(tmp_path, mode):
         assert (tmp_path / f"ok4_{mode}_{r}").exists()
 
 
+def _bench_worker8(rank, world, port, tmpdir):
+    """BASELINE configs[4]'s shape: eight independent 3840 x 2160 RGBA32F viewports, one per rank, gathered to rank 0 every frame
+    (132.7 MB per rank and frame), bench.py's own timed loop; the root renders into its slot of the receive buffer."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from godot_atmosphere_shader_amd.sharding import FrameGather
+
+        h, w = 2160, 3840
+        calls = {"n": 0, "ptrs": set()}
+
+        def render_into(buf):
+            calls["n"] += 1
+            calls["ptrs"].add(buf.data_ptr())
+            buf[::540, ::960].fill_(float(100 * rank + calls["n"]))   # a sparse signature: the test moves 1 GB per gather as it is
+
+        steps, warmup = 1, 0   # plus the loop's own set-up gather: 2 x 1 GB through gloo
+        dt, _, _ = bench.timed_loop_distributed(torch, dist, render_into, h, w, torch.device("cpu"), steps, warmup, "every", None)
+        assert dt > 0 and calls["n"] == steps + warmup
+        res = bench.timed_loop_distributed.last_gathered
+        if rank == 0:
+            assert res.shape == (world, h, w, 4) and res.element_size() * res[0].numel() == 132710400
+            for r in range(world):
+                assert torch.all(res[r, ::540, ::960] == float(100 * r + steps + warmup)), r
+            # the root's frames were rendered inside the receive buffers: no send buffer, no self-copy
+            g = FrameGather(h, w, torch.device("cpu"), dst=0, depth=1)
+            buf, slot = g.next_send_buffer()
+            assert buf.data_ptr() == g.recv[slot][0].data_ptr()
+        else:
+            assert res is None
+        with open(os.path.join(tmpdir, f"ok8_{rank}"), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_distributed_timed_loop_world_size_8_config4_shape(tmp_path):
+    world = 8
+    port = _free_port()
+    mp.spawn(_bench_worker8, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert (tmp_path / f"ok8_{r}").exists()
+
+
+def test_measured_row_costs_cut_bands_of_equal_work():
+    """bench.py --shard bands --band-cost measured: per-row sums of measured tile costs (atmo_measure_tile_costs) cut the frame;
+    here with a synthetic cost map shaped like a cloud frame (a heavy blob off-centre on a cheap background)."""
+    sys.path.insert(0, ROOT)
+    from godot_atmosphere_shader_amd.sharding import balanced_row_bands
+
+    gy, gx, th = 135, 120, 8
+    yy, xx = np.mgrid[0:gy, 0:gx]
+    cost = 2000.0 + 60000.0 * np.exp(-(((yy - 40) / 12.0) ** 2 + ((xx - 70) / 25.0) ** 2))
+    rows = np.repeat(cost.sum(axis=1) / th, th)[:1080]
+    for world in (2, 4, 8):
+        bands = balanced_row_bands(rows, world)
+        assert bands[0][0] == 0 and bands[-1][1] == 1080 and all(bands[k][1] == bands[k + 1][0] for k in range(world - 1))
+        work = np.array([rows[a:b].sum() for a, b in bands])
+        assert work.max() / work.mean() < 1.0 + 0.02 * world          # within a row's worth of the mean
+        equal = np.array([rows[1080 * k // world:1080 * (k + 1) // world].sum() for k in range(world)])
+        assert equal.max() / equal.mean() > 1.25                      # equal ROWS would leave one GPU with far more work
+
+
 def test_cloud_weighted_row_cost_balances_cloud_variants():
     """bench.py --shard bands: rows that cross the cloud shell weigh CLOUD_WEIGHT more for the cloud variants, so the
     bands of a cloud frame are cut by estimated work, not by shell hits alone."""

@@ -301,6 +301,15 @@ def test_exact_math_selftest():
         rc = lib.atmo_selftest_exact_math(ctx, e << 23, 1 << 23, divisors[e % len(divisors)], C.byref(bs), C.byref(bd))
         assert rc == N.ATMO_OK
         assert bs.value == 0 and bd.value == 0, (e, bs.value, bd.value)
+    # round 3: the same function divides world.xyz by a per-pixel world.w with RN(1 / w) as its reciprocal (world_div3): more
+    # divisors -- all-ones and all-zeros significands, numbers just above / below powers of two, random ones, negative ones
+    rng = np.random.default_rng(3)
+    more = [float(np.float32(x)) for x in (1.0, 0.99999994, 1.0000001, 3.9999998, -1.9999999, 0.1, -7.25, 1e-20, 3e20, 123456.79)]
+    more += [float(np.uint32(rng.integers(0x30000000, 0x50000000)).view(np.float32)) for _ in range(14)]
+    for k, dv in enumerate(more):
+        bs, bd = C.c_uint32(0), C.c_uint32(0)
+        assert lib.atmo_selftest_exact_math(ctx, (110 + 2 * k) << 23, 1 << 23, dv, C.byref(bs), C.byref(bd)) == N.ATMO_OK
+        assert bd.value == 0, (dv, bd.value)
     # negative dividends (heights below the cloud bottom)
     bs, bd = C.c_uint32(0), C.c_uint32(0)
     assert lib.atmo_selftest_exact_math(ctx, (1 << 31) | (127 << 23), 1 << 23, divisors[0], C.byref(bs), C.byref(bd)) == N.ATMO_OK
