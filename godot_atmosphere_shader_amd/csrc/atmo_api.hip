@@ -1117,7 +1117,9 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     // move in that time; the sort dilates the cost map by that distance, so a tile counts as cheap only if everything within
     // reach of it was cheap (atmo_tile_dilate_kernel); costs are recorded every 2nd draw instead of every fb_period-th while
     // the camera moves; and an order whose reach the motion has outrun is not used (row-major instead).
-    constexpr float FB_STILL_PX = 0.5f, FB_MAX_REACH_PX = 160.0f, FB_INSTREAM_PX = 3.0f;
+    // reach beyond which an order says nothing about the frame it would be used on: 160 px for the in-stream sort (a frame of lag),
+    // 48 px for the side-stream sort (four to six frames of lag: measured, recording every 2nd frame without a usable order costs 1-2 %)
+    constexpr float FB_STILL_PX = 0.5f, FB_MAX_REACH_PX = 160.0f, FB_MAX_REACH_SIDE_PX = 48.0f, FB_INSTREAM_PX = 3.0f;
     int dil_rx = 0, dil_ry = 0;
     float reach_px = 0.0f;
     if (fb) {
@@ -1133,7 +1135,7 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         const unsigned period = moving ? (ctx->fb_period < ctx->moving_period ? ctx->fb_period : ctx->moving_period) : ctx->fb_period;
         // what an order sorted now would have to cover: it is in use from ~2 frames after its recording draw until the next takes over
         const float want_reach = moving ? fb->motion_px * (float)(period + 4u) * ctx->env_reach_scale : 0.0f;
-        const bool too_fast = want_reach > FB_MAX_REACH_PX;  // nothing measured now says anything about the frame it would order
+        const bool too_fast = want_reach > FB_MAX_REACH_SIDE_PX;  // nothing measured now says anything about the frame it would order
         if (fb->pending) {
             if (hipEventQuery(fb->ev_order[fb->write]) == hipSuccess) {
                 fb->active = fb->write;  // complete: no stream-side wait needed
