@@ -582,7 +582,8 @@ def run_workload(torch, S, name, w, h, pose, steps, warmup, textures, params, lo
 
 def workload_suffix(config_name, sampler):
     """States which sampler a cloud number is for (the reference declares a linear-mipmap samplerCube, cloud_funcs.gdshaderinc:15,45)."""
-    if "cloud" not in config_name:
+    from godot_atmosphere_shader_amd.demo import CONFIGS
+    if not CONFIGS[config_name][1].get("cloud_steps"):
         return ""
     if sampler == "lod":
         return "; coverage cubemap sampled with the implicit LOD of a linear-mipmap sampler (the reference's declared sampler)"

@@ -1135,7 +1135,10 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         const unsigned period = moving ? (ctx->fb_period < ctx->moving_period ? ctx->fb_period : ctx->moving_period) : ctx->fb_period;
         // what an order sorted now would have to cover: it is in use from ~2 frames after its recording draw until the next takes over
         const float want_reach = moving ? fb->motion_px * (float)(period + 4u) * ctx->env_reach_scale : 0.0f;
-        const bool too_fast = want_reach > FB_MAX_REACH_SIDE_PX;  // nothing measured now says anything about the frame it would order
+        // nothing measured now says anything about the frame it would order -- or the frames are so short (the baked-LUT atmosphere
+        // without clouds: 20-50 us, +3 % from the order at best) that recording and sorting every other frame costs more than it brings
+        const bool short_frames = !(flags & (atmo::KF_CLOUDS | atmo::KF_LIGHT_DIRECT));
+        const bool too_fast = want_reach > FB_MAX_REACH_SIDE_PX || (moving && short_frames);
         if (fb->pending) {
             if (hipEventQuery(fb->ev_order[fb->write]) == hipSuccess) {
                 fb->active = fb->write;  // complete: no stream-side wait needed

@@ -584,7 +584,7 @@ def test_hip_direct_light_march_against_the_reference_lut(oracle32, vectors, tex
         print(f"{sname}: light march, {steps} steps: max relative deviation {rel_big:.3e} over the {int(big.sum())} texels >= 1e-3 max "
               f"({want.max():.3g}); max absolute deviation below that {abs_small:.3e}")
         assert rel_big <= (1e-5 if steps == 64 else 2e-5)   # 64: against the executed reference's texels; 8: against the fp32 oracle, itself rounded
-        assert abs_small <= 1e-5 * 1e-3 * want.max()
+        assert abs_small <= 2e-5 * 1e-3 * want.max()
     node.close()
 
 
