@@ -177,6 +177,9 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--pose", default="P_space")
+    ap.add_argument("--sampler", default="lod0", choices=["lod0", "lod"],
+                    help="cloud workloads: how the coverage cubemap is sampled -- 'lod0' (level 0; every cloud number of rounds 1-2) or "
+                         "'lod' (the implicit LOD of the linear-mipmap sampler the reference declares, atmo_set_sampler_lod 1)")
     ap.add_argument("--motion", default="", help="orbit:<deg/frame> or pan:<deg/frame>: a new camera pose every step (N = 1); "
                     "all frames and depth buffers are prepared before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -686,7 +689,8 @@ def main():
     cam = S.Camera.from_pose(w, h, pose)
     depth_np = S.depth_ground_sphere(cam)
     depth = torch.from_numpy(depth_np).cuda()
-    node = make_node(config_name, textures, params, device=local_rank, **node_kwargs(args.workload))
+    lod = args.sampler == "lod" and bool(__import__("godot_atmosphere_shader_amd.demo", fromlist=["CONFIGS"]).CONFIGS[config_name][1].get("cloud_steps"))
+    node = make_node(config_name, textures, params, device=local_rank, **dict(node_kwargs(args.workload), **(dict(cubemap_lod=True) if lod else {})))
     rays = w * h
     device = torch.device("cuda", local_rank)
 
@@ -768,7 +772,7 @@ def main():
         value = (1 if strong else world) * rays * args.steps / dt_max / 1e6
         if no_gather_rate is None:
             no_gather_rate = value
-        pmc = None if (strong or args.pose != "P_space") else pmc_summary(args.workload, w, h)
+        pmc = None if (strong or args.pose != "P_space" or motion is not None) else pmc_summary(args.workload + ("@lod" if lod else ""), w, h)
         kernel_avg_ms = kernel_ms / launches if launches else 0.0
         launch_rays = rays if not strong else w * (bands[0][1] - bands[0][0])  # rank 0's kernel shades its band only
         frame_img = node.render(cam, depth)
@@ -791,7 +795,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{desc}{workload_suffix(config_name, None)}; {w}x{h}; demo scene, pose {args.pose}"
+                "workload": f"{desc}{workload_suffix(config_name, 'lod' if lod else None)}; {w}x{h}; demo scene, pose {args.pose}"
                             + ("" if world == 1 or strong else f" on rank 0, orbit poses on ranks 1..{world - 1}; one viewport per GPU"),
                 "width": w, "height": h, "rays_per_step_per_gpu": rays if not strong else None,
                 "hit_fraction": hit_fraction,

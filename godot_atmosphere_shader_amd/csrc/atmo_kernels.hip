@@ -883,14 +883,27 @@ __device__ __forceinline__ float cloud_density_precise(const RenderConsts &rc, f
     const float t = 2.0f * hr - 1.0f;
     const float hc = fmaxf(1.0f - t * t, 0.0f);
     if (EARLY_OUT && !(hc > 0.0f)) return 0.0f;
+    if (EARLY_OUT && LOD) {
+        // Before the (expensive) implicit-LOD coverage sample: near the top and the bottom of the layer the height curve alone
+        // decides.  A filtered UNORM8 texel (any level, any mix of two levels) is at most 1 + 2^-20, and every fp32 step from the
+        // texel to the density is monotone non-decreasing in it (cloud_density_precise below), so if the expression is <= 0 at
+        // that bound and at the largest shape value the exact result is 0.  ~10 % of the samples inside the layer.
+        const float cov_hi = (1.0f + 9.5367431640625e-07f) - 0.25f * hr + rc.coverage_bias;
+        const float m_hi = -1.2f * (1.0f - cov_hi) + 1.5f * cov_hi;
+        if (((rc.shape_hi01 + m_hi) * hc) * 50.0f - 20.0f <= 0.0f) return 0.0f;
+    }
     float coverage = 1.0f;
     if (rc.cube != nullptr) {
         const float qx = rc.cov_rot[0] * px + rc.cov_rot[2] * pz;
         const float qz = rc.cov_rot[1] * px + rc.cov_rot[3] * pz;
         if (LOD) {
             auto rot = [&](V3 q) { return V3{rc.cov_rot[0] * q.x + rc.cov_rot[2] * q.z, q.y, rc.cov_rot[1] * q.x + rc.cov_rot[3] * q.z}; };
+#ifdef ATMO_LOD_FAST_ONLY  // static instruction counts of the fast path alone (tools/isa_histogram.py); never shipped
+            coverage = cube_sample_lod_fast(rc, V3{qx, py, qz}, nb->vx, rot(nb->px), nb->vy, rot(nb->py));
+#else
             if (rc.cube_lod_fast) coverage = cube_sample_lod_fast(rc, V3{qx, py, qz}, nb->vx, rot(nb->px), nb->vy, rot(nb->py));
             else coverage = cube_sample_lod(rc, V3{qx, py, qz}, nb->vx, rot(nb->px), nb->vy, rot(nb->py));
+#endif
         } else {
             coverage = cube_sample<true>(rc.cube, rc.cube_n, qx, py, qz);
         }

@@ -4,6 +4,7 @@
 # Output: gpurun_out/prof_<workload>/{stats,pmc_*}/...csv ; summarise with tools/summarize_pmc.py
 set -u
 WL=${1:-direct32x8}; W=${2:-1920}; H=${3:-1080}; POSE=${4:-P_space}
+SAMPLER=lod0; case "$WL" in *@lod) SAMPLER=lod; WLN=${WL%@lod};; *) WLN=$WL;; esac   # clouds_high@lod = --workload clouds_high --sampler lod
 R=$PWD
 # the real interpreter binary, resolved BEFORE profiling: a pyenv/conda shim or wrapper script after `--` would be an
 # exec hop behind the profiler's preloaded (GPU-initialising) library, which this pool forbids
@@ -12,7 +13,7 @@ OUT=$R/gpurun_out/prof_${WL}_${W}x${H}$( [ "$POSE" = P_space ] || echo _$POSE )
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--workload $WL --width $W --height $H --pose $POSE --no-cpu-baseline --also ,"
+ARGS="--workload $WLN --sampler $SAMPLER --width $W --height $H --pose $POSE --no-cpu-baseline --also ,"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $PY $R/bench.py $ARGS --steps 50 --warmup 5 > $OUT/stats.log 2>&1
 i=0
 for PMC in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
