@@ -604,7 +604,11 @@ def bench_motion(torch, S, name, w, h, steps, warmup, textures, params, local_ra
         for fb in (1, 0):
             r = run_workload(torch, S, name, w, h, "P_space", steps, warmup, textures, params, local_rank, with_frame_stats=False,
                              motion=motion if motion is not None else ("orbit", 0.0), node_extra=dict(tile_feedback=fb))
-            row["feedback_on" if fb else "feedback_off"] = {k: r[k] for k in ("Mrays/s", "ms_per_step", "kernel_avg_ms", "roofline")}
+            rf = r["roofline"]
+            row["feedback_on" if fb else "feedback_off"] = {
+                "Mrays/s": r["Mrays/s"], "ms_per_step": r["ms_per_step"], "kernel_avg_ms": r["kernel_avg_ms"],
+                "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_avg_ms", "algorithmic_bytes_per_launch")},
+                "feedback_stats": r["feedback_stats"]}
         row["gain"] = row["feedback_on"]["Mrays/s"] / row["feedback_off"]["Mrays/s"] - 1.0
         out[key] = row
     out["workload"] = (f"{WORKLOADS[name][1]}; {w}x{h}; demo scene, camera still / orbiting / panning (bench.motion_cameras), "

@@ -9,6 +9,10 @@ for k, v in (d.get("extra") or {}).items():
     if "Mrays/s" in v:
         r = v.get("valu_roofline") or {}
         print(f"  {k:28s} {v['Mrays/s']:9.0f} Mrays/s  kernel {v.get('kernel_avg_ms')}  {v.get('kernel')}  valu frac {r.get('frac_vs_spec')} / {r.get('frac_vs_measured')}")
+    elif "static" in v:  # name@moving: camera still / orbiting / panning, tile-order feedback on and off
+        for m, row in v.items():
+            if isinstance(row, dict):
+                print(f"  {k:28s} {m:10s} feedback on {row['feedback_on']['Mrays/s']:8.0f}  off {row['feedback_off']['Mrays/s']:8.0f} Mrays/s  gain {100 * row['gain']:+5.1f} %")
     else:
         print(f"  {k:28s} {v}")
 print("  cpu_baseline", d.get("cpu_baseline"))
