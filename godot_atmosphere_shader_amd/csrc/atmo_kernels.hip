@@ -973,12 +973,20 @@ __device__ __forceinline__ void cloud_height(const RenderConsts &rc, float px, f
 
 // get_light_raymarched (cloud_funcs.gdshaderinc:104-151): 6 density taps towards the sun.
 // 1 - prod(exp(-d_i)) = 1 - exp(-sum d_i): one exp instead of six.
+// Tap 0 is the sample itself: pos0 + float(0) * step_len * dir = pos0 (clouds:129 with i = 0), and get_density there is the value
+// raymarch_cloud computes for the same position one line later (clouds:217) -- the same function of the same arguments (both
+// alpha0 branches are, with CLOUDS_ALWAYS_LOW_QUALITY).  The caller passes that density in as d0 (ATMO_RM_TAP0_REUSE): five taps
+// are evaluated instead of six, and the one saved is the expensive one -- a lit sample has density > 0, so its tap 0 never takes
+// an early-out and always pays the full exact shape + coverage filters.  Bit-identical.
+#ifndef ATMO_RM_TAP0_REUSE
+#define ATMO_RM_TAP0_REUSE 1
+#endif
 template <bool PRECISE, bool LOD = false>
-__device__ __forceinline__ float light_raymarched(const RenderConsts &rc, float px, float py, float pz, float hr0,
+__device__ __forceinline__ float light_raymarched(const RenderConsts &rc, float px, float py, float pz, float hr0, float d0,
                                                   float sx, float sy, float sz, const QuadNb *nb = nullptr) {
-    float sum = 0.0f;
+    float sum = ATMO_RM_TAP0_REUSE ? __builtin_fmaf(d0, rc.rm_weight[0], 0.0f) : 0.0f;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = ATMO_RM_TAP0_REUSE ? 1 : 0; i < 6; ++i) {
         const float k = rc.rm_offset[i];  // float(i) * step_len_i, step_len_i = step0 * 1.2^i  [host]
         // exact: pos0 + (i*step)*dir, unfused
         const float qx = px + k * sx, qy = py + k * sy, qz = pz + k * sz;
@@ -1077,7 +1085,7 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
             // the light value of a zero-density sample (6 more density taps in the raymarched variant) is never observed
             if (density > 0.0f) {
 #pragma clang fp contract(fast)
-                la = RM ? light_raymarched<PRECISE, LOD>(rc, px, py, pz, hr, sx, sy, sz, LOD ? &nb : nullptr) : hr;
+                la = RM ? light_raymarched<PRECISE, LOD>(rc, px, py, pz, hr, density, sx, sy, sz, LOD ? &nb : nullptr) : hr;
                 // get_planet_shadow: smoothstep(-0.3, 0.3, dot(normalize(pos), -sun_dir))
                 const float sd = -(px * sx + py * sy + pz * sz) * hw_rcp(r);
                 const float st = sat((sd + 0.3f) * (1.0f / 0.6f));
@@ -1119,22 +1127,23 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
 //     evaluates the 6-tap light for THAT sample and multiplies it into the slot;
 //   phase C, end of the chunk: every lane adds its slots in step order.
 // Per ray the arithmetic is fixed (own slots, step order), so the picture does not depend on which rays share a wave.
-// LDS per wave: 5 x 128 queue words + 16 x 64 slots = 6.5 KB (13 KB per 2-wave workgroup).
+// LDS per wave: 6 x 128 queue words + 16 x 64 slots = 7 KB (14 KB per 2-wave workgroup).
 #ifndef ATMO_RM_QUEUE
 #define ATMO_RM_QUEUE 1
 #endif
 // With the implicit cubemap LOD an entry also carries the sample positions of the two quad partners (the light taps of a queued
 // sample difference THEIR tap positions: 6 more words) and, in bits 10-11 of the slot word, whether each partner marches.
 constexpr int RMQ_CHUNK = 16, RMQ_CAP = 128;
-constexpr int rmq_words_per_wave(bool lod) { return (lod ? 11 : 5) * RMQ_CAP + RMQ_CHUNK * 64; }
+constexpr int rmq_words_per_wave(bool lod) { return (lod ? 12 : 6) * RMQ_CAP + RMQ_CHUNK * 64; }
 
 template <bool PRECISE, bool LOD = false>
 __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, V3 dir_m, float t_begin, float t_end, float jitter,
                                                         float *__restrict__ lds, const MarchRay *nbray = nullptr) {
     float *qx = lds, *qy = lds + RMQ_CAP, *qz = lds + 2 * RMQ_CAP, *qh = lds + 3 * RMQ_CAP;
     uint32_t *qs = reinterpret_cast<uint32_t *>(lds + 4 * RMQ_CAP);
-    float *qn = lds + 5 * RMQ_CAP;  // LOD: partner positions, 6 arrays of RMQ_CAP
-    float *slot = lds + (LOD ? 11 : 5) * RMQ_CAP;
+    float *qd = lds + 5 * RMQ_CAP;  // the sample's own density = light tap 0
+    float *qn = lds + 6 * RMQ_CAP;  // LOD: partner positions, 6 arrays of RMQ_CAP
+    float *slot = lds + (LOD ? 12 : 6) * RMQ_CAP;
     const int lane = threadIdx.x & 63;
     const unsigned long long active = __builtin_amdgcn_ballot_w64(true);  // the lanes of this wave that march
     auto rank_in = [&](unsigned long long m) {
@@ -1164,7 +1173,7 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (rank < avail) {
             const int e = (qhead + rank) & (RMQ_CAP - 1);
-            const float ex = qx[e], ey = qy[e], ez = qz[e], eh = qh[e];
+            const float ex = qx[e], ey = qy[e], ez = qz[e], eh = qh[e], ed = qd[e];
             uint32_t sl = qs[e];
             QuadNb enb;
             if (LOD) {
@@ -1173,7 +1182,7 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
                 enb.py = V3{qn[3 * RMQ_CAP + e], qn[4 * RMQ_CAP + e], qn[5 * RMQ_CAP + e]};
                 sl &= 1023u;
             }
-            const float light = light_raymarched<PRECISE, LOD>(rc, ex, ey, ez, eh, sx, sy, sz, LOD ? &enb : nullptr);
+            const float light = light_raymarched<PRECISE, LOD>(rc, ex, ey, ez, eh, ed, sx, sy, sz, LOD ? &enb : nullptr);
             slot[sl] = light * slot[sl];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1204,7 +1213,7 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
             if (lit) {
                 const int e = (qcount + rank_in(lm)) & (RMQ_CAP - 1);
                 const uint32_t sl = (uint32_t)(k * 64 + lane);
-                qx[e] = px; qy[e] = py; qz[e] = pz; qh[e] = hr;
+                qx[e] = px; qy[e] = py; qz[e] = pz; qh[e] = hr; qd[e] = density;
                 if (LOD) {
                     qn[e] = nb.px.x; qn[RMQ_CAP + e] = nb.px.y; qn[2 * RMQ_CAP + e] = nb.px.z;
                     qn[3 * RMQ_CAP + e] = nb.py.x; qn[4 * RMQ_CAP + e] = nb.py.y; qn[5 * RMQ_CAP + e] = nb.py.z;
