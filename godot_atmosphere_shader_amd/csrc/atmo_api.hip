@@ -156,7 +156,6 @@ struct AtmoContext {
     float env_reach_scale = 1.0f;                      // ATMO_FB_REACH_SCALE: multiplies the predicted reach (A/B)
     unsigned moving_period = 2;                        // ATMO_FB_MOVING_PERIOD: recording period while the camera moves
     int instream = 1;                                  // ATMO_FB_INSTREAM=0: never sort on the draw stream (A/B)
-    int two_pass = 1;                                  // ATMO_TWO_PASS=0: never use the two-pass launch (A/B)
     uint32_t *measure_cost = nullptr;                  // atmo_measure_tile_costs: the next draw records here
     bool drew = false;                                 // a draw of this context has been enqueued ...
     hipStream_t last_draw_stream = nullptr;            // ... most recently on this stream (texture updates elsewhere wait)
@@ -593,7 +592,6 @@ int atmo_create(int device, int variant, int view_steps, int cloud_steps, int li
     // A/B overrides for the tools (tools/ab_feedback.sh, tools/ab_bench.sh): read here, once -- never in the launch path
     if (const char *ev = std::getenv("ATMO_LANE_SPLIT")) ctx->env_split = ev[0] == '1' ? 1 : (ev[0] == '2' ? 2 : 0);
     if (const char *ev = std::getenv("ATMO_TILE_FEEDBACK")) ctx->env_feedback = ev[0] == '1' ? 1 : 0;
-    if (const char *ev = std::getenv("ATMO_TWO_PASS")) ctx->two_pass = ev[0] == '1' ? 1 : 0;
     if (const char *ev = std::getenv("ATMO_FB_INSTREAM")) ctx->instream = ev[0] == '1' ? 1 : 0;
     if (const char *ev = std::getenv("ATMO_FB_REACH_SCALE")) ctx->env_reach_scale = (float)std::atof(ev);
     if (const char *ev = std::getenv("ATMO_FB_MOVING_PERIOD")) { const int v = std::atoi(ev); ctx->moving_period = (unsigned)(v < 1 ? 1 : v); }
@@ -1098,15 +1096,9 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     int gx = 0, gy = 0;
     atmo::render_grid(rc, split, &gx, &gy);
     rc.tiles_x = gx;
-    rc.tiles_y = gy;
-    // Two-pass launch (atmo_render_kernel_2p): the cloudless direct-light kernel's cost map is the planet's silhouette, which this
-    // frame's camera gives exactly -- no feedback needed, nothing a moving camera can invalidate.
-    rc.two_pass = (ctx->two_pass && flags == atmo::KF_LIGHT_DIRECT && split == 1 && rc.miss_k > 0.0f && !composite && !ctx->measure_cost &&
-                   (long long)gx * gy >= 512) ? 1 : 0;
     // default (-1): on for every variant since the sort no longer costs the draws anything (profiles/round2/ab_tile_feedback.txt)
     bool feedback = ctx->env_feedback >= 0 ? ctx->env_feedback != 0 : ctx->tile_feedback != 0;
     if (ctx->measure_cost) feedback = false;  // a measuring draw: plain row-major launch that records into the caller's buffer
-    if (rc.two_pass) feedback = false;        // the analytic order replaces the measured one
     if (feedback && (long long)gx * gy < 512) feedback = false;  // tiny launches: nothing to schedule
     if (feedback) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -1244,7 +1236,7 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     if (fb) fb->n += 1;
     ctx->drew = true;
     ctx->last_draw_stream = s;
-    ctx->last_split = rc.two_pass ? 3 : split;
+    ctx->last_split = split;
     ctx->launch_counter += 1;  // counted only once the launch was accepted
     if (timed) {
         HIP_TRY(ctx, hipEventRecord(ev.e1, s));

@@ -1568,49 +1568,6 @@ __global__ __launch_bounds__(TILE_W *TILE_H ATMO_MIN_WAVES_ARG) ATMO_SGPR_ATTR v
     }
 }
 
-// ---- two-pass launch: an ANALYTIC tile order for the kernels whose cost map is the planet's silhouette (round 3) ---------------
-// The tile-order feedback gives the cloudless direct-light kernel +9.7 % by dispatching the tiles that miss the planet last, into
-// the drain of the draw -- from costs measured a few frames earlier, which a panning camera invalidates (the gain drops to 0,
-// profiles/round3/ab_tile_feedback_motion.txt).  But for this kernel "cheap" needs no measurement: a wave is cheap iff every one of
-// its rays surely misses the shell, and THIS frame's camera says which (the sure-miss inequality of shade_pixel).  The grid is
-// launched twice as long: block b < N shades tile b, except that a WAVE all of whose rays are sure misses leaves
-// at once; block N + b visits tile b again and only stores the discard value for exactly those waves.  Same picture, heaviest
-// waves first, no feedback state, no lag, nothing for a moving camera to invalidate; the price is one more (immediately
-// retiring) workgroup per tile and the vote.
-template <int FLAGS, int LSTEPS>
-__global__ __launch_bounds__(TILE_W *TILE_H) void atmo_render_kernel_2p(const RenderConsts rc) {
-    const uint32_t ntiles = (uint32_t)rc.tiles_x * (uint32_t)rc.tiles_y;
-    uint32_t blk = blockIdx.y * gridDim.x + blockIdx.x;
-    const bool second = blk >= ntiles;
-    const uint32_t tile = second ? blk - ntiles : blk;
-    const uint32_t tile_y = tile / (uint32_t)rc.tiles_x, tile_x = tile - tile_y * (uint32_t)rc.tiles_x;
-    // the wave's pixels (same mapping as shade_pixel, one lane per ray)
-    const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
-    constexpr int WAVES_X = TILE_W / (WAVE_W > TILE_W ? TILE_W : WAVE_W);
-    const int px = rc.x0 + (int)tile_x * TILE_W + (wave % WAVES_X) * WAVE_W + lane % WAVE_W;
-    const int py = rc.y0 + (int)tile_y * TILE_H + (wave / WAVES_X) * WAVE_H + lane / WAVE_W;
-    const bool inside = px < rc.x1 && py < rc.y1;
-    bool sure = false;
-    {
-#pragma clang fp contract(fast)
-        const float fnx = fmaf((float)px + 0.5f, rc.rcp_vw + rc.rcp_vw, -1.0f), fny = fmaf((float)py + 0.5f, rc.rcp_vh + rc.rcp_vh, -1.0f);
-        const float *Q = rc.inv_p;
-        const float ax = fmaf(Q[0], fnx, fmaf(Q[4], fny, Q[12]));
-        const float ay = fmaf(Q[1], fnx, fmaf(Q[5], fny, Q[13]));
-        const float az = fmaf(Q[2], fnx, fmaf(Q[6], fny, Q[14]));
-        const float cv = rc.center[0] * ax + rc.center[1] * ay + rc.center[2] * az;
-        const float vv = ax * ax + ay * ay + az * az;
-        sure = cv * cv < rc.miss_k * vv;   // rc.miss_k > 0 is the host's condition for launching this kernel
-    }
-    const bool wave_is_cheap = __builtin_amdgcn_ballot_w64(inside && !sure) == 0ull;
-    if (!second) {
-        if (wave_is_cheap) return;
-        shade_pixel<FLAGS, LSTEPS, 1>(rc, (int)tile_x, (int)tile_y);
-    } else if (wave_is_cheap && inside) {
-        rc.out[(size_t)(py - rc.out_y0) * (size_t)rc.out_pitch + (px - rc.out_x0)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-}
-
 // Stable counting sort of the tiles by the cost a recording draw measured, heaviest class first; clears the costs for
 // the next recording.  32 classes = half octaves of the wave duration (2^8 .. 2^24 cycles); tiles of one class keep their
 // row-major order, so neighbouring tiles -- which share texture footprints in L1/L2 -- still run together.
@@ -2017,15 +1974,7 @@ static hipError_t launch_direct(const RenderConsts &rc, int split, hipStream_t s
     return rc.light_steps == 8 ? launch_t<FLAGS, 8>(rc, split, stream) : launch_t<FLAGS, 0>(rc, split, stream);
 }
 
-template <int FLAGS, int LSTEPS>
-static hipError_t launch_2p(const RenderConsts &rc, hipStream_t stream) {
-    hipLaunchKernelGGL((atmo_render_kernel_2p<FLAGS, LSTEPS>), dim3(rc.tiles_x, 2 * rc.tiles_y), dim3(TILE_W * TILE_H), 0, stream, rc);
-    return hipGetLastError();
-}
-
 hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream_t stream) {
-    if (rc.two_pass && flags == KF_LIGHT_DIRECT && split != 2)
-        return rc.light_steps == 8 ? launch_2p<KF_LIGHT_DIRECT, 8>(rc, stream) : launch_2p<KF_LIGHT_DIRECT, 0>(rc, stream);
     switch (flags) {
     case 0: return launch_t<0, 0>(rc, split, stream);
     case KF_LIGHT_DIRECT: return launch_direct<KF_LIGHT_DIRECT>(rc, split, stream);
@@ -2062,10 +2011,6 @@ const char *render_kernel_name(int flags, int light_steps, int split) {
     // demangled template name as rocprofv3 prints it: atmo_render_kernel<FLAGS, LSTEPS, SPLIT>
     static thread_local char name[64];
     const int lsteps = ((flags & KF_LIGHT_DIRECT) && light_steps == 8) ? 8 : 0;
-    if (split == 3) {  // the two-pass launch (atmo_render_kernel_2p)
-        snprintf(name, sizeof(name), "atmo_render_kernel_2p<%d, %d>", flags, lsteps);
-        return name;
-    }
     snprintf(name, sizeof(name), "atmo_render_kernel<%d, %d, %d>", flags, lsteps, split == 2 ? 2 : 1);
     return name;
 }
