@@ -26,7 +26,7 @@ CORE_SYMBOLS = (
 )
 # every symbol include/atmo_debug.h declares: experiment knobs and diagnostics (tests, bench.py, tools/)
 DEBUG_SYMBOLS = (
-    "atmo_set_lane_split", "atmo_get_feedback_stats", "atmo_set_timing", "atmo_get_timing", "atmo_host_layout_cubemap", "atmo_host_layout_shape",
+    "atmo_set_lane_split", "atmo_debug_motion_px", "atmo_get_feedback_stats", "atmo_set_timing", "atmo_get_timing", "atmo_host_layout_cubemap", "atmo_host_layout_shape",
     "atmo_host_layout_lut", "atmo_host_cubemap_mip", "atmo_read_texture_layout", "atmo_selftest_exact_math", "atmo_debug_marched_optical_depth", "atmo_kernel_name",
 )
 EXPORTED_SYMBOLS = CORE_SYMBOLS + DEBUG_SYMBOLS
@@ -97,6 +97,7 @@ def load() -> C.CDLL:
         "atmo_set_host_double_precision": (ip, [vp, ip]),
         "atmo_set_lane_split": (ip, [vp, ip]),
         "atmo_set_tile_feedback": (ip, [vp, ip]),
+        "atmo_debug_motion_px": (C.c_float, [C.POINTER(AtmoFrame), C.POINTER(AtmoFrame), C.c_float, ip]),
         "atmo_get_feedback_stats": (ip, [vp, C.POINTER(ip), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
         "atmo_set_timing": (ip, [vp, ip]),
         "atmo_get_timing": (ip, [vp, C.POINTER(ip), C.POINTER(C.c_double)]),

@@ -1287,6 +1287,11 @@ int atmo_set_tile_feedback(AtmoContext *ctx, int mode) {
     return ATMO_OK;
 }
 
+float atmo_debug_motion_px(const AtmoFrame *a, const AtmoFrame *b, float radius, int surface_points) {
+    if (!a || !b) return -1.0f;
+    return feedback_motion_px(*a, *b, radius, surface_points != 0);
+}
+
 int atmo_get_feedback_stats(AtmoContext *ctx, int *states, unsigned *ordered_draws, unsigned *sorts, unsigned *recycled) {
     if (!ctx) return ATMO_E_ARG;
     int n = 0;

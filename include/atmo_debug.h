@@ -27,6 +27,11 @@ int atmo_set_lane_split(AtmoContext *ctx, int lanes_per_ray);
  * stream, at most 4), draws so far that were dispatched in a sorted order, sorts enqueued, states recycled for another key. */
 int atmo_get_feedback_stats(AtmoContext *ctx, int *states, unsigned *ordered_draws, unsigned *sorts, unsigned *recycled);
 
+/* The host-side motion estimate behind the tile-order feedback (no device, no context): how many pixels the picture's cost
+ * features move between two frames -- the planet's silhouette (centre and four limb points along the camera's axes), plus, with
+ * surface_points != 0, six points fixed on the planet (the cloud pattern).  radius = u_planet_radius + u_atmosphere_height. */
+float atmo_debug_motion_px(const AtmoFrame *a, const AtmoFrame *b, float radius, int surface_points);
+
 /* Device time of `atmo_render` kernels measured with HIP events recorded around the launch on its own stream:
  * atmo_set_timing(ctx, k): k = 0 off, k >= 1 brackets every k-th launch (k > 1 keeps the ~5 us cost of recording two
  * events out of most steps); atmo_get_timing returns the number of bracketed launches and their total milliseconds

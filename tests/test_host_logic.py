@@ -305,3 +305,36 @@ def test_pixel_coordinate_division_is_exact(tmp_path):
         res = (a.astype(f64) - q0.astype(f64) * f64(c)).astype(f32)
         q1 = (q0.astype(f64) + res.astype(f64) * f64(r)).astype(f32)  # float64 sum, then one float32 rounding
         assert np.array_equal(q1, a / c), n
+
+
+def test_feedback_motion_estimate_matches_the_camera_motion():
+    """The tile-order feedback predicts, from the matrices of consecutive frames, how far the picture's cost features move
+    (atmo_api.hip feedback_motion_px; host arithmetic, no device): a pan of 1 degree moves everything by focal * 1 degree =
+    12.3 px at 1920x1080 / 75 degrees; an orbit around the planet leaves the SILHOUETTE where it is (what a cloudless kernel's
+    cost map is) but moves points fixed on the planet (the cloud pattern); a still camera moves nothing."""
+    import bench
+    from godot_atmosphere_shader_amd import _native as N
+    from godot_atmosphere_shader_amd import scene as S
+    from godot_atmosphere_shader_amd.planet_atmosphere import _to_native_frame, make_frame
+
+    lib = N.load()
+    w, h = 1920, 1080
+
+    def frames(motion):
+        cams = bench.motion_cameras(S, w, h, motion, 3)
+        return [_to_native_frame(make_frame(c, np.eye(4), S.DEMO_SUN_POSITION, 0.0)) for c in cams]
+
+    def px(a, b, surface):
+        return lib.atmo_debug_motion_px(C.byref(a), C.byref(b), 108.0, surface)
+
+    focal = 0.5 * h / np.tan(np.radians(37.5))
+    f = frames(("pan", 1.0))
+    assert abs(px(f[1], f[0], 0) - focal * np.radians(1.0)) < 0.15 * focal * np.radians(1.0) + 1.0   # larger off-axis: sec^2
+    assert px(f[1], f[0], 0) >= focal * np.radians(1.0) * 0.99
+    assert px(f[0], f[0], 1) == 0.0
+    f = frames(("orbit", 1.0))
+    assert px(f[1], f[0], 0) < 0.05                       # the disc stays where it is
+    surf = px(f[1], f[0], 1)
+    assert 15.0 < surf < 50.0                              # the sub-camera point moves R * 1 degree at 50 units' distance: ~ 26 px
+    f = frames(("orbit", 0.0))
+    assert px(f[1], f[0], 1) == 0.0
