@@ -1612,10 +1612,10 @@ __global__ __launch_bounds__(64) void atmo_tile_hist_kernel(const uint32_t *__re
         if (valid && lanes_below(m) == 0) cnt[c] += (uint32_t)__builtin_popcountll(m);  // one lane per class present
     }
     __syncthreads();
-    if (lane < ORDER_CLASSES) hist[blockIdx.x * ORDER_CLASSES + lane] = cnt[lane];
+    if (lane < ORDER_CLASSES) hist[lane * ORDER_BLOCKS + blockIdx.x] = cnt[lane];   // [class][block]: the scan reads a class's row contiguously
 }
 
-// hist[block][class] -> first output index of (block, class): classes in order 0 (heaviest) .. 31, blocks in order inside a class
+// hist[class][block] -> first output index of (block, class): classes in order 0 (heaviest) .. 31, blocks in order inside a class
 __global__ __launch_bounds__(256) void atmo_tile_scan_kernel(uint32_t *__restrict__ hist) {
     __shared__ uint32_t total[ORDER_CLASSES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1628,7 +1628,7 @@ __global__ __launch_bounds__(256) void atmo_tile_scan_kernel(uint32_t *__restric
 #pragma unroll
         for (int k = 0; k < PER_LANE; ++k) {
             excl_keep[q][k] = sum;
-            sum += hist[(lane * PER_LANE + k) * ORDER_CLASSES + c];
+            sum += hist[c * ORDER_BLOCKS + lane * PER_LANE + k];
         }
         uint32_t incl = sum;
 #pragma unroll
@@ -1656,7 +1656,7 @@ __global__ __launch_bounds__(256) void atmo_tile_scan_kernel(uint32_t *__restric
     for (int q = 0; q < PER_WAVE; ++q) {
         const int c = wave * PER_WAVE + q;
 #pragma unroll
-        for (int k = 0; k < PER_LANE; ++k) hist[(lane * PER_LANE + k) * ORDER_CLASSES + c] = total[c] + excl_keep[q][k];
+        for (int k = 0; k < PER_LANE; ++k) hist[c * ORDER_BLOCKS + lane * PER_LANE + k] = total[c] + excl_keep[q][k];
     }
 }
 
@@ -1665,7 +1665,7 @@ __global__ __launch_bounds__(64) void atmo_tile_scatter_kernel(const uint32_t *k
     __shared__ uint32_t off[ORDER_CLASSES];
     const int lane = threadIdx.x, chunk = (n + ORDER_BLOCKS - 1) / ORDER_BLOCKS;
     const int i0 = min((int)blockIdx.x * chunk, n), i1 = min(i0 + chunk, n);
-    if (lane < ORDER_CLASSES) off[lane] = base[blockIdx.x * ORDER_CLASSES + lane];
+    if (lane < ORDER_CLASSES) off[lane] = base[lane * ORDER_BLOCKS + blockIdx.x];
     __syncthreads();
     for (int i = i0; i < i1; i += 64) {
         const bool valid = i + lane < i1;
@@ -1714,7 +1714,10 @@ hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int tiles_x, int t
                              uint32_t *scratch, hipStream_t stream) {
     const int n = tiles_x * tiles_y;
     const uint32_t *key = cost;
-    if (rx > 0 || ry > 0) {  // separable: rows, then columns
+    if ((rx > 0 || ry > 0) && (2 * rx + 1) * (2 * ry + 1) <= 81) {  // a small window (the in-stream sort's: a tile or two): one pass
+        hipLaunchKernelGGL(atmo_tile_dilate_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cost, tmp2, tiles_x, tiles_y, rx, ry);
+        key = tmp2;
+    } else if (rx > 0 || ry > 0) {  // separable: rows, then columns
         hipLaunchKernelGGL(atmo_tile_dilate_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cost, tmp1, tiles_x, tiles_y, rx, 0);
         hipLaunchKernelGGL(atmo_tile_dilate_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, tmp1, tmp2, tiles_x, tiles_y, 0, ry);
         key = tmp2;
