@@ -556,6 +556,49 @@ def test_render_on_a_side_stream_is_ordered():
     node.close()
 
 
+def test_texture_updates_on_different_streams_take_effect_in_call_order():
+    """a LUT baked on stream A followed by another texture set on stream B, then a draw on B -- the draw used to see
+    `tex_stream == B` and skip the wait for A's bake.  Updates are now chained in call order (a later update waits for the earlier
+    one's event), and an update arriving on a stream other than the one the context last drew on waits for those draws first.
+    Every iteration changes BOTH textures (a new u_density re-bakes the LUT on A behind a long kernel; a new jitter table on B)."""
+    from godot_atmosphere_shader_amd import _native as N
+
+    tex = demo_textures(cube_n=64, shape_n=32)
+    cam = S.Camera.from_pose(640, 360, "P_space")
+    depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
+    variants = [(0.5, S.make_blue_noise(1)), (0.3, S.make_blue_noise(5))]
+    want = []
+    for dens, bn in variants:
+        r = make_node("clouds_high", dict(tex, blue_noise=bn), demo_params(u_density=dens))
+        want.append(r.render(cam, depth).clone())
+        r.close()
+    assert not torch.equal(want[0], want[1])
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    node = make_node("clouds_high", tex, demo_params())
+    node.render(cam, depth)
+    torch.cuda.synchronize()
+    lib, ctx = node._lib, node._ctx
+    for it in range(6):
+        dens, bn = variants[(it + 1) % 2]
+        with torch.cuda.stream(a):   # a long kernel in front of the bake, so the bake is still pending when B's update is enqueued
+            junk = torch.randn(4096, 4096, device="cuda") @ torch.randn(4096, 4096, device="cuda")
+        v = (C.c_float * 1)(dens)
+        assert lib.atmo_set_param_f32(ctx, b"u_density", v, 1) == N.ATMO_OK
+        assert lib.atmo_bake_optical_depth(ctx, C.c_void_p(a.cuda_stream)) == N.ATMO_OK
+        bn = np.ascontiguousarray(bn)
+        assert lib.atmo_set_texture(ctx, b"u_blue_noise_texture", N.TEX_2D_R8, 256, 256, 1, 1, bn.ctypes.data_as(C.c_void_p), N.MEM_HOST,
+                                    C.c_void_p(b.cuda_stream)) == N.ATMO_OK
+        out = torch.empty_like(want[0])
+        frame = node.prepare_frame(cam)
+        assert lib.atmo_render(ctx, C.byref(frame), C.c_void_p(depth.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(b.cuda_stream)) == N.ATMO_OK
+        b.synchronize()
+        assert torch.equal(out, want[(it + 1) % 2]), it
+        del junk
+    torch.cuda.synchronize()
+    node.close()
+
+
 def test_render_is_hip_graph_capturable():
     """atmo_render does no allocation or synchronisation when timing is off, so a render loop can be captured into a
     HIP graph and replayed (MI355X_MICROARCH.md 'graph-capture restrictions')."""
@@ -1039,10 +1082,11 @@ def test_measured_row_costs_follow_the_work():
 
     tex, params = demo_textures(), demo_params()
     w, h = 1280, 720
-    cam = S.Camera.from_pose(w, h, "P_space")
+    cam = S.Camera.from_pose(w, h, dict(eye=(0.0, 0.0, 330.0), target=(0.0, 0.0, 0.0)))   # the disc fills the middle third of the rows
     depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
     node = make_node("clouds_high_rm", tex, params)
     want = node.render(cam, depth).clone()
+    assert float(want[:8].abs().sum()) == 0.0 and float(want[h // 2].abs().sum()) > 0.0   # sky at the top, planet in the middle
     for _ in range(3):
         rows = node.measure_row_costs(cam, depth)
     assert rows.shape == (h,) and np.all(rows > 0)
