@@ -249,6 +249,40 @@ def main_round3():
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def main_fuzz_lod():
+    """tests/golden/reference_exec_fuzz_lod.npz: the random scenes of reference_exec_fuzz.npz that have a cubemap and a cloud variant,
+    executed again with the declared linear-mipmap cubemap sampler (implicit LOD): other planet scales, cube sizes 17 .. 128 (17 is
+    not a power of two: the kernels' general LOD path), moved and rotated planets, cameras inside the layer."""
+    import json
+
+    t0 = time.time()
+    fz = np.load(os.path.join(HERE, "reference_exec_fuzz.npz"))
+    out = {}
+    for k in range(RS.FUZZ_SEEDS):
+        tex = RS.fuzz_textures(k)
+        shaders = [sh for sh in RS.fuzz_variants(k) if VARIANTS[sh].get("cloud_steps")]
+        if tex["cubemap"] is None or not shaders:
+            continue
+        shader = shaders[0]
+        params = {kk: (tuple(v) if isinstance(v, list) else v) for kk, v in json.loads(str(fz[f"params_{k}"])).items()}
+        _, cam_args, sun, model, _ = RS.random_scene(k)
+        cam = S.Camera(RS.FUZZ_W, RS.FUZZ_H, **cam_args)
+        m = fz[f"cam_{k}"]
+        cam.inv_projection, cam.inv_view, cam.view = m[0].copy(), m[1].copy(), m[2].copy()
+        lut, _ = run_bake({kk: params[kk] for kk in ("u_planet_radius", "u_atmosphere_height", "u_density")})
+        units = dict(u_optical_depth_texture=T.LutTexture(lut), u_blue_noise_texture=T.ByteTexture2D(tex["blue_noise"]),
+                     u_cloud_shape_texture=T.ShapeTexture(tex["shape"]))
+        rgba, disc, _, _ = run_frame(shader, None, params, np.linalg.inv(model), model, cam, fz[f"depth_{k}"], units, sun=sun,
+                                     cube_chain=T.mip_chain(tex["cubemap"]))
+        out[f"rgba_{k}_{shader}"] = rgba
+        d0 = float(np.nanmax(np.abs(rgba - fz[f"rgba_{k}_{shader}"])))
+        print(f"{time.time() - t0:6.1f}s seed {k} {shader} (cube {tex['cubemap'].shape[1]}): {int((~disc).sum())} kept, max |LOD - LOD0| = {d0:.3e}", flush=True)
+    out["cases"] = np.array(sorted(out))
+    path = os.path.join(HERE, "reference_exec_fuzz_lod.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 class UnsetCube:
     """An unbound samplerCube: the engine's default white texture (README.md:46 "cover uniformly")."""
 
@@ -290,10 +324,14 @@ def main_fuzz():
 
 
 if __name__ == "__main__":
-    if "--round3-only" in sys.argv:
+    if "--fuzz-lod-only" in sys.argv:
+        main_fuzz_lod()
+    elif "--round3-only" in sys.argv:
         main_round3()
+        main_fuzz_lod()
     else:
         if "--fuzz-only" not in sys.argv:
             main()
             main_round3()
         main_fuzz()
+        main_fuzz_lod()

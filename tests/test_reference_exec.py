@@ -330,6 +330,34 @@ def test_oracle_equals_reference_random_scenes(oracle32, fuzz, k):
         assert err <= ORACLE_TOL, f"seed {k} {shader}: oracle vs executed reference {err:.3e}"
 
 
+@pytest.fixture(scope="module")
+def fuzz_lod():
+    return np.load(os.path.join(GOLDEN, "reference_exec_fuzz_lod.npz"))
+
+
+def _fuzz_lod_cases(z):
+    return [(int(c.split("_")[1]), c[len("rgba_") + len(c.split("_")[1]) + 1:]) for c in z["cases"] if str(c).startswith("rgba_")]
+
+
+def test_oracle_equals_reference_random_scenes_with_the_declared_sampler(oracle32, fuzz, fuzz_lod):
+    """The random scenes that have a cubemap and a cloud variant, executed again from the reference text with the linear-mipmap
+    samplerCube it declares: planets R = 1 ... 637, cube sizes 17 (not a power of two) ... 128, moved and rotated planets, cameras
+    inside the cloud layer.  20 frames; the oracle's implicit-LOD rule (partners' rays recomputed per pixel) against the
+    interpreter's (differences between the lanes of a pixel quad)."""
+    cases = _fuzz_lod_cases(fuzz_lod)
+    assert len(cases) >= 18
+    for k, shader in cases:
+        params, cam, sun, model, tex, depth = _fuzz_case(fuzz, k)
+        lut = oracle32.bake_optical_depth(params["u_planet_radius"], params["u_atmosphere_height"], params["u_density"])
+        frame = make_frame(cam, model, sun, 0.0)
+        cfg = dict(RS.VARIANTS[shader], cube_lod=1)
+        got, _ = oracle32.render(params, dict(tex, cubemap=oracle32.cubemap_mip_chain(tex["cubemap"]), optical_depth=lut), cfg, frame, depth, nthreads=4)
+        want = fuzz_lod[f"rgba_{k}_{shader}"]
+        assert np.array_equal(np.all(got == 0.0, axis=-1), np.all(want == 0.0, axis=-1))
+        err = _rel_err(got, want)
+        assert err <= ORACLE_TOL, f"seed {k} {shader}: oracle (implicit LOD) vs executed reference {err:.3e}"
+
+
 # ------------------------------------------------------------------------------------------------ the interpreter's own tests
 def _run(tmp_path, text, lanes, inputs, entry="main", uniforms=None):
     path = tmp_path / "t.gdshader"
@@ -645,3 +673,36 @@ def test_hip_equals_reference_at_32_and_64_view_steps(vectors, r3, textures, ste
     worst = max(worst, float(np.abs(got - r3[f"steps{steps}_rgba_full"]).max()))
     print(f"no_clouds, {steps} view steps: HIP vs executed reference {worst:.3e}")
     assert worst <= TOL
+
+
+@pytest.mark.gpu
+def test_hip_equals_reference_random_scenes_with_the_declared_sampler(fuzz, fuzz_lod):
+    """atmo_set_sampler_lod(ctx, 1) on the random scenes: power-of-two cubemaps take the fast LOD path, the 17-texel ones the
+    general path; both against the reference text executed with the declared sampler."""
+    from godot_atmosphere_shader_amd import PlanetAtmosphere, load_shader
+    from godot_atmosphere_shader_amd.planet_atmosphere import LinearColor, _SOURCE_COLOR
+
+    worst = 0.0
+    for k, shader in _fuzz_lod_cases(fuzz_lod):
+        params, cam, sun, model, tex, depth = _fuzz_case(fuzz, k)
+        node = PlanetAtmosphere(blue_noise=tex["blue_noise"], cubemap_lod=True)
+        node.custom_shader = load_shader(shader)
+        node.planet_radius, node.atmosphere_height, node.sun_path = params["u_planet_radius"], params["u_atmosphere_height"], sun
+        for name, v in params.items():
+            if name in ("u_planet_radius", "u_atmosphere_height", "u_cloud_coverage_rotation", "u_world_to_model_matrix"):
+                continue
+            node.set(f"shader_params/{name}", LinearColor(v) if name in _SOURCE_COLOR else v)
+        node.global_transform = model
+        node._process(0.0, cam, time=0.0)
+        node.set_shader_parameter("u_cloud_coverage_rotation", np.asarray(params["u_cloud_coverage_rotation"], dtype=np.float32))
+        node.set_shader_parameter("u_cloud_shape_texture", tex["shape"])
+        node.set_shader_parameter("u_cloud_coverage_cubemap", tex["cubemap"])
+        got = _gpu_render(node, cam, depth)
+        assert int(node.kernel_name.split("<")[1].split(",")[0]) & 32
+        node.close()
+        want = fuzz_lod[f"rgba_{k}_{shader}"]
+        assert np.array_equal(np.all(got == 0.0, axis=-1), np.all(want == 0.0, axis=-1)), f"seed {k} {shader}: discard sets differ"
+        err = _rel_err(got, want)
+        worst = max(worst, err)
+        assert err <= TOL, f"seed {k} {shader}: HIP (implicit LOD) vs executed reference {err:.3e}"
+    print(f"random scenes, declared sampler: worst HIP vs executed reference {worst:.3e}")
