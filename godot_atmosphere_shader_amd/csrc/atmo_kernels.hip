@@ -1127,13 +1127,20 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
 //     evaluates the 6-tap light for THAT sample and multiplies it into the slot;
 //   phase C, end of the chunk: every lane adds its slots in step order.
 // Per ray the arithmetic is fixed (own slots, step order), so the picture does not depend on which rays share a wave.
-// LDS per wave: 6 x 128 queue words + 16 x 64 slots = 7 KB (14 KB per 2-wave workgroup).
+// LDS per wave: 6 x 128 queue words + 8 x 64 slots = 5 KB (10 KB per 2-wave workgroup).
 #ifndef ATMO_RM_QUEUE
 #define ATMO_RM_QUEUE 1
 #endif
 // With the implicit cubemap LOD an entry also carries the sample positions of the two quad partners (the light taps of a queued
 // sample difference THEIR tap positions: 6 more words) and, in bits 10-11 of the slot word, whether each partner marches.
-constexpr int RMQ_CHUNK = 16, RMQ_CAP = 128;
+// Steps per chunk of the lit-sample queue = rows of the per-lane slot array in LDS.  8 (round 3; was 16): 5 KB instead of 7 KB per wave,
+// i.e. LDS no longer caps the raymarched-light kernel at 5.5 waves per SIMD -- together with __launch_bounds__(128, 6) (80 instead of
+// 84 VGPRs, one spilled dword) it runs 6 waves per SIMD: -6.9 % at 1920x1080, -5.2 % at 3840x2160 (profiles/round3/ab_occupancy.txt;
+// either change alone: -1.5 % / +-0.4 %).
+#ifndef ATMO_RMQ_CHUNK
+#define ATMO_RMQ_CHUNK 8
+#endif
+constexpr int RMQ_CHUNK = ATMO_RMQ_CHUNK, RMQ_CAP = 128;
 constexpr int rmq_words_per_wave(bool lod) { return (lod ? 12 : 6) * RMQ_CAP + RMQ_CHUNK * 64; }
 
 template <bool PRECISE, bool LOD = false>
@@ -1523,7 +1530,10 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
 // SGPR cap: 256-thread workgroups are admitted 8 per CU only up to 80 SGPRs (81-96 => 7, although the occupancy API and
 // the compiler's "Occupancy" line still say 8: MI355X_MICROARCH.md "Residency").  The atmosphere-only kernels sat at 82
 // after RenderConsts grew, which cost the direct-light kernel 7 %; the cap makes hipcc keep a few uniforms in VGPRs instead.
-#ifdef ATMO_MIN_WAVES  // __launch_bounds__ second argument: minimum waves per SIMD the register allocation must allow
+#ifndef ATMO_MIN_WAVES  // __launch_bounds__ second argument: minimum waves per SIMD the register allocation must allow (0 = none).
+#define ATMO_MIN_WAVES 6  // 6: only atmo_render_kernel<19 / 23, ..> change (84 -> 80 VGPRs); see ATMO_RMQ_CHUNK
+#endif
+#if ATMO_MIN_WAVES > 0
 #define ATMO_MIN_WAVES_ARG , ATMO_MIN_WAVES
 #else
 #define ATMO_MIN_WAVES_ARG
