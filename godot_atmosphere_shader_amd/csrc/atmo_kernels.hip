@@ -1536,8 +1536,11 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
 #ifndef ATMO_MIN_WAVES_LOD_RM  // the declared-sampler form of that kernel stays at its natural 111 VGPRs = 4 waves: bound 5 (96 VGPRs,
 #define ATMO_MIN_WAVES_LOD_RM 4  // 13 spilled dwords) measured +3 % slower at both sizes (profiles/round3/ab_occupancy.txt)
 #endif
+#ifndef ATMO_MIN_WAVES_LOD
+#define ATMO_MIN_WAVES_LOD ATMO_MIN_WAVES
+#endif
 constexpr int render_min_waves(int flags) {
-    return ((flags & KF_CUBE_LOD) && (flags & KF_CLOUD_LIGHT_RM)) ? ATMO_MIN_WAVES_LOD_RM : ATMO_MIN_WAVES;
+    return (flags & KF_CUBE_LOD) ? ((flags & KF_CLOUD_LIGHT_RM) ? ATMO_MIN_WAVES_LOD_RM : ATMO_MIN_WAVES_LOD) : ATMO_MIN_WAVES;
 }
 #if ATMO_MIN_WAVES > 0
 #define ATMO_MIN_WAVES_ARG , render_min_waves(FLAGS)
