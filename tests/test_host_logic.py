@@ -338,3 +338,27 @@ def test_feedback_motion_estimate_matches_the_camera_motion():
     assert 15.0 < surf < 50.0                              # the sub-camera point moves R * 1 degree at 50 units' distance: ~ 26 px
     f = frames(("orbit", 0.0))
     assert px(f[1], f[0], 1) == 0.0
+
+
+def test_bench_motion_helpers():
+    """bench.py --motion: pose sequences are continuous (no jump when replayed ping-pong), a pan stays inside +-25 degrees and advances
+    by the requested angle per frame, an orbit keeps its distance; the workload string names the cubemap sampler for cloud workloads only."""
+    import bench
+    from godot_atmosphere_shader_amd import scene as S
+
+    assert bench.parse_motion("") is None and bench.parse_motion("static") is None
+    assert bench.parse_motion("orbit:0.5") == ("orbit", 0.5) and bench.parse_motion("pan:5") == ("pan", 5.0)
+    with pytest.raises(SystemExit):
+        bench.parse_motion("spin:1")
+    assert [bench.pingpong(i, 4) for i in range(9)] == [0, 1, 2, 3, 2, 1, 0, 1, 2] and bench.pingpong(5, 1) == 0
+    cams = bench.motion_cameras(S, 192, 108, ("pan", 5.0), 24)
+    yaw = [np.degrees(np.arctan2(c.inv_view[0, 2], c.inv_view[2, 2])) for c in cams]
+    assert max(abs(y) for y in yaw) <= 25.0 + 1e-6
+    steps = np.abs(np.diff(yaw))
+    assert np.all(steps <= 5.0 + 1e-6) and np.median(steps) > 4.99                     # 5 degrees per frame except at the turning points
+    assert all(np.allclose(c.inv_view[:3, 3], cams[0].inv_view[:3, 3]) for c in cams)  # the eye stays where it is
+    cams = bench.motion_cameras(S, 192, 108, ("orbit", 1.0), 8)
+    r = [np.hypot(c.inv_view[0, 3], c.inv_view[2, 3]) for c in cams]
+    assert np.allclose(r, r[0]) and not np.allclose(cams[1].inv_view[:3, 3], cams[0].inv_view[:3, 3])
+    assert bench.workload_suffix("no_clouds_32x8_direct", None) == "" and bench.workload_suffix("no_clouds_8", "lod") == ""
+    assert "LOD 0" in bench.workload_suffix("clouds_high", None) and "linear-mipmap" in bench.workload_suffix("clouds_high_rm", "lod")
