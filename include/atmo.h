@@ -233,6 +233,11 @@ int atmo_set_host_double_precision(AtmoContext *ctx, int enable);
  * the first launch of its key; a fifth key recycles the least recently used state (which waits for that state's work),
  * and a context that keeps producing new keys runs out of recycling budget (8, one regained every 256 draws) and draws
  * those keys in row-major order while the resident states keep working.
+ * A state follows the camera: it compares the matrices of consecutive draws of its key, dilates the measured cost map by the
+ * distance the picture moves while an order is in use, records more often (the raymarched-cloud-light kernels sort on the
+ * draw stream itself, one frame of lag), and falls back to the row-major launch when the picture moves faster than a cost
+ * map stays meaningful -- so two different views alternating on ONE (grid, stream) key (stereo eyes) look like a fast camera
+ * and get no reordering: give each eye its own stream or context.
  */
 int atmo_set_tile_feedback(AtmoContext *ctx, int mode);
 
