@@ -522,6 +522,23 @@ def timed_loop_distributed(torch, dist, render_into, h, w, device, steps, warmup
     return float(tmax.item()), launches, kernel_ms
 
 
+def cut_bands_measured(torch, dist, device, world, rank, measure, repeats=3):
+    """Row bands of equal MEASURED cost for `world` ranks: rank 0 calls `measure()` (per-row costs of the whole frame,
+    PlanetAtmosphere.measure_row_costs; the last of `repeats` measurements counts: clocks and caches warm), cuts, and broadcasts the cuts
+    -- every rank must use the same cuts, and measured costs differ from GPU to GPU."""
+    from godot_atmosphere_shader_amd.sharding import balanced_row_bands
+
+    cuts = torch.zeros(world + 1, dtype=torch.int64, device=device)
+    if rank == 0:
+        for _ in range(repeats):
+            row_cost = measure()
+        b = balanced_row_bands(row_cost, world)
+        cuts.copy_(torch.tensor([b[0][0]] + [x[1] for x in b], dtype=torch.int64))
+    dist.broadcast(cuts, src=0)
+    c = [int(v) for v in cuts.tolist()]
+    return [(c[k], c[k + 1]) for k in range(world)]
+
+
 def cloud_row_cost(np, S, cam, cloudy):
     """Per-row cost estimate for band balancing: pixels whose ray hits the atmosphere shell count 1; for the cloud
     variants a pixel whose ray also crosses the cloud shell (between the ground sphere and the cloud-top sphere: the
@@ -720,15 +737,7 @@ def main():
             # analytic (--band-cost analytic): shell hits per row, cloud-shell hits weighted (cloud_row_cost).
             from godot_atmosphere_shader_amd.sharding import balanced_row_bands, band_rect
             if args.band_cost == "measured":
-                cuts = torch.zeros(world + 1, dtype=torch.int64, device=device)
-                if rank == 0:
-                    for _ in range(3):  # clocks and caches warm; the last measurement counts
-                        row_cost = node.measure_row_costs(cam, depth)
-                    b = balanced_row_bands(row_cost, world)
-                    cuts.copy_(torch.tensor([b[0][0]] + [x[1] for x in b], dtype=torch.int64))
-                dist.broadcast(cuts, src=0)
-                c = [int(v) for v in cuts.tolist()]
-                bands = [(c[k], c[k + 1]) for k in range(world)]
+                bands = cut_bands_measured(torch, dist, device, world, rank, lambda: node.measure_row_costs(cam, depth))
             else:
                 bands = balanced_row_bands(cloud_row_cost(np, S, cam, "cloud" in config_name), world)
             frame = node.prepare_frame(cam, rect=band_rect(w, bands[rank]))

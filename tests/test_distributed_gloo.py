@@ -255,6 +255,43 @@ def test_bench_distributed_timed_loop_world_size_8_config4_shape(tmp_path):
         assert (tmp_path / f"ok8_{r}").exists()
 
 
+def _bands_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+
+        calls = {"n": 0}
+
+        def measure():   # only rank 0 may be asked; other ranks would produce other numbers (measured costs differ per GPU)
+            assert rank == 0
+            calls["n"] += 1
+            rows = np.full(100, 1.0)
+            rows[60:80] = 10.0 * calls["n"]   # the last measurement counts
+            return rows
+
+        bands = bench.cut_bands_measured(torch, dist, torch.device("cpu"), world, rank, measure)
+        assert calls["n"] == (3 if rank == 0 else 0)
+        rows = np.full(100, 1.0)
+        rows[60:80] = 30.0
+        from godot_atmosphere_shader_amd.sharding import balanced_row_bands
+        assert bands == balanced_row_bands(rows, world)          # every rank holds rank 0's cuts
+        assert bands[0][0] == 0 and bands[-1][1] == 100
+        with open(os.path.join(tmpdir, f"okb_{rank}"), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_measured_band_cuts_are_made_on_rank_0_and_broadcast(tmp_path):
+    world = 3
+    port = _free_port()
+    mp.spawn(_bands_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert (tmp_path / f"okb_{r}").exists()
+
+
 def test_measured_row_costs_cut_bands_of_equal_work():
     """bench.py --shard bands --band-cost measured: per-row sums of measured tile costs (atmo_measure_tile_costs) cut the frame;
     here with a synthetic cost map shaped like a cloud frame (a heavy blob off-centre on a cheap background)."""

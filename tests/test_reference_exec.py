@@ -461,6 +461,67 @@ def test_vm_preprocessor(tmp_path):
     assert m.globals["OUT"].a[0] == 6.0
 
 
+def test_vm_force_defines_win_over_the_files_own_defines(tmp_path):
+    """`force_defines` (how a step count other than the shipped one is run through the reference text unchanged): the forced macro
+    wins over an in-file #define of the same name; a plain predefined macro is replaced by it, as in C."""
+    path = tmp_path / "t.gdshader"
+    path.write_text("#define STEPS 8\nvoid main() { float s = 0.0; for (int i = 0; i < STEPS; ++i) { s += 1.0; } OUT = s; }\n")
+    for kw, want in ((dict(), 8.0), (dict(defines={"STEPS": 5}), 8.0), (dict(force_defines={"STEPS": 32}), 32.0)):
+        m = VM.Machine(VM.load(str(path), **kw), 1, {}, {})
+        m.globals["OUT"] = m.from_host("float", [0])
+        m.run("main")
+        assert m.globals["OUT"].a[0] == want, kw
+
+
+class _RecordingQuadSampler:
+    """A samplerCube unit that records what the interpreter hands an implicit-LOD texture unit."""
+    needs_quad = True
+
+    def __init__(self):
+        self.calls = []
+
+    def texture_quad(self, coords, reach):
+        self.calls.append((coords.copy(), reach.copy()))
+        return coords[0]
+
+
+def test_vm_quad_derivative_units_see_all_lanes_and_the_twin_call_rule(tmp_path):
+    """What vm_textures.CubeTextureLod builds on: at a texture() call of an implicit-LOD unit the interpreter passes the coordinate
+    EVERY lane holds and the lanes that reach the call -- the active ones, or, with merge_twin_calls, all lanes that entered an
+    if / else whose two branches assign the same variable from calls with the same arguments (cloud_funcs.gdshaderinc:132-136)."""
+    src = """
+    uniform samplerCube tex;
+    float f(vec3 p) { return texture(tex, p).r; }
+    float g(vec3 p) { return texture(tex, p).r; }
+    void main() {
+        vec3 p = vec3(IN, 2.0, 3.0);
+        float d;
+        if (IN < 2.5) { d = f(p); } else { d = g(p); }
+        float e = 0.0;
+        if (IN > 0.5) { e = texture(tex, p * 2.0).r; }
+        OUT = d + e;
+    }
+    """
+    path = tmp_path / "t.gdshader"
+    path.write_text(src)
+    x = np.array([0.0, 1.0, 2.0, 3.0], dtype=np.float32)
+    for merged in (False, True):
+        unit = _RecordingQuadSampler()
+        m = VM.Machine(VM.load(str(path)), 4, {"tex": unit}, {}, merge_twin_calls=merged)
+        m.globals["IN"] = m.from_host("float", x)
+        m.globals["OUT"] = m.from_host("float", np.zeros(4))
+        m.run("main")
+        assert np.array_equal(m.globals["OUT"].a, x + np.where(x > 0.5, 2.0 * x, 0.0))
+        (c1, r1), (c2, r2), (c3, r3) = unit.calls
+        for c in (c1, c2):
+            assert np.array_equal(c[0], x)                      # every lane's coordinate, whatever the mask
+        if merged:   # the twin branches count as one call site: all four lanes reach it from either branch
+            assert r1.tolist() == [True] * 4 and r2.tolist() == [True] * 4
+        else:        # literal: only the lanes of the branch being executed
+            assert r1.tolist() == [True, True, True, False] and r2.tolist() == [False, False, False, True]
+        assert r3.tolist() == [False, True, True, True] and np.array_equal(c3[0], 2.0 * x)   # an if without a twin: its own mask
+
+
 def test_vm_rejects_what_it_does_not_model(tmp_path):
     with pytest.raises(VM.ShaderError):
         _run(tmp_path, "void main() { while (true) { } }", 1, {})
