@@ -186,12 +186,12 @@ def parse_args():
     ap.add_argument("--band-cost", default="measured", choices=["measured", "analytic"],
                     help="--shard bands: cut the viewport by MEASURED per-row costs (rank 0 draws the frame once through "
                          "atmo_measure_tile_costs and broadcasts the cuts; default) or by the analytic estimate cloud_row_cost")
-    ap.add_argument("--gather", default="every", choices=["final", "none-then-final", "every", "none"],
-                    help="N>1: 'every' (default) = RCCL gather of EVERY frame to rank 0, two in flight, overlapped with the "
-                         "next render (root ingress over xGMI then sets the step time); 'final' (= 'none-then-final', north_star's "
-                         "\"final RCCL gather\") = frames stay where they were rendered, one gather of every rank's last frame "
-                         "inside the timed region; 'none' = no collective.  Whatever the mode, the other two rates are measured in "
-                         "further loops and reported as config.mrays_per_s_no_gather / _final_gather (SURVEY.md 8e asks for both).")
+    ap.add_argument("--gather", default="final", choices=["final", "none-then-final", "every", "none"],
+                    help="N>1: 'final' (default since round 3; = 'none-then-final', north_star's \"final RCCL gather\") = frames stay in "
+                         "the HBM of the GPU that rendered them, one gather of every rank's last frame to rank 0 INSIDE the timed region; "
+                         "'every' = RCCL gather of EVERY frame to rank 0, two in flight, overlapped with the next render (root ingress "
+                         "over xGMI then sets the step time; round 2's default); 'none' = no collective.  Whatever the mode, the other two "
+                         "rates are measured in further loops and reported as config.mrays_per_s_no_gather / _final_gather / _gather_every.")
     ap.add_argument("--shard", default="viewports", choices=["viewports", "bands"],
                     help="N>1: 'viewports' = one full viewport per GPU (weak scaling, default); 'bands' = ONE viewport cut "
                          "into hit-balanced row bands, one per GPU, gathered in place into the frame on rank 0 (strong scaling)")
@@ -469,8 +469,10 @@ def timed_loop_distributed(torch, dist, render_into, h, w, device, steps, warmup
     """The N > 1 timed region (also run on CPU/gloo by tests/test_distributed_gloo.py with a stub renderer).
 
     `render_into(buf)` enqueues one frame into the (h, w, 4) float32 tensor `buf`.  W untimed warm-up steps, then
-    EXACTLY `steps` steps bracketed by barrier + device synchronisation on both sides; returns (max over ranks of the
-    elapsed seconds, kernel launches, kernel ms) -- the last two from `timing = (start, read)` when given.
+    EXACTLY `steps` steps bracketed by barrier + device synchronisation on both sides (every rank reads its clock after ITS device
+    has drained and before the closing barrier -- an RCCL barrier is a ~0.1 ms collective of its own, 5 % of a 20-step region, and the
+    maximum over ranks already is the time the slowest rank needed); returns (max over ranks of the elapsed seconds, kernel launches,
+    kernel ms) -- the last two from `timing = (start, read)` when given.
     gather_mode: "final" (only the last frame is gathered to rank 0, inside the timed region), "every", "none"."""
     from godot_atmosphere_shader_amd.sharding import FrameGather
 
@@ -512,9 +514,9 @@ def timed_loop_distributed(torch, dist, render_into, h, w, device, steps, warmup
         step(i == steps - 1)
     result = gather.finish() if gather is not None else None
     sync()
+    dt = time.perf_counter() - t0  # this rank's K steps (+ its part of the gather) are complete; the MAX over ranks below is the job's time
     dist.barrier()
     sync()
-    dt = time.perf_counter() - t0
     launches, kernel_ms = timing[1]() if timing is not None else (0, 0.0)
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -779,6 +781,11 @@ def main():
             dt_fg, _, _ = timed_loop_distributed(torch, dist, render_into, h, w, device, args.steps, max(2, args.warmup // 4),
                                                  "final", None, bands=bands)
             final_gather_rate = scale * rays * args.steps / dt_fg / 1e6
+        every_gather_rate = None
+        if args.gather != "every":
+            dt_eg, _, _ = timed_loop_distributed(torch, dist, render_into, h, w, device, args.steps, max(2, args.warmup // 4),
+                                                 "every", None, bands=bands)
+            every_gather_rate = scale * rays * args.steps / dt_eg / 1e6
 
     result = None
     if rank == 0:
@@ -816,6 +823,7 @@ def main():
                 "gather": gather_mode,
                 "mrays_per_s_no_gather": no_gather_rate,
                 "mrays_per_s_final_gather": (value if args.gather == "final" else final_gather_rate) if multi else None,
+                "mrays_per_s_gather_every": (value if args.gather == "every" else every_gather_rate) if multi else None,
                 "shard": (f"one viewport in row bands of equal {args.band_cost} cost: " + str(bands)) if strong else "one viewport per GPU",
                 "kernel": node.kernel_name,
             },
@@ -880,7 +888,8 @@ def main():
 
 def bench_config4(torch, dist, S, textures, params, local_rank, rank, world, steps, warmup):
     """BASELINE.json configs[4]: `world` independent 3840x2160 planet_atmosphere_clouds_high_rm viewports (orbit poses), one
-    per GPU, every frame gathered to rank 0 (132.7 MB per rank per frame over xGMI); weak scaling, with and without the gather."""
+    per GPU; weak scaling, three rates: one final gather of every rank's last frame to rank 0 inside the timed region (north_star), every
+    frame gathered to rank 0 (132.7 MB per rank per frame over xGMI), and no collective."""
     from godot_atmosphere_shader_amd.demo import make_node
 
     w, h = 3840, 2160
@@ -901,11 +910,11 @@ def bench_config4(torch, dist, S, textures, params, local_rank, rank, world, ste
         torch.cuda.synchronize()
     del prime
     out = {}
-    for mode in ("every", "none"):
+    for mode in ("final", "every", "none"):
         timing = (lambda: node.set_timing(True, every=TIMING_EVERY), node.get_timing)
         dt, launches, kernel_ms = timed_loop_distributed(torch, dist, render_into, h, w, device, steps, warmup, mode, timing)
         node.set_timing(False)
-        out["Mrays/s_gather_every_frame" if mode == "every" else "Mrays/s_no_gather"] = world * w * h * steps / dt / 1e6
+        out[{"final": "Mrays/s_final_gather", "every": "Mrays/s_gather_every_frame", "none": "Mrays/s_no_gather"}[mode]] = world * w * h * steps / dt / 1e6
         out["ms_per_step_" + mode] = dt / steps * 1e3
         out["kernel_avg_ms_rank0"] = kernel_ms / launches if launches else None
     out.update(workload=f"planet_atmosphere_clouds_high_rm, 3840x2160, one viewport per GPU x {world}", steps=steps, n_gpus=world,
