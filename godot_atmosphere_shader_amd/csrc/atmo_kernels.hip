@@ -878,11 +878,28 @@ __device__ __forceinline__ float4 march_atmosphere_v1_precise(const RenderConsts
 // Precise mode (atmo_set_precision(ctx, 1)): the whole density expression in the reference's operation order, unfused,
 // with exact UNORM8 conversions and filters -- the density ramp (x50) then sees the same X as a scalar fp32 evaluation,
 // bit for bit, and the cloud variants' error drops to the atmosphere's (profiles/round1/ab_clouds_exact.txt); -15 % speed.
+#if defined(ATMO_WAVE_TRACE) && ATMO_RMQ_STATS
+// diagnostic build: lanes x calls and wave x calls that reach a stage of the density evaluation (words 16.. of the statistics block;
+// DENS_STAT_PHASE is 0 in the march, 1 in the light taps)
+#define DENS_STAT(stage_) do { \
+        const unsigned long long m_ = __builtin_amdgcn_ballot_w64(true); \
+        if (rc.wave_trace != nullptr && (int)(threadIdx.x & 63) == __builtin_ffsll((long long)m_) - 1) { \
+            unsigned long long *st_ = rc.wave_trace + 16ull * gridDim.x * gridDim.y - 64 + 16 + 8 * stat_phase + 2 * (stage_); \
+            atomicAdd(st_, (unsigned long long)__builtin_popcountll(m_)); atomicAdd(st_ + 1, 1ull); } } while (0)
+#define DENS_STAT_ARG , int stat_phase = 0
+#define DENS_STAT_PASS(ph_) , ph_
+#else
+#define DENS_STAT(stage_) do { } while (0)
+#define DENS_STAT_ARG
+#define DENS_STAT_PASS(ph_)
+#endif
 template <bool EARLY_OUT, bool LOD = false>
-__device__ __forceinline__ float cloud_density_precise(const RenderConsts &rc, float px, float py, float pz, float hr, const QuadNb *nb = nullptr) {
+__device__ __forceinline__ float cloud_density_precise(const RenderConsts &rc, float px, float py, float pz, float hr, const QuadNb *nb = nullptr DENS_STAT_ARG) {
+    DENS_STAT(0);
     const float t = 2.0f * hr - 1.0f;
     const float hc = fmaxf(1.0f - t * t, 0.0f);
     if (EARLY_OUT && !(hc > 0.0f)) return 0.0f;
+    DENS_STAT(1);
     if (EARLY_OUT && LOD) {
         // Before the (expensive) implicit-LOD coverage sample: near the top and the bottom of the layer the height curve alone
         // decides.  A filtered UNORM8 texel (any level, any mix of two levels) is at most 1 + 2^-20, and every fp32 step from the
@@ -922,6 +939,7 @@ __device__ __forceinline__ float cloud_density_precise(const RenderConsts &rc, f
         const float d_lo = ((rc.shape_lo01 + m) * hc) * 50.0f - 20.0f;
         if (d_lo >= 1.0f) return 1.0f;
     }
+    DENS_STAT(2);
     const float s = rc.shape_scale;
     const float tex = shape_sample<true>(rc.shape, rc.shape_n, px * s, py * s, pz * s);
     float shape = 0.5f * (1.0f - rc.shape_factor) + tex * rc.shape_factor;
@@ -961,8 +979,8 @@ __device__ __forceinline__ float cloud_density_fast(const RenderConsts &rc, floa
 // EARLY_OUT = false evaluates the fetches unconditionally (result is the same: hc = 0 forces the clamp to 0), which
 // removes the divergent branch so that several independent taps can be interleaved by the scheduler.
 template <bool EARLY_OUT, bool PRECISE, bool LOD = false>
-__device__ __forceinline__ float cloud_density(const RenderConsts &rc, float px, float py, float pz, float hr, const QuadNb *nb = nullptr) {
-    return PRECISE ? cloud_density_precise<EARLY_OUT, LOD>(rc, px, py, pz, hr, nb) : cloud_density_fast<EARLY_OUT>(rc, px, py, pz, hr);
+__device__ __forceinline__ float cloud_density(const RenderConsts &rc, float px, float py, float pz, float hr, const QuadNb *nb = nullptr DENS_STAT_ARG) {
+    return PRECISE ? cloud_density_precise<EARLY_OUT, LOD>(rc, px, py, pz, hr, nb DENS_STAT_PASS(stat_phase)) : cloud_density_fast<EARLY_OUT>(rc, px, py, pz, hr);
 }
 
 // exact |p| and (|p| - bottom) / thickness, as a scalar fp32 evaluation would produce them
@@ -998,7 +1016,7 @@ __device__ __forceinline__ float light_raymarched(const RenderConsts &rc, float 
             tap.px = V3{nb->px.x + k * sx, nb->px.y + k * sy, nb->px.z + k * sz};
             tap.py = V3{nb->py.x + k * sx, nb->py.y + k * sy, nb->py.z + k * sz};
         }
-        const float d = cloud_density<ATMO_RM_TAPS_EARLY_OUT != 0, PRECISE, LOD>(rc, qx, qy, qz, hr, LOD ? &tap : nullptr);
+        const float d = cloud_density<ATMO_RM_TAPS_EARLY_OUT != 0, PRECISE, LOD>(rc, qx, qy, qz, hr, LOD ? &tap : nullptr DENS_STAT_PASS(1));
         sum = __builtin_fmaf(d, rc.rm_weight[i], sum);  // step_len_i * density_scale  [host]
     }
     const float alpha = 1.0f - hw_exp2(-sum * LOG2E);
@@ -1140,6 +1158,8 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
 #ifndef ATMO_RMQ_CHUNK
 #define ATMO_RMQ_CHUNK 8
 #endif
+// (Round 3, measured and dropped: summing a half-chunk one half later so that no partial batch is lit at the chunk ends fills the
+// batches to 97 % instead of 93 % -- tools/rmq_stats.py -- and is 0.7-2 % slower: profiles/round3/rmq_stage_stats.txt.)
 constexpr int RMQ_CHUNK = ATMO_RMQ_CHUNK, RMQ_CAP = 128;
 constexpr int rmq_words_per_wave(bool lod) { return (lod ? 12 : 6) * RMQ_CAP + RMQ_CHUNK * 64; }
 
@@ -1159,6 +1179,17 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
     const int rank = rank_in(active);
     const int batch = __builtin_popcountll(active);
     int qhead = 0, qcount = 0;  // wave-uniform (SGPRs): entries [qhead, qcount) are waiting, indices modulo RMQ_CAP
+#if defined(ATMO_WAVE_TRACE) && ATMO_RMQ_STATS  // diagnostic build: how full the light batches run (tools/rmq_stats.py)
+    unsigned long long st_calls = 0, st_avail = 0, st_ticks_b = 0;
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+#define RMQ_STAT_BATCH(avail_) do { ++st_calls; st_avail += (unsigned long long)(avail_); } while (0)
+#define RMQ_STAT_B_BEGIN() const unsigned long long st_b0 = __builtin_amdgcn_s_memtime()
+#define RMQ_STAT_B_END() st_ticks_b += __builtin_amdgcn_s_memtime() - st_b0
+#else
+#define RMQ_STAT_BATCH(avail_) do { } while (0)
+#define RMQ_STAT_B_BEGIN() do { } while (0)
+#define RMQ_STAT_B_END() do { } while (0)
+#endif
 
     const int steps = rc.cloud_steps;
     const MarchRay self = cloud_march_ray(rc, dir_m, t_begin, t_end, jitter);
@@ -1177,6 +1208,8 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
     }
 
     auto light_batch = [&](int avail) {  // phase B: lane `rank` lights queue entry qhead + rank
+        RMQ_STAT_BATCH(avail);
+        RMQ_STAT_B_BEGIN();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (rank < avail) {
             const int e = (qhead + rank) & (RMQ_CAP - 1);
@@ -1193,6 +1226,7 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
             slot[sl] = light * slot[sl];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        RMQ_STAT_B_END();
     };
 
     for (int c0 = 0; c0 < steps; c0 += RMQ_CHUNK) {
@@ -1250,6 +1284,20 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
             if ((lit_bits >> k) & 1u) total_light += slot[k * 64 + lane];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+#if defined(ATMO_WAVE_TRACE) && ATMO_RMQ_STATS
+    if (rc.wave_trace != nullptr && rank == 0) {  // the last 64 words of the trace buffer (its upper half is unused: 2 waves per tile)
+        unsigned long long *st = rc.wave_trace + 16ull * gridDim.x * gridDim.y - 64;
+        atomicAdd(st + 0, 1ull);                                   // waves that march
+        atomicAdd(st + 1, (unsigned long long)batch);              // marching lanes
+        atomicAdd(st + 2, st_calls);                               // light batches
+        atomicAdd(st + 3, st_avail);                               // entries lit (= lit samples)
+        atomicAdd(st + 4, st_calls * (unsigned long long)batch);   // lanes offered to the batches
+        atomicAdd(st + 5, (unsigned long long)batch * (unsigned long long)steps);  // density evaluations of the march (lanes x steps)
+        atomicAdd(st + 6, st_ticks_b);                             // s_memtime ticks inside phase B
+        atomicAdd(st + 7, __builtin_amdgcn_s_memtime() - st_t0);   // ... inside the whole cloud march
+        atomicAdd(st + 8, st_calls * 64ull);                       // lanes of the wave x batches
+    }
+#endif
     return make_float2(total_light, 1.0f - one_minus_alpha);
 }
 

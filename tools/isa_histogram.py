@@ -82,8 +82,7 @@ def parse_kernels(asm: str):
             continue
         if cur is None:
             continue
-        if line.strip().startswith("s_endpgm"):
-            cur.append(line)
+        if line.startswith(".Lfunc_end"):  # not the first s_endpgm: kernels with early exits have several
             cur = None
             continue
         cur.append(line)
