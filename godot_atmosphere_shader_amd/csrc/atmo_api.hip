@@ -82,6 +82,8 @@ struct DeviceBuffer {
     size_t bytes = 0;
 };
 
+constexpr int F4_MAX_CUBE_N = 1024, F4_MAX_SHAPE_N = 128;  // largest textures that get a float copy of their footprints
+
 thread_local std::string g_create_error = "";
 
 }  // namespace
@@ -93,6 +95,7 @@ struct AtmoContext {
     int view_steps = 8, cloud_steps = 0, light_steps = 0;
     Params p;
     DeviceBuffer lut, blue, shape, cube;
+    DeviceBuffer cube_f4, shape_f4;  // float copies of the level-0 cubemap / shape footprints (16 B each): what the precise samplers read
     DeviceBuffer lut4;  // footprint copy of `lut` (derived on the device whenever `lut` is written): what the kernels sample
     int lut_w = 0, lut_h = 0, shape_n = 0, cube_n = 0;
     int cube_levels = 0;                 // mip levels bound (footprint arrays packed level after level in `cube`)
@@ -155,6 +158,7 @@ struct AtmoContext {
     int env_feedback = -1, env_split = 0;
     float env_reach_scale = 1.0f;                      // ATMO_FB_REACH_SCALE: multiplies the predicted reach (A/B)
     unsigned moving_period = 2;                        // ATMO_FB_MOVING_PERIOD: recording period while the camera moves
+    int f4_footprints = 3;                             // ATMO_F4=0..3 (A/B): bit 0 = float copy of the cubemap footprints, bit 1 = of the shape volume's
     int instream = 1;                                  // ATMO_FB_INSTREAM=0: never sort on the draw stream (A/B)
     uint32_t *measure_cost = nullptr;                  // atmo_measure_tile_costs: the next draw records here
     bool drew = false;                                 // a draw of this context has been enqueued ...
@@ -336,6 +340,8 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
     rc.cube_levels = ctx->cube_levels;
     rc.cube_level_off = (const uint32_t *)ctx->cube_level_off.ptr;
     rc.cube_bytes = (uint32_t)ctx->cube.bytes;
+    rc.cube_f4 = (ctx->f4_footprints & 1) ? (const float *)ctx->cube_f4.ptr : nullptr;
+    rc.shape_f4 = (ctx->f4_footprints & 2) ? (const float *)ctx->shape_f4.ptr : nullptr;
     rc.cube_lod_fast = (ctx->cube_n >= 1 && ctx->cube_n <= 1024 && (ctx->cube_n & (ctx->cube_n - 1)) == 0) ? 1 : 0;
     {   // sure-miss test (shade_pixel): usable when the view-ray direction does not depend on the depth sample (x, y, z rows of
         // inv_projection have no depth column: every perspective and orthographic-free Godot camera) and the camera is well
@@ -592,6 +598,7 @@ int atmo_create(int device, int variant, int view_steps, int cloud_steps, int li
     // A/B overrides for the tools (tools/ab_feedback.sh, tools/ab_bench.sh): read here, once -- never in the launch path
     if (const char *ev = std::getenv("ATMO_LANE_SPLIT")) ctx->env_split = ev[0] == '1' ? 1 : (ev[0] == '2' ? 2 : 0);
     if (const char *ev = std::getenv("ATMO_TILE_FEEDBACK")) ctx->env_feedback = ev[0] == '1' ? 1 : 0;
+    if (const char *ev = std::getenv("ATMO_F4")) ctx->f4_footprints = std::atoi(ev) & 3;
     if (const char *ev = std::getenv("ATMO_FB_INSTREAM")) ctx->instream = ev[0] == '1' ? 1 : 0;
     if (const char *ev = std::getenv("ATMO_FB_REACH_SCALE")) ctx->env_reach_scale = (float)std::atof(ev);
     if (const char *ev = std::getenv("ATMO_FB_MOVING_PERIOD")) { const int v = std::atoi(ev); ctx->moving_period = (unsigned)(v < 1 ? 1 : v); }
@@ -623,6 +630,8 @@ int atmo_destroy(AtmoContext *ctx) {
     dev_free(ctx->shape);
     dev_free(ctx->cube);
     dev_free(ctx->cube_level_off);
+    dev_free(ctx->cube_f4);
+    dev_free(ctx->shape_f4);
     dev_free(ctx->staging);
     if (ctx->tex_event) (void)hipEventDestroy(ctx->tex_event);
     if (ctx->fb_stream) {
@@ -777,20 +786,29 @@ int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h,
         return tex_updated(ctx, s);
     }
     if (std::strcmp(name, "u_cloud_shape_texture") == 0) {
-        if (!data) { dev_free(ctx->shape); ctx->shape_n = 0; return ATMO_OK; }
+        if (!data) { dev_free(ctx->shape); dev_free(ctx->shape_f4); ctx->shape_n = 0; return ATMO_OK; }
         if (kind != ATMO_TEX_3D_R8) return fail(ctx, ATMO_E_ARG, "u_cloud_shape_texture must be ATMO_TEX_3D_R8");
         if (w < 1 || w > 512 || h != w || d != w) return fail(ctx, ATMO_E_ARG, "u_cloud_shape_texture must be n x n x n, n <= 512");
         uint8_t *raw = nullptr;
         int rc = tex_begin_update(ctx, s);
         if (rc == ATMO_OK) rc = stage_texels(ctx, data, (size_t)w * w * w, memory, s, 0, &raw);
         if (rc == ATMO_OK) rc = tex_alloc(ctx, ctx->shape, (size_t)w * w * w * sizeof(uint32_t));
-        if (rc != ATMO_OK) return rc;
+        // the float copy (16 B per footprint) up to 128^3 = 32 MB; larger volumes are sampled from the byte footprints
+        const bool f4 = w <= F4_MAX_SHAPE_N;
+        if (rc == ATMO_OK) { if (f4) rc = tex_alloc(ctx, ctx->shape_f4, (size_t)w * w * w * 16); else dev_free(ctx->shape_f4); }
+        if (rc != ATMO_OK) {
+            dev_free(ctx->shape);
+            dev_free(ctx->shape_f4);
+            ctx->shape_n = 0;
+            return rc;
+        }
         HIP_TRY(ctx, atmo::launch_layout_shape(raw, w, (uint32_t *)ctx->shape.ptr, s));
+        if (f4) HIP_TRY(ctx, atmo::launch_footprints_f4((const uint32_t *)ctx->shape.ptr, (size_t)w * w * w, (float *)ctx->shape_f4.ptr, s));
         ctx->shape_n = w;
         return tex_updated(ctx, s);
     }
     if (is_cube) {
-        if (!data) { dev_free(ctx->cube); ctx->cube_n = 0; ctx->cube_levels = 0; return ATMO_OK; }
+        if (!data) { dev_free(ctx->cube); dev_free(ctx->cube_f4); ctx->cube_n = 0; ctx->cube_levels = 0; return ATMO_OK; }
         if (kind != ATMO_TEX_CUBE_R8) return fail(ctx, ATMO_E_ARG, "u_cloud_coverage_cubemap must be ATMO_TEX_CUBE_R8");
         if (w < 1 || w > 4096 || h != w || d != 6) return fail(ctx, ATMO_E_ARG, "u_cloud_coverage_cubemap must be n x n x 6 faces");
         const int full = atmo::cube_full_mip_count(w);
@@ -811,8 +829,12 @@ int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h,
         if (rc == ATMO_OK) rc = stage_texels(ctx, data, given_bytes, memory, s, chain_bytes - given_bytes + 1, &raw);
         if (rc == ATMO_OK) rc = tex_alloc(ctx, ctx->cube, fp_words * sizeof(uint32_t));
         if (rc == ATMO_OK) rc = dev_alloc(ctx, ctx->cube_level_off, sizeof(ctx->cube_level_off_host));
+        // the float copy of the chain (16 B per footprint) up to 1024^2 faces = 134 MB; larger faces are sampled from the byte footprints
+        const bool f4 = w <= F4_MAX_CUBE_N;
+        if (rc == ATMO_OK) { if (f4) rc = tex_alloc(ctx, ctx->cube_f4, fp_words * 16); else dev_free(ctx->cube_f4); }
         if (rc != ATMO_OK) {  // nothing half-bound: the cubemap is unset (= 1.0) until a later update succeeds
             dev_free(ctx->cube);
+            dev_free(ctx->cube_f4);
             ctx->cube_n = 0; ctx->cube_levels = 0;
             return rc;
         }
@@ -825,6 +847,7 @@ int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h,
             HIP_TRY(ctx, atmo::launch_layout_cube(raw + off, nl, (uint32_t *)ctx->cube.ptr + ctx->cube_level_off_host[l], s));
             off += atmo::cube_level_texels(w, l);
         }
+        if (f4) HIP_TRY(ctx, atmo::launch_footprints_f4((const uint32_t *)ctx->cube.ptr, fp_words, (float *)ctx->cube_f4.ptr, s));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->cube_level_off.ptr, ctx->cube_level_off_host, sizeof(ctx->cube_level_off_host), hipMemcpyHostToDevice, s));
         ctx->cube_n = w;
         ctx->cube_levels = levels;

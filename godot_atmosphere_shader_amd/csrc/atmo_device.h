@@ -78,6 +78,8 @@ struct RenderConsts {
     // --- exact short division of the pixel coordinates (pixel_coord in atmo_kernels.hip)
     float rcp_vw, rcp_vh;           // [host] RN(1 / vw), RN(1 / vh)
     // --- sure-miss test in front of the exact prologue (shade_pixel)
+    const float *cube_f4;           // level 0 of `cube` with every footprint's four texels as exact byte / 255 floats (16 B), or null
+    const float *shape_f4;          // the same for `shape`
     float miss_k;                   // [host] (|c|^2 - R_atm^2) (1 - 1e-3)^2 when the test is usable, else 0
 };
 
@@ -108,6 +110,7 @@ hipError_t launch_layout_lut(const float *lut, int w, int h, float *out, hipStre
 hipError_t launch_lut_footprints(const float *apron, int w, int h, float *out4, hipStream_t stream);
 hipError_t launch_layout_shape(const uint8_t *t, int n, uint32_t *out, hipStream_t stream);
 hipError_t launch_layout_cube(const uint8_t *faces, int n, uint32_t *out, hipStream_t stream);
+hipError_t launch_footprints_f4(const uint32_t *words, size_t n_words, float *out4, hipStream_t stream);
 hipError_t launch_cube_mip(const uint8_t *level, int n, uint8_t *next, hipStream_t stream);
 void render_grid(const RenderConsts &rc, int split, int *tiles_x, int *tiles_y);
 hipError_t launch_noise_cubemap(const NoiseCubemapConsts &nc, hipStream_t stream);

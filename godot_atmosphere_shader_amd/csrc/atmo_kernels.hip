@@ -157,6 +157,9 @@ __device__ __forceinline__ float exact_div_uniform(float a, float c, float rc) {
 #ifndef ATMO_FAST_MISS
 #define ATMO_FAST_MISS 1
 #endif
+#ifndef ATMO_F4_FOOTPRINTS  // 1: the precise samplers read a float copy of the cloud textures' footprints when the context holds one
+#define ATMO_F4_FOOTPRINTS 1
+#endif
 #ifndef ATMO_WORLD_DIV3  // 1: the three world.xyz / world.w quotients share one reciprocal in the DIET kernels (world_div3)
 #define ATMO_WORLD_DIV3 1
 #endif
@@ -288,10 +291,11 @@ __device__ __forceinline__ float lut_sample_fp(const float *__restrict__ lut4, i
 }
 
 __device__ __forceinline__ float trilinear_unorm8_exact(uint32_t w0, uint32_t w1, float fx, float fy, float fz);
+__device__ __forceinline__ float unorm8_exact(float b);
 
 // texture(u_cloud_shape_texture, p).r : trilinear, repeat, R8.  PRECISE: exact UNORM8 conversions + unfused mixes.
 template <bool PRECISE>
-__device__ __forceinline__ float shape_sample(const uint32_t *__restrict__ fp, int n, float px, float py, float pz) {
+__device__ __forceinline__ float shape_sample(const uint32_t *__restrict__ fp, int n, float px, float py, float pz, const float *__restrict__ f4 = nullptr) {
 #pragma clang fp contract(fast)
     const float nf = (float)n;
     const float x = px * nf - 0.5f, y = py * nf - 0.5f, z = pz * nf - 0.5f;
@@ -305,6 +309,30 @@ __device__ __forceinline__ float shape_sample(const uint32_t *__restrict__ fp, i
     } else {
         i0 = ((i % n) + n) % n; j0 = ((j % n) + n) % n; k0 = ((k % n) + n) % n; k1 = (k0 + 1) % n;
     }
+#if ATMO_F4_FOOTPRINTS && ATMO_BUFFER_LOADS
+    if (PRECISE) {  // with a float copy of the footprints: two 16-byte gathers, no conversions
+        f32x4 a, b;
+        const uint32_t e0 = (uint32_t)((k0 * n + j0) * n + i0), e1 = (uint32_t)((k1 * n + j0) * n + i0);
+        if (f4 != nullptr) {
+            const __amdgpu_buffer_rsrc_t rs4 = make_rsrc(f4, (uint32_t)(n * n * n) * 16u);
+            a = buf_f32x4(rs4, e0 * 16u);
+            b = buf_f32x4(rs4, e1 * 16u);
+        } else {
+            const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(fp, (uint32_t)(n * n * n) * 4u);
+            const uint32_t w0 = buf_u32(rs1, e0 * 4u), w1 = buf_u32(rs1, e1 * 4u);
+            a = f32x4{unorm8_exact(ub0(w0)), unorm8_exact(ub1(w0)), unorm8_exact(ub2(w0)), unorm8_exact(ub3(w0))};
+            b = f32x4{unorm8_exact(ub0(w1)), unorm8_exact(ub1(w1)), unorm8_exact(ub2(w1)), unorm8_exact(ub3(w1))};
+        }
+        const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;  // trilinear_unorm8_exact on converted texels, unfused
+        const float c00 = a.x * gx + a.y * fx;
+        const float c10 = a.z * gx + a.w * fx;
+        const float c01 = b.x * gx + b.y * fx;
+        const float c11 = b.z * gx + b.w * fx;
+        const float c0 = c00 * gy + c10 * fy;
+        const float c1 = c01 * gy + c11 * fy;
+        return c0 * gz + c1 * fz;
+    }
+#endif
 #if ATMO_ABLATE_FETCH
     const uint32_t w0 = (uint32_t)((k0 * n + j0) * n + i0) * 2654435761u;
     const uint32_t w1 = (uint32_t)((k1 * n + j0) * n + i0) * 2246822519u;
@@ -354,6 +382,14 @@ __device__ __forceinline__ float bilinear_unorm8_exact(uint32_t w, float fx, flo
     return a * gy + b * fy;
 }
 
+// the same filter on texels that are already exact byte / 255 floats (no contraction in this function either)
+__device__ __forceinline__ float bilinear_exact4(float t00, float t10, float t01, float t11, float fx, float fy) {
+    const float gx = 1.0f - fx, gy = 1.0f - fy;
+    const float a = t00 * gx + t10 * fx;
+    const float b = t01 * gx + t11 * fx;
+    return a * gy + b * fy;
+}
+
 __device__ __forceinline__ float trilinear_unorm8_exact(uint32_t w0, uint32_t w1, float fx, float fy, float fz) {
     const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
     const float c00 = unorm8_exact(ub0(w0)) * gx + unorm8_exact(ub1(w0)) * fx;
@@ -369,7 +405,7 @@ __device__ __forceinline__ float trilinear_unorm8_exact(uint32_t w0, uint32_t w1
 // Face selection and the in-face coordinates come from the hardware cube instructions (v_cubeid/sc/tc/ma_f32):
 // same table and tie-break as Vulkan (z over y over x), ma = 2 * major axis value.
 template <bool PRECISE>
-__device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, int n, float dx, float dy, float dz) {
+__device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, int n, float dx, float dy, float dz, const float *__restrict__ f4 = nullptr) {
 #pragma clang fp contract(fast)
     const float fid = __builtin_amdgcn_cubeid(dx, dy, dz);
     const float sc = __builtin_amdgcn_cubesc(dx, dy, dz);
@@ -400,7 +436,20 @@ __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, in
         // add and a shift-add
         const float nm1 = (float)(n - 1), s4 = (float)(stride * 4);
         const float ic = __builtin_amdgcn_fmed3f(xf, -1.0f, nm1), jc = __builtin_amdgcn_fmed3f(yf, -1.0f, nm1);
-        const uint32_t off = (uint32_t)fmaf(fid, s4 * (float)stride, fmaf(jc, s4, fmaf(ic, 4.0f, s4 + 4.0f)));
+        const float offf = fmaf(fid, s4 * (float)stride, fmaf(jc, s4, fmaf(ic, 4.0f, s4 + 4.0f)));
+#if ATMO_F4_FOOTPRINTS
+        if (PRECISE) {  // with a float copy of the footprints: one 16-byte gather at four times the offset, no conversions
+            f32x4 t;
+            if (f4 != nullptr) {
+                t = buf_f32x4(make_rsrc(f4, (uint32_t)(6 * stride * stride) * 16u), (uint32_t)(offf * 4.0f));
+            } else {
+                const uint32_t w = buf_u32(make_rsrc(fp, (uint32_t)(6 * stride * stride) * 4u), (uint32_t)offf);
+                t = f32x4{unorm8_exact(ub0(w)), unorm8_exact(ub1(w)), unorm8_exact(ub2(w)), unorm8_exact(ub3(w))};
+            }
+            return bilinear_exact4(t.x, t.y, t.z, t.w, fx, fy);
+        }
+#endif
+        const uint32_t off = (uint32_t)offf;
         const uint32_t w = buf_u32(make_rsrc(fp, (uint32_t)(6 * stride * stride) * 4u), off);
         if (PRECISE || ATMO_CUBE_EXACT) return bilinear_unorm8_exact(w, fx, fy);
         const float t00 = ub0(w), t10 = ub1(w), t01 = ub2(w), t11 = ub3(w);
@@ -501,7 +550,7 @@ __device__ __forceinline__ float cube_sample_lod(const RenderConsts &rc, V3 d, b
 // integer address chains and a global load of the level offset (here: one buffer gather per level at a byte offset formed in
 // fp32; the level's base follows from the geometric series of the packed chain).  Bit-for-bit the same s, t, texels and
 // filters as the general form; lambda agrees to a few ulp.
-__device__ __forceinline__ float cube_level_sample_fast(__amdgpu_buffer_rsrc_t rs, float fid, float q1s, float q1t, float nf, float c0, int lo) {
+__device__ __forceinline__ float cube_level_sample_fast(__amdgpu_buffer_rsrc_t rs, bool f4, float fid, float q1s, float q1t, float nf, float c0, int lo) {
     // level `lo`: faces of nl = n >> lo texels, footprints (nl + 1)^2 per face, packed behind the levels below it:
     //   words before level l = 6 sum_{k<l} (n_k + 1)^2 = 8 n^2 - 8 nl^2 + 24 n - 24 nl + 6 l        (n a power of two)
     const float nl = __builtin_amdgcn_ldexpf(nf, -lo);
@@ -514,8 +563,14 @@ __device__ __forceinline__ float cube_level_sample_fast(__amdgpu_buffer_rsrc_t r
     // byte offsets: every term and partial sum is a multiple of 4 below 2^26 (33.6 MB for the whole chain at n = 1024): exact
     const float base = __builtin_fmaf(-32.0f * nl, nl, __builtin_fmaf(-96.0f, nl, __builtin_fmaf(24.0f, (float)lo, c0)));
     const float in_level = __builtin_fmaf(fid, s4 * (nl + 1.0f), __builtin_fmaf(jc, s4, __builtin_fmaf(ic, 4.0f, s4 + 4.0f)));
-    const uint32_t w = buf_u32(rs, (uint32_t)(base + in_level));
-    return bilinear_unorm8_exact(w, fx, fy);
+    f32x4 t;
+    if (f4) {  // `rs` is the chain's float copy: 16-byte footprints at four times the offset (a multiple of 16 below 2^28: exact in fp32)
+        t = buf_f32x4(rs, (uint32_t)((base + in_level) * 4.0f));
+    } else {
+        const uint32_t w = buf_u32(rs, (uint32_t)(base + in_level));
+        t = f32x4{unorm8_exact(ub0(w)), unorm8_exact(ub1(w)), unorm8_exact(ub2(w)), unorm8_exact(ub3(w))};
+    }
+    return bilinear_exact4(t.x, t.y, t.z, t.w, fx, fy);
 }
 
 // The selected face's frame as coefficients (0, +1 or -1, so the products and sums below are exact): for any vector v
@@ -574,12 +629,13 @@ __device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3
     lambda = fminf(fmaxf(lambda, 0.0f), (float)(rc.cube_levels - 1));
     const float lf = floorf(lambda), fr = lambda - lf;
     const int lo = (int)lf;
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(rc.cube, rc.cube_bytes);
     const float c0 = __builtin_fmaf(32.0f * nf, nf, 96.0f * nf);
     const float q1s = qs + 1.0f, q1t = qt + 1.0f;
-    const float v0 = cube_level_sample_fast(rs, fid, q1s, q1t, nf, c0, lo);
+    const bool f4 = ATMO_F4_FOOTPRINTS && rc.cube_f4 != nullptr;  // wave-uniform: the float copy of the chain, or the byte footprints
+    const __amdgpu_buffer_rsrc_t rs = f4 ? make_rsrc(rc.cube_f4, rc.cube_bytes * 4u) : make_rsrc(rc.cube, rc.cube_bytes);
+    const float v0 = cube_level_sample_fast(rs, f4, fid, q1s, q1t, nf, c0, lo);
     if (lo + 1 >= rc.cube_levels || fr == 0.0f) return v0;
-    const float v1 = cube_level_sample_fast(rs, fid, q1s, q1t, nf, c0, lo + 1);
+    const float v1 = cube_level_sample_fast(rs, f4, fid, q1s, q1t, nf, c0, lo + 1);
     return v0 * (1.0f - fr) + v1 * fr;
 }
 
@@ -922,7 +978,7 @@ __device__ __forceinline__ float cloud_density_precise(const RenderConsts &rc, f
             else coverage = cube_sample_lod(rc, V3{qx, py, qz}, nb->vx, rot(nb->px), nb->vy, rot(nb->py));
 #endif
         } else {
-            coverage = cube_sample<true>(rc.cube, rc.cube_n, qx, py, qz);
+            coverage = cube_sample<true>(rc.cube, rc.cube_n, qx, py, qz, rc.cube_f4);
         }
     }
     coverage = coverage - 0.25f * hr + rc.coverage_bias;
@@ -941,7 +997,7 @@ __device__ __forceinline__ float cloud_density_precise(const RenderConsts &rc, f
     }
     DENS_STAT(2);
     const float s = rc.shape_scale;
-    const float tex = shape_sample<true>(rc.shape, rc.shape_n, px * s, py * s, pz * s);
+    const float tex = shape_sample<true>(rc.shape, rc.shape_n, px * s, py * s, pz * s, rc.shape_f4);
     float shape = 0.5f * (1.0f - rc.shape_factor) + tex * rc.shape_factor;
     if (rc.shape_invert) shape = 1.0f - shape;
     float density = (shape - 0.1f + m) * hc;
@@ -1827,6 +1883,18 @@ hipError_t launch_layout_shape(const uint8_t *t, int n, uint32_t *out, hipStream
     hipLaunchKernelGGL(atmo_layout_shape_kernel, dim3((n + 63) / 64, (n + 3) / 4, n), dim3(256), 0, stream, t, n, out);
     return hipGetLastError();
 }
+// Footprint words -> four exact byte / 255 floats each (ATMO_F4_FOOTPRINTS): the samplers then skip the 12 conversion instructions.
+__global__ __launch_bounds__(256) void atmo_footprints_f4_kernel(const uint32_t *__restrict__ words, size_t n, float4 *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t w = words[i];
+    out[i] = make_float4(unorm8_exact(ub0(w)), unorm8_exact(ub1(w)), unorm8_exact(ub2(w)), unorm8_exact(ub3(w)));
+}
+hipError_t launch_footprints_f4(const uint32_t *words, size_t n_words, float *out4, hipStream_t stream) {
+    hipLaunchKernelGGL(atmo_footprints_f4_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, stream, words, n_words, (float4 *)out4);
+    return hipGetLastError();
+}
+
 hipError_t launch_layout_cube(const uint8_t *faces, int n, uint32_t *out, hipStream_t stream) {
     hipLaunchKernelGGL(atmo_layout_cube_kernel, dim3((n + 1 + 63) / 64, (n + 1 + 3) / 4, 6), dim3(256), 0, stream, faces, n, out);
     return hipGetLastError();

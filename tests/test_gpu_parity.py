@@ -1234,3 +1234,59 @@ def test_implicit_lod_needs_a_chain_and_the_precise_kernels(oracle32):
             _gpu_render(node, cam, depth)
         assert e.value.code == N.ATMO_E_STATE
         node.close()
+
+
+def test_float_footprint_copies_do_not_change_a_bit(monkeypatch):
+    """Round 3: the precise samplers read a float copy of the cloud textures' footprints (four exact byte / 255 values per 16-byte
+    footprint: one gather, no conversions).  The copy holds the very floats the byte path computes, so frames are bit-identical with
+    the copy (default) and without it (ATMO_F4=0, read once in atmo_create) -- LOD 0 and implicit LOD, both cloud light modes -- and
+    a texture UPDATE refreshes the copy too."""
+    tex, params = demo_textures(), demo_params()
+    w, h = 320, 180
+    for config_name, lod, pose in (("clouds_high", False, "P_space"), ("clouds_high_rm", False, "P_clouds"), ("clouds_high_rm", True, "P_space"),
+                                   ("clouds", True, "P_limb")):
+        cam = S.Camera.from_pose(w, h, pose)
+        depth = S.depth_ground_sphere(cam)
+        frames = []
+        for f4 in ("0", None):
+            if f4 is None:
+                monkeypatch.delenv("ATMO_F4", raising=False)
+            else:
+                monkeypatch.setenv("ATMO_F4", f4)
+            node = make_node(config_name, tex, params, cubemap_lod=lod)
+            frames.append(_gpu_render(node, cam, depth))
+            if f4 is None:  # update both cloud textures: the float copies must follow
+                rng = np.random.default_rng(5)
+                shape2 = rng.integers(0, 256, size=tex["shape"].shape, dtype=np.uint8)
+                cube2 = np.ascontiguousarray(tex["cubemap"][:, ::-1, :])
+                node.set_shader_parameter("u_cloud_shape_texture", shape2)
+                node.set_shader_parameter("u_cloud_coverage_cubemap", cube2)
+                after = _gpu_render(node, cam, depth)
+            node.close()
+        assert np.array_equal(frames[0], frames[1]), (config_name, lod, pose)
+        assert np.abs(frames[1]).max() > 0.0
+        monkeypatch.setenv("ATMO_F4", "0")
+        ref = make_node(config_name, dict(tex, shape=shape2, cubemap=cube2), params, cubemap_lod=lod)
+        want_after = _gpu_render(ref, cam, depth)
+        ref.close()
+        monkeypatch.delenv("ATMO_F4", raising=False)
+        assert np.array_equal(after, want_after), (config_name, lod, pose)
+        assert not np.array_equal(after, frames[1])
+
+
+def test_shape_volume_too_large_for_a_float_copy_still_matches_the_oracle(oracle32):
+    """A 160^3 shape volume (larger than the 128^3 limit of the float copy, and not a power of two: the general wrap) is sampled
+    from the byte footprints; parity against the oracle as for every other scene."""
+    tex, params = demo_textures(), demo_params()
+    tex = dict(tex, shape=S.make_shape_texture(160))
+    w, h = 160, 90
+    cam = S.Camera.from_pose(w, h, "P_space")
+    depth = S.depth_ground_sphere(cam)
+    for config_name in ("clouds_high", "clouds_high_rm"):
+        node = make_node(config_name, tex, params)
+        got = _gpu_render(node, cam, depth)
+        lut = node.read_optical_depth()
+        node.close()
+        want, _ = _oracle_render(oracle32, config_name, params, tex, cam, depth, lut)
+        assert np.array_equal(np.all(got == 0.0, axis=-1), np.all(want == 0.0, axis=-1))
+        assert np.abs(got - want).max() <= TOL
