@@ -329,6 +329,7 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
         for (int i = 0; i < 6; ++i) {
             rc.rm_offset[i] = (float)i * step_len;
             rc.rm_weight[i] = step_len * p.u_cloud_density_scale;
+            for (int c = 0; c < 3; ++c) rc.rm_tap[i][c] = rc.rm_offset[i] * rc.sun_dir_model[c];
             step_len *= 1.2f;
         }
     }

@@ -49,6 +49,7 @@ struct RenderConsts {
     int32_t cloud_steps;
     float rm_offset[6];               // [host] float(i) * step_len_i, step_len_i = reach/6 * 1.2^i   clouds:108,114-115,129,143
     float rm_weight[6];               // [host] step_len_i * density_scale     clouds:138
+    float rm_tap[6][3];               // [host] rm_offset[i] * sun_dir_model: the uniform product of clouds:129, rounded once on the host
     // --- textures (device memory owned by the context)
     const float *lut;        // u_optical_depth_texture: (lut_h+2) rows of (lut_w+2), clamp-to-edge apron
     int32_t lut_w, lut_h;

@@ -1052,6 +1052,9 @@ __device__ __forceinline__ void cloud_height(const RenderConsts &rc, float px, f
 // alpha0 branches are, with CLOUDS_ALWAYS_LOW_QUALITY).  The caller passes that density in as d0 (ATMO_RM_TAP0_REUSE): five taps
 // are evaluated instead of six, and the one saved is the expensive one -- a lit sample has density > 0, so its tap 0 never takes
 // an early-out and always pays the full exact shape + coverage filters.  Bit-identical.
+#ifndef ATMO_RM_TAP_HOST
+#define ATMO_RM_TAP_HOST 1
+#endif
 #ifndef ATMO_RM_TAP0_REUSE
 #define ATMO_RM_TAP0_REUSE 1
 #endif
@@ -1061,16 +1064,22 @@ __device__ __forceinline__ float light_raymarched(const RenderConsts &rc, float 
     float sum = ATMO_RM_TAP0_REUSE ? __builtin_fmaf(d0, rc.rm_weight[0], 0.0f) : 0.0f;
 #pragma unroll
     for (int i = ATMO_RM_TAP0_REUSE ? 1 : 0; i < 6; ++i) {
+        // exact: pos0 + (i*step)*dir, unfused; the product (float(i) * step_len_i) * dir is uniform and comes rounded from the host
+        // (ATMO_RM_TAP_HOST: two SGPR factors would cost a move and a multiply per component and tap)
+#if ATMO_RM_TAP_HOST
+        const float kx = rc.rm_tap[i][0], ky = rc.rm_tap[i][1], kz = rc.rm_tap[i][2];
+#else
         const float k = rc.rm_offset[i];  // float(i) * step_len_i, step_len_i = step0 * 1.2^i  [host]
-        // exact: pos0 + (i*step)*dir, unfused
-        const float qx = px + k * sx, qy = py + k * sy, qz = pz + k * sz;
+        const float kx = k * sx, ky = k * sy, kz = k * sz;
+#endif
+        const float qx = px + kx, qy = py + ky, qz = pz + kz;
         float r, hr;
         cloud_height(rc, qx, qy, qz, r, hr);
         QuadNb tap;
         if (LOD) {  // the quad partners evaluate the same tap from their own sample position
             tap.vx = nb->vx; tap.vy = nb->vy;
-            tap.px = V3{nb->px.x + k * sx, nb->px.y + k * sy, nb->px.z + k * sz};
-            tap.py = V3{nb->py.x + k * sx, nb->py.y + k * sy, nb->py.z + k * sz};
+            tap.px = V3{nb->px.x + kx, nb->px.y + ky, nb->px.z + kz};
+            tap.py = V3{nb->py.x + kx, nb->py.y + ky, nb->py.z + kz};
         }
         const float d = cloud_density<ATMO_RM_TAPS_EARLY_OUT != 0, PRECISE, LOD>(rc, qx, qy, qz, hr, LOD ? &tap : nullptr DENS_STAT_PASS(1));
         sum = __builtin_fmaf(d, rc.rm_weight[i], sum);  // step_len_i * density_scale  [host]
