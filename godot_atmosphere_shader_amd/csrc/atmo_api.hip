@@ -82,7 +82,11 @@ struct DeviceBuffer {
     size_t bytes = 0;
 };
 
-constexpr int F4_MAX_CUBE_N = 1024, F4_MAX_SHAPE_N = 128;  // largest textures that get a float copy of their footprints
+// Largest textures that get a float copy of their footprints (tools/texsize_probe.py, profiles/round3/ab_float_footprints.txt): the whole shape
+// volume is touched by every frame (repeat wrap), and its float copy stops paying between 96^3 (14 MB: -2 %) and 128^3 (34 MB: +50 %, it
+// no longer lives in the L2s / Infinity Cache beside everything else); of the cubemap only the visible part is touched: the copy wins up to
+// the 1024^2 faces the fp32-addressed sampler handles.
+constexpr int F4_MAX_CUBE_N = 1024, F4_MAX_SHAPE_N = 100;
 
 thread_local std::string g_create_error = "";
 
