@@ -623,6 +623,7 @@ class PlanetAtmosphere:
         cost = np.zeros((gy.value, gx.value), dtype=np.uint32)
         N.check(self._ctx, self._lib.atmo_measure_tile_costs(*args, cost.ctypes.data_as(C.c_void_p), cost.size, C.byref(gx), C.byref(gy),
                                                             C.byref(tw), C.byref(th)))
+        self._last_tile_costs = cost  # (tiles_y, tiles_x) uint32, for diagnostics (tools/xcd_balance.py)
         rows = np.repeat(cost.astype(np.float64).sum(axis=1) / th.value, th.value)[: y1 - y0]
         return rows
 

@@ -105,6 +105,22 @@ def main():
     ends = np.array([e_us[simd_key == key].max() for key in keys])
     print("SIMD runs out of work at us: p5 %.1f  p25 %.1f  p50 %.1f  p75 %.1f  p95 %.1f  max %.1f" %
           tuple(np.percentile(ends, [5, 25, 50, 75, 95, 100])))
+    # who is still running during the drain: start time, duration and dispatch rank of the waves that end in the last tenth of the span
+    late = e_us >= 0.9 * span
+    if late.any():
+        rank = np.argsort(np.argsort(entry_us))  # dispatch order
+        print(f"waves ending in the last tenth of the span: {late.sum()} of {len(t)}; they entered at us p5 %.1f p50 %.1f p95 %.1f; "
+              "duration us p5 %.1f p50 %.1f p95 %.1f; dispatch rank (0 = first) p5 %.0f p50 %.0f p95 %.0f"
+              % (tuple(np.percentile(entry_us[late], [5, 50, 95])) + tuple(np.percentile(dur[late], [5, 50, 95]))
+                 + tuple(np.percentile(rank[late], [5, 50, 95]))))
+        heavy = dur >= np.percentile(dur, 90)
+        print("the heaviest tenth of the waves: duration us p50 %.1f; entered at us p5 %.1f p50 %.1f p95 %.1f max %.1f; ended at us p50 %.1f p95 %.1f max %.1f"
+              % ((np.percentile(dur[heavy], 50),) + tuple(np.percentile(entry_us[heavy], [5, 50, 95, 100])) + tuple(np.percentile(e_us[heavy], [50, 95, 100]))))
+        for lo_, hi_ in ((0.0, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 0.9), (0.9, 1.0)):
+            m = (entry_us >= lo_ * span) & (entry_us < hi_ * span)
+            if m.any():
+                print(f"  waves entering in {lo_ * 100:3.0f}-{hi_ * 100:3.0f} % of the span: {m.sum():6d}, duration us p50 {np.percentile(dur[m], 50):6.1f} "
+                      f"p95 {np.percentile(dur[m], 95):6.1f} max {dur[m].max():6.1f}")
     lifetime = e_us - entry_us
     print(f"wave lifetime from entry: mean {lifetime.mean():.1f} us = {lifetime.sum() / span / n_simd:.2f} resident waves per SIMD; "
           f"of which past the preamble {dur.sum() / lifetime.sum() * 100:.0f} %")
