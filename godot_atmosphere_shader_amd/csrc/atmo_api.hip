@@ -82,11 +82,11 @@ struct DeviceBuffer {
     size_t bytes = 0;
 };
 
-// Largest textures that get a float copy of their footprints (tools/texsize_probe.py, profiles/round3/ab_float_footprints.txt): the whole shape
-// volume is touched by every frame (repeat wrap), and its float copy stops paying between 96^3 (14 MB: -2 %) and 128^3 (34 MB: +50 %, it
-// no longer lives in the L2s / Infinity Cache beside everything else); of the cubemap only the visible part is touched: the copy wins up to
-// the 1024^2 faces the fp32-addressed sampler handles.
-constexpr int F4_MAX_CUBE_N = 1024, F4_MAX_SHAPE_N = 100;
+// Largest textures that get a float copy of their footprints (tools/texsize_probe.py, profiles/round3/ab_float_footprints.txt).  Of the cubemap
+// a frame touches only the visible part: the copy wins up to the 1024^2 faces the fp32-addressed sampler handles.  The shape volume repeats, so
+// every XCD touches all of it in every frame, and its copy has to fit into an XCD's 4 MB L2 beside everything else: at 32^3 (0.5 MB) it is worth
+// 4 %, at 64^3 (4 MB) 1 % of the kernel time for 27 MB more fabric traffic per 1920x1080 frame, at 128^3 (34 MB) it COSTS 50 %.
+constexpr int F4_MAX_CUBE_N = 1024, F4_MAX_SHAPE_N = 48;
 
 thread_local std::string g_create_error = "";
 
@@ -798,7 +798,7 @@ int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h,
         int rc = tex_begin_update(ctx, s);
         if (rc == ATMO_OK) rc = stage_texels(ctx, data, (size_t)w * w * w, memory, s, 0, &raw);
         if (rc == ATMO_OK) rc = tex_alloc(ctx, ctx->shape, (size_t)w * w * w * sizeof(uint32_t));
-        // the float copy (16 B per footprint) up to 128^3 = 32 MB; larger volumes are sampled from the byte footprints
+        // the float copy (16 B per footprint) only for volumes small enough to stay L2-resident; larger ones are sampled from the byte footprints
         const bool f4 = w <= F4_MAX_SHAPE_N;
         if (rc == ATMO_OK) { if (f4) rc = tex_alloc(ctx, ctx->shape_f4, (size_t)w * w * w * 16); else dev_free(ctx->shape_f4); }
         if (rc != ATMO_OK) {

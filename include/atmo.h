@@ -126,7 +126,7 @@ int atmo_get_param_f32(AtmoContext *ctx, const char *name, float *v, int n);
  * on a stream OTHER than the one the context last drew on, which waits for the device first (draws may still be reading
  * the bound copy there) -- send updates down the draw stream and stream order is all there is.
  * Device memory per bound texture: 4 bytes per texel position for the two cloud textures (bilinear footprints) plus, up to
- * 128^3 (shape volume) and 1024^2 faces (cubemap, whole chain), a float copy of the same footprints at 16 bytes each, which
+ * 1024^2 faces (cubemap, whole chain) and 48^3 (shape volume), a float copy of the same footprints at 16 bytes each, which
  * the precise cloud kernels sample (same bits, fewer instructions); larger textures are sampled from the 4-byte footprints.
  */
 int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h, int d, int mips,

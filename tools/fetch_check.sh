@@ -7,7 +7,7 @@ PY=$(python3 -c 'import sys,os;print(os.path.realpath(sys.executable))')
 export TMPDIR=/tmp
 cd /tmp
 for v in on off; do
-  if [ $v = off ]; then export $VAR=0; else unset $VAR; fi
+  if [ $v = off ]; then export $VAR=${OFF:-0}; else unset $VAR; fi
   OUT=$R/gpurun_out/fetch_${WL}_${W}x${H}_$v
   rm -rf $OUT; mkdir -p $OUT
   for PMC in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TA_BUSY_avr TCP_TCC_READ_REQ_sum"; do
