@@ -949,6 +949,12 @@ __device__ __forceinline__ float4 march_atmosphere_v1_precise(const RenderConsts
 #define DENS_STAT_ARG
 #define DENS_STAT_PASS(ph_)
 #endif
+// The density ramp clamp(x * 50 - 20, 0, 1) of get_density (clouds:60-75), unfused fp32: RN(RN(x * 50) - 20) <= 0  <=>  RN(x * 50) <= 20
+// <=>  x <= 0x3ecccccd (the largest float whose product with 50 rounds to at most 20), and RN(RN(x * 50) - 20) >= 1  <=>  RN(x * 50) >= 21
+// (the subtraction is exact there)  <=>  x >= 0x3ed70a3d.  Both equivalences checked for every float in [0.125, 1) and samples of the rest
+// (profiles/round3/ab_density_ramp.txt); a NaN fails both tests in either form.
+#define DENSITY_RAMP_ZERO __uint_as_float(0x3ecccccdu)
+#define DENSITY_RAMP_ONE __uint_as_float(0x3ed70a3du)
 template <bool EARLY_OUT, bool LOD = false>
 __device__ __forceinline__ float cloud_density_precise(const RenderConsts &rc, float px, float py, float pz, float hr, const QuadNb *nb = nullptr DENS_STAT_ARG) {
     DENS_STAT(0);
@@ -963,7 +969,7 @@ __device__ __forceinline__ float cloud_density_precise(const RenderConsts &rc, f
         // that bound and at the largest shape value the exact result is 0.  ~10 % of the samples inside the layer.
         const float cov_hi = (1.0f + 9.5367431640625e-07f) - 0.25f * hr + rc.coverage_bias;
         const float m_hi = -1.2f * (1.0f - cov_hi) + 1.5f * cov_hi;
-        if (((rc.shape_hi01 + m_hi) * hc) * 50.0f - 20.0f <= 0.0f) return 0.0f;
+        if ((rc.shape_hi01 + m_hi) * hc <= DENSITY_RAMP_ZERO) return 0.0f;
     }
     float coverage = 1.0f;
     if (rc.cube != nullptr) {
@@ -990,10 +996,9 @@ __device__ __forceinline__ float cloud_density_precise(const RenderConsts &rc, f
         // mix/invert of a filtered UNORM8 value in [0, 1 + 2^-20]).  So if the expression is <= 0 at shape_hi the exact
         // result is 0, and if it is >= 1 at shape_lo the exact result is 1: bit-identical, no trilinear fetch (the
         // 8-texel exact filter is ~45 % of a density evaluation).
-        const float d_hi = ((rc.shape_hi01 + m) * hc) * 50.0f - 20.0f;
-        if (d_hi <= 0.0f) return 0.0f;
-        const float d_lo = ((rc.shape_lo01 + m) * hc) * 50.0f - 20.0f;
-        if (d_lo >= 1.0f) return 1.0f;
+        // (x * 50 - 20 <= 0 and >= 1 decided on x itself: DENSITY_RAMP_ZERO / _ONE, two instructions fewer per test)
+        if ((rc.shape_hi01 + m) * hc <= DENSITY_RAMP_ZERO) return 0.0f;
+        if ((rc.shape_lo01 + m) * hc >= DENSITY_RAMP_ONE) return 1.0f;
     }
     DENS_STAT(2);
     const float s = rc.shape_scale;
