@@ -289,6 +289,14 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
     rc.clouds_top = p.u_planet_radius + p.u_cloud_top * p.u_atmosphere_height;
     rc.cloud_thickness = rc.clouds_top - rc.clouds_bottom;
     rc.inv_cloud_thickness = 1.0f / rc.cloud_thickness;
+    {   // sure-outside bounds on |p|^2 for the march (atmo_kernels.hip, ATMO_SURE_OUTSIDE): 2e-6 relative is ten times the rounding of the
+        // unfused |p|^2 sum and of the root; below lo the exact chain gives r < bottom, hr < 0, above hi r > top, hr >= 1: hc = 0 either way
+        const double lo = (double)rc.clouds_bottom * (double)rc.clouds_bottom * (1.0 - 2e-6);
+        const double hi = (double)rc.clouds_top * (double)rc.clouds_top * (1.0 + 2e-6);
+        rc.layer_r2_lo = (float)lo;
+        rc.layer_r2_hi = (float)hi;
+        if (!(rc.cloud_thickness > 0.0f) || !std::isfinite(rc.layer_r2_hi)) { rc.layer_r2_lo = 0.0f; rc.layer_r2_hi = INFINITY; }  // odd layers: never skip
+    }
     rc.cloud_density_scale = p.u_cloud_density_scale;
     rc.cloud_blend = p.u_cloud_blend;
     rc.coverage_bias = p.u_cloud_coverage_bias;

@@ -37,6 +37,7 @@ struct RenderConsts {
     float clouds_bottom, clouds_top;  // [host] R + u_cloud_{bottom,top} * H   clouds:260-261
     float cloud_thickness;            // [host] top - bottom
     float inv_cloud_thickness;        // [host] RN(1 / thickness), for exact_div_uniform
+    float layer_r2_lo, layer_r2_hi;   // [host] (bottom (1 - 1e-6))^2, (top (1 + 1e-6))^2: |p|^2 outside [lo, hi] => surely outside the cloud layer
     float cloud_density_scale, cloud_blend, coverage_bias, shape_factor, shape_scale;
     int32_t shape_invert;             // u_cloud_shape_invert == 1.0           clouds:57
     float shape_lo01, shape_hi01;     // [host] bounds of (shape - 0.1) over every filtered texel value: coverage-first early outs

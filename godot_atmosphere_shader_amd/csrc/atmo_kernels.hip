@@ -1045,9 +1045,21 @@ __device__ __forceinline__ float cloud_density(const RenderConsts &rc, float px,
 }
 
 // exact |p| and (|p| - bottom) / thickness, as a scalar fp32 evaluation would produce them
-__device__ __forceinline__ void cloud_height(const RenderConsts &rc, float px, float py, float pz, float &r, float &hr) {
-    r = exact_sqrt(px * px + py * py + pz * pz);
+__device__ __forceinline__ void cloud_height_r2(const RenderConsts &rc, float r2, float &r, float &hr) {
+    r = exact_sqrt(r2);
     hr = exact_div_uniform(r - rc.clouds_bottom, rc.cloud_thickness, rc.inv_cloud_thickness);
+}
+__device__ __forceinline__ void cloud_height(const RenderConsts &rc, float px, float py, float pz, float &r, float &hr) {
+    cloud_height_r2(rc, px * px + py * py + pz * pz, r, hr);
+}
+// A march step at which NO lane of the wave can be inside the cloud layer skips the exact height chain and the density evaluation (28 % of the
+// steps of a 1920x1080 frame at pose P_space: the stretch of a ray between the bottom shell and the ground).  |p|^2 below rc.layer_r2_lo means
+// r < bottom, hr < 0, above rc.layer_r2_hi r > top, hr >= 1 (margins in fill_consts): hc = 0 and the density is 0 in the exact chain as well.
+#ifndef ATMO_SURE_OUTSIDE
+#define ATMO_SURE_OUTSIDE 1
+#endif
+__device__ __forceinline__ bool wave_may_be_in_layer(const RenderConsts &rc, float r2) {
+    return !ATMO_SURE_OUTSIDE || __builtin_amdgcn_ballot_w64(r2 >= rc.layer_r2_lo && r2 <= rc.layer_r2_hi) != 0ull;
 }
 
 // get_light_raymarched (cloud_funcs.gdshaderinc:104-151): 6 density taps towards the sun.
@@ -1167,9 +1179,12 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
     for (int it = 0; it < iters; ++it) {
         float density = 0.0f, la = 0.0f, lb = 0.0f;
         if (SPLIT == 1 || it * SPLIT + half < steps) {
-            float r, hr;
-            cloud_height(rc, px, py, pz, r, hr);
-            density = cloud_density<true, PRECISE, LOD>(rc, px, py, pz, hr, LOD ? &nb : nullptr);
+            float r = 0.0f, hr = 0.0f;
+            const float r2 = px * px + py * py + pz * pz;
+            if (wave_may_be_in_layer(rc, r2)) {
+                cloud_height_r2(rc, r2, r, hr);
+                density = cloud_density<true, PRECISE, LOD>(rc, px, py, pz, hr, LOD ? &nb : nullptr);
+            }
             // the light value of a zero-density sample (6 more density taps in the raymarched variant) is never observed
             if (density > 0.0f) {
 #pragma clang fp contract(fast)
@@ -1303,9 +1318,12 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
         const int cn = steps - c0 < RMQ_CHUNK ? steps - c0 : RMQ_CHUNK;
         uint32_t lit_bits = 0;
         for (int k = 0; k < cn; ++k) {
-            float r, hr;
-            cloud_height(rc, px, py, pz, r, hr);
-            const float density = cloud_density<true, PRECISE, LOD>(rc, px, py, pz, hr, LOD ? &nb : nullptr);
+            float r = 0.0f, hr = 0.0f, density = 0.0f;
+            const float r2 = px * px + py * py + pz * pz;
+            if (wave_may_be_in_layer(rc, r2)) {
+                cloud_height_r2(rc, r2, r, hr);
+                density = cloud_density<true, PRECISE, LOD>(rc, px, py, pz, hr, LOD ? &nb : nullptr);
+            }
             const bool lit = density > 0.0f;
             float w = 0.0f;
             if (lit) {
