@@ -131,6 +131,26 @@ __device__ __forceinline__ float exact_sqrt(float x) {
     o = (r_up > 0.0f) ? s_up : o;
     return o;
 }
+// The same result from the reciprocal root with one coupled Newton step and a final FMA correction (the sequence hipcc itself emits for
+// sqrtf when denormals are flushed): rsq + 7 fast-class instructions instead of sqrt + 4 fast + 4 slow (compares / selects).  For the
+// cloud chain only, where x = |p|^2 is a normal positive number (x = 0 would give NaN here).  ATMO_SQRT_V2; equal to the IEEE root for every
+// float from 2^-102 up (tools/sqrt_sweep.py: all 2^23 significands of all 230 binades; profiles/round3/ab_sqrt_v2.txt).
+#ifndef ATMO_SQRT_V2
+#define ATMO_SQRT_V2 1
+#endif
+__device__ __forceinline__ float exact_sqrt_pos(float x) {
+#if ATMO_SQRT_V2
+    const float y = hw_rsq(x);
+    float g = x * y, h = 0.5f * y;
+    const float e = __builtin_fmaf(-h, g, 0.5f);
+    h = __builtin_fmaf(h, e, h);
+    g = __builtin_fmaf(g, e, g);
+    const float d = __builtin_fmaf(-g, g, x);
+    return __builtin_fmaf(d, h, g);
+#else
+    return exact_sqrt(x);
+#endif
+}
 // Correctly rounded a / c for a wave-uniform divisor c with rc = RN(1/c) computed on the host (IEEE):
 // two Markstein corrections of a*rc with exact FMA residuals.  5 VALU instead of 11 + v_rcp.
 // (Checked exhaustively on the CPU for every float32 significand of `a` against a / c for the demo's divisors;
@@ -1046,7 +1066,7 @@ __device__ __forceinline__ float cloud_density(const RenderConsts &rc, float px,
 
 // exact |p| and (|p| - bottom) / thickness, as a scalar fp32 evaluation would produce them
 __device__ __forceinline__ void cloud_height_r2(const RenderConsts &rc, float r2, float &r, float &hr) {
-    r = exact_sqrt(r2);
+    r = exact_sqrt_pos(r2);
     hr = exact_div_uniform(r - rc.clouds_bottom, rc.cloud_thickness, rc.inv_cloud_thickness);
 }
 __device__ __forceinline__ void cloud_height(const RenderConsts &rc, float px, float py, float pz, float &r, float &hr) {
@@ -2105,7 +2125,8 @@ __global__ __launch_bounds__(256) void atmo_selftest_kernel(uint32_t first_bits,
     unsigned int bad_sqrt = 0, bad_div = 0;
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
         const float x = __int_as_float((int)(first_bits + k));
-        if (__float_as_int(exact_sqrt(x)) != __float_as_int(ieee_sqrt(x))) ++bad_sqrt;
+        const int want = __float_as_int(ieee_sqrt(x));  // both short forms: the prologue's and the cloud chain's
+        if (__float_as_int(exact_sqrt(x)) != want || __float_as_int(exact_sqrt_pos(x)) != want) ++bad_sqrt;
         if (__float_as_int(exact_div_uniform(x, c, rc)) != __float_as_int(ieee_div(x, c))) ++bad_div;
     }
     if (bad_sqrt) atomicAdd(&mismatch[0], bad_sqrt);
