@@ -295,7 +295,8 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
         const double hi = (double)rc.clouds_top * (double)rc.clouds_top * (1.0 + 2e-6);
         rc.layer_r2_lo = (float)lo;
         rc.layer_r2_hi = (float)hi;
-        if (!(rc.cloud_thickness > 0.0f) || !std::isfinite(rc.layer_r2_hi)) { rc.layer_r2_lo = 0.0f; rc.layer_r2_hi = INFINITY; }  // odd layers: never skip
+        if (!(rc.clouds_bottom > 0.0f)) rc.layer_r2_lo = 0.0f;  // a bottom shell of radius <= 0: |p| < bottom cannot be told from |p|^2
+        if (!(rc.cloud_thickness > 0.0f) || !(rc.clouds_top > 0.0f) || !std::isfinite(rc.layer_r2_hi)) { rc.layer_r2_lo = 0.0f; rc.layer_r2_hi = INFINITY; }  // odd layers: never skip
     }
     rc.cloud_density_scale = p.u_cloud_density_scale;
     rc.cloud_blend = p.u_cloud_blend;

@@ -1291,3 +1291,28 @@ def test_shape_volume_too_large_for_a_float_copy_still_matches_the_oracle(oracle
         want, _ = _oracle_render(oracle32, config_name, params, tex, cam, depth, lut)
         assert np.array_equal(np.all(got == 0.0, axis=-1), np.all(want == 0.0, axis=-1))
         assert np.abs(got - want).max() <= TOL
+
+
+@pytest.mark.parametrize("case", [dict(u_cloud_bottom=0.6, u_cloud_top=0.2), dict(u_cloud_bottom=-13.0, u_cloud_top=0.5),
+                                  dict(u_cloud_bottom=0.3, u_cloud_top=0.30001)],
+                         ids=["inverted_layer", "bottom_shell_of_negative_radius", "paper_thin_layer"])
+def test_degenerate_cloud_layers_follow_the_arithmetic(oracle32, case):
+    """The march skips the exact height chain where |p|^2 says that no lane can be inside the layer (ATMO_SURE_OUTSIDE); the per-frame bounds
+    behind that are only set up for a proper layer (0 < bottom < top).  Degenerate layers -- top below bottom, a bottom shell of negative
+    radius, a layer of a few ulps of the radius (8e-5 units at radius 102.4) -- must keep following the reference's arithmetic, whatever it yields."""
+    tex = demo_textures()
+    params = demo_params(**case)
+    w, h = 160, 90
+    for pose in ("P_space", "P_clouds"):
+        cam = S.Camera.from_pose(w, h, pose)
+        depth = S.depth_ground_sphere(cam)
+        for config_name in ("clouds_high", "clouds_high_rm"):
+            node = make_node(config_name, tex, params)
+            got = _gpu_render(node, cam, depth)
+            lut = node.read_optical_depth()
+            node.close()
+            want, _ = _oracle_render(oracle32, config_name, params, tex, cam, depth, lut)
+            finite = np.isfinite(want).all(axis=-1)
+            assert np.array_equal(np.isfinite(got).all(axis=-1), finite)
+            # degenerate layers produce values far outside [0, 1]: the tolerance is relative there
+            assert (np.abs(got[finite] - want[finite]) / np.maximum(1.0, np.abs(want[finite]))).max() <= TOL, (case, pose, config_name)
