@@ -352,7 +352,7 @@ def _random_scene(rng, k):
     return params, cam, tuple(sun.tolist())
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 + int(__import__("os").environ.get("ATMO_FUZZ_EXTRA", "0"))))  # ATMO_FUZZ_EXTRA=n: n more seeds on demand
 def test_parity_random_scenes(oracle32, seed):
     """Random planets, cameras (inside/outside the atmosphere and the cloud layer), suns, step counts (incl. the
     run-time light-step path and 16/64 view steps), non-power-of-two shape textures and small cubemaps."""
