@@ -916,6 +916,91 @@ __device__ __forceinline__ float4 march_atmosphere_v1(const RenderConsts &rc, V3
 // product of (1 - density * step_len) grows like 1e5 and amplifies the fast form's rsq / fused rounding to 2e-4 relative
 // (found by the executed-reference fuzz, tests/test_reference_exec.py seed 10).  ~3x the instructions of the fast form,
 // still the cheapest kernels of the set.  SPLIT = 2: both lanes of a ray evaluate the whole march (no sharing).
+// ---- compute_atmosphere_v2 in the REFERENCE'S operation order (atmo_set_precision 1 on the no-cloud variants) -----------------------
+// The fast form above keeps one running position relative to the planet centre, sums the view optical depth and takes alpha from it in
+// closed form; the reference accumulates the VIEW-SPACE position, subtracts the centre at every use, and builds alpha step by step
+// (atmosphere_funcs_v2.gdshaderinc:60-82).  In fp32 the two drift apart with the number of view steps (1e-4 of alpha after 64 steps on a
+// thin atmosphere: tools/fuzz_debug.py).  This form follows the reference statement by statement -- unfused, IEEE sqrt / divide, expf,
+// the LUT's bilinear filter as mix(mix(), mix()) on clamped texels, the direct light march as get_optical_depth writes it -- at about
+// twice the instructions; it exists so that parity can be had to a few 1e-6 where it matters, not for the benchmarks.
+__device__ __forceinline__ float precise_density(const RenderConsts &rc, float dist) {  // get_atmosphere_density, atmosphere_common:12-24
+    const float sd = dist - rc.planet_radius;
+    const float h = fminf(fmaxf(ieee_div(sd, rc.atmosphere_height), 0.0f), 1.0f);
+    const float y = 1.0f - h;
+    return y * y * y * rc.density;
+}
+__device__ __forceinline__ float precise_lut(const RenderConsts &rc, float u, float v) {  // texture(u_optical_depth_texture, uv).r, clamp, linear
+    const int w = rc.lut_w, h = rc.lut_h, st = w + 2;
+    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    const float xf = floorf(x), yf = floorf(y);
+    const float fx = x - xf, fy = y - yf;
+    const int i0 = min(max((int)xf, 0), w - 1), i1 = min(max((int)xf + 1, 0), w - 1);
+    const int j0 = min(max((int)yf, 0), h - 1), j1 = min(max((int)yf + 1, 0), h - 1);
+    const float *t = rc.lut + st + 1;  // texel (0, 0) inside the apron
+    const float t00 = t[j0 * st + i0], t10 = t[j0 * st + i1], t01 = t[j1 * st + i0], t11 = t[j1 * st + i1];
+    return mixf(mixf(t00, t10, fx), mixf(t01, t11, fx), fy);
+}
+template <bool DIRECT>
+__device__ __forceinline__ float4 march_atmosphere_v2_precise(const RenderConsts &rc, V3 dir, float t_begin, float t_end, float jitter) {
+    const int steps = rc.view_steps;
+    const V3 c = {rc.center[0], rc.center[1], rc.center[2]}, sun = {rc.sun_dir[0], rc.sun_dir[1], rc.sun_dir[2]};
+    const float step_len = ieee_div(t_end - t_begin, (float)steps);
+    float lr = 0.0f, lg = 0.0f, lb = 0.0f, view_od = 0.0f, alpha = 0.0f;
+    V3 pos = {0.0f + dir.x * t_begin, 0.0f + dir.y * t_begin, 0.0f + dir.z * t_begin};  // ray_origin (0) + ray_dir * t_begin
+    for (int i = 0; i < steps; ++i) {
+        const V3 oc = {pos.x - c.x, pos.y - c.y, pos.z - c.z};
+        const float dist = ieee_sqrt(oc.x * oc.x + oc.y * oc.y + oc.z * oc.z);
+        float sun_od;
+        if (DIRECT) {
+            // get_optical_depth over the chord to the outer sphere (optical_depth.gdshader:17-31,56-65), light_steps left-Riemann samples
+            const float b = oc.x * sun.x + oc.y * sun.y + oc.z * sun.z;
+            const V3 qc = {oc.x - sun.x * b, oc.y - sun.y * b, oc.z - sun.z * b};
+            float hh = rc.atmosphere_radius * rc.atmosphere_radius - (qc.x * qc.x + qc.y * qc.y + qc.z * qc.z);
+            float x0 = 1000000.0f, x1 = 1000000.0f;
+            if (!(hh < 0.0f)) {
+                hh = ieee_sqrt(hh);
+                x0 = -b - hh;
+                x1 = -b + hh;
+            }
+            const float ray_len = x1 - fmaxf(x0, 0.0f);
+            const float lstep = ieee_div(ray_len, (float)rc.light_steps);
+            const V3 ls = {sun.x * lstep, sun.y * lstep, sun.z * lstep};
+            sun_od = 0.0f;
+            for (int j = 0; j < rc.light_steps; ++j) {
+                const float fj = (float)j;
+                const V3 p = {pos.x + ls.x * fj, pos.y + ls.y * fj, pos.z + ls.z * fj};
+                const V3 d = {p.x - c.x, p.y - c.y, p.z - c.z};
+                const float density = precise_density(rc, ieee_sqrt(d.x * d.x + d.y * d.y + d.z * d.z));
+                sun_od += density * lstep * rc.density;
+            }
+        } else {
+            // get_baked_optical_depth (v2:14-29)
+            const float height = dist - rc.planet_radius;
+            const float height_ratio = fminf(fmaxf(ieee_div(height, rc.atmosphere_height), 0.0f), 1.0f);
+            const float inv = ieee_div(1.0f, dist);
+            const V3 up = {oc.x * inv, oc.y * inv, oc.z * inv};
+            const float uvx = 0.5f + 0.5f * (up.x * sun.x + up.y * sun.y + up.z * sun.z);
+            sun_od = precise_lut(rc, uvx, height_ratio);
+        }
+        const float local_density = precise_density(rc, dist) * rc.density;
+        view_od += local_density * step_len;
+        const float od = sun_od + view_od;
+        const float tr = expf(-od * rc.coeff[0]), tg = expf(-od * rc.coeff[1]), tb = expf(-od * rc.coeff[2]);
+        lr += local_density * step_len * tr * rc.coeff[0];
+        lg += local_density * step_len * tg * rc.coeff[1];
+        lb += local_density * step_len * tb * rc.coeff[2];
+        const float vt = expf(-local_density * step_len);
+        alpha += (1.0f - vt) * (1.0f - alpha);
+        pos = V3{pos.x + dir.x * step_len, pos.y + dir.y * step_len, pos.z + dir.z * step_len};
+    }
+    float4 o;
+    o.x = fminf(fmaxf(lr + rc.ambient[0], 0.0f), 1.0f) * rc.modulate[0];
+    o.y = fminf(fmaxf(lg + rc.ambient[1], 0.0f), 1.0f) * rc.modulate[1];
+    o.z = fminf(fmaxf(lb + rc.ambient[2], 0.0f), 1.0f) * rc.modulate[2];
+    o.w = fminf(fmaxf(alpha + jitter * 0.02f, 0.0f), 0.99f);
+    return o;
+}
+
 __device__ __forceinline__ float4 march_atmosphere_v1_precise(const RenderConsts &rc, V3 dir, float t_begin, float t_end) {
 #pragma clang fp contract(off)
     const float inv_steps = ieee_div(1.0f, (float)rc.view_steps);
@@ -1598,8 +1683,12 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
         if constexpr (PRECISE) rgba = march_atmosphere_v1_precise(rc, dir, t_begin, t_end);
         else rgba = march_atmosphere_v1<SPLIT>(rc, dir, t_begin, t_end, half);  // main:172-175
     } else {
-        const float view_step_len = ieee_div(t_end - t_begin, (float)rc.view_steps);
-        rgba = march_atmosphere<DIRECT, LSTEPS, SPLIT>(rc, dir, t_begin, view_step_len, jitter, half);
+        if constexpr (PRECISE && !CLOUDS && SPLIT == 1) {
+            rgba = march_atmosphere_v2_precise<DIRECT>(rc, dir, t_begin, t_end, jitter);  // reference order (atmo_set_precision 1, no-cloud variants)
+        } else {
+            const float view_step_len = ieee_div(t_end - t_begin, (float)rc.view_steps);
+            rgba = march_atmosphere<DIRECT, LSTEPS, SPLIT>(rc, dir, t_begin, view_step_len, jitter, half);
+        }
     }
 
     if (CLOUDS) {
@@ -2175,6 +2264,9 @@ hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream
     case KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT: return launch_direct<KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT>(rc, split, stream);
     case KF_LITE: return launch_t<KF_LITE, 0>(rc, split, stream);
     case KF_LITE | KF_CLOUDS: return launch_t<KF_LITE | KF_CLOUDS, 0>(rc, split, stream);
+    // the v2 atmosphere in the reference's operation order (atmo_set_precision 1 on a no-cloud context), one lane per ray
+    case KF_PRECISE: return launch_s<KF_PRECISE, 0, 1>(rc, stream);
+    case KF_PRECISE | KF_LIGHT_DIRECT: return launch_s<KF_PRECISE | KF_LIGHT_DIRECT, 0, 1>(rc, stream);
     // precise cloud density (atmo_set_precision 1, the default of the cloud variants)
     case KF_PRECISE | KF_CLOUDS: return launch_t<KF_PRECISE | KF_CLOUDS, 0>(rc, split, stream);
     case KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT: return launch_direct<KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT>(rc, split, stream);
@@ -2201,7 +2293,8 @@ hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream
 const char *render_kernel_name(int flags, int light_steps, int split) {
     // demangled template name as rocprofv3 prints it: atmo_render_kernel<FLAGS, LSTEPS, SPLIT>
     static thread_local char name[64];
-    const int lsteps = ((flags & KF_LIGHT_DIRECT) && light_steps == 8) ? 8 : 0;
+    const bool v2_precise = (flags & KF_PRECISE) && !(flags & (KF_CLOUDS | KF_LITE));  // its light march is a run-time loop
+    const int lsteps = ((flags & KF_LIGHT_DIRECT) && light_steps == 8 && !v2_precise) ? 8 : 0;
     snprintf(name, sizeof(name), "atmo_render_kernel<%d, %d, %d>", flags, lsteps, split == 2 ? 2 : 1);
     return name;
 }

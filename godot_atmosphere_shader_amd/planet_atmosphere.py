@@ -214,7 +214,7 @@ class PlanetAtmosphere:
 
     def __init__(self, device: int = 0, light_mode: str = "lut", light_steps: int = 0,
                  view_steps: int | None = None, cloud_steps: int | None = None, blue_noise=None,
-                 precise_clouds: bool = True, double_precision: bool = False, lane_split: int = 0,
+                 precise_clouds: bool = True, precise_atmosphere: bool = False, double_precision: bool = False, lane_split: int = 0,
                  tile_feedback: int = -1, cubemap_lod: bool = False):
         self._lib = N.load()
         self._device = int(device)
@@ -223,6 +223,7 @@ class PlanetAtmosphere:
         self._view_steps_override = view_steps    # macro override of ATMOSPHERE_RAYMARCH_STEPS
         self._cloud_steps_override = cloud_steps  # macro override of CLOUDS_MAX_RAYMARCH_STEPS
         self._precise_clouds = bool(precise_clouds)  # atmo_set_precision: bit-faithful cloud density (default); False = fast mode
+        self._precise_atmosphere = bool(precise_atmosphere)  # atmo_set_precision 2: the v2 atmosphere march of a no-cloud variant in reference order
         self._double_precision = bool(double_precision)  # `#define DOUBLE_PRECISION` (main:25): engine negates INV_VIEW origin
         self._lane_split = int(lane_split)  # atmo_set_lane_split: 0 auto, 1 / 2 lanes per ray
         self._tile_feedback = int(tile_feedback)  # atmo_set_tile_feedback: -1 default (on), 0 off, 1 on
@@ -261,7 +262,7 @@ class PlanetAtmosphere:
         rc = self._lib.atmo_create(self._device, sh.variant, vs, cs, self._light_mode, self._light_steps, C.byref(ctx))
         N.check(None, rc)
         self._ctx = ctx
-        N.check(ctx, self._lib.atmo_set_precision(ctx, 1 if self._precise_clouds else 0))
+        N.check(ctx, self._lib.atmo_set_precision(ctx, 2 if self._precise_atmosphere else (1 if self._precise_clouds else 0)))
         N.check(ctx, self._lib.atmo_set_host_double_precision(ctx, 1 if self._double_precision else 0))
         N.check(ctx, self._lib.atmo_set_lane_split(ctx, self._lane_split))
         N.check(ctx, self._lib.atmo_set_tile_feedback(ctx, self._tile_feedback))

@@ -1316,3 +1316,53 @@ def test_degenerate_cloud_layers_follow_the_arithmetic(oracle32, case):
             assert np.array_equal(np.isfinite(got).all(axis=-1), finite)
             # degenerate layers produce values far outside [0, 1]: the tolerance is relative there
             assert (np.abs(got[finite] - want[finite]) / np.maximum(1.0, np.abs(want[finite]))).max() <= TOL, (case, pose, config_name)
+
+
+def test_reference_order_v2_atmosphere(oracle32):
+    """atmo_set_precision(ctx, 2) on a no-cloud v2 context: the atmosphere march in the reference's operation order (view-space position
+    accumulated, centre subtracted at every use, alpha built step by step, IEEE sqrt / divide, expf).  Held to 1e-5 -- ten times tighter than
+    the contract -- on the demo poses in both light modes, and on the two random scenes where the default form's running sums reach 1.07e-4
+    with 64 view steps; the default form stays within the 1e-4 contract on the demo poses."""
+    from godot_atmosphere_shader_amd import PlanetAtmosphere, load_shader
+    from godot_atmosphere_shader_amd.planet_atmosphere import make_frame
+
+    tex, params = demo_textures(), demo_params()
+    w, h = 192, 108
+    worst = {}
+    for config_name in ("no_clouds_32_lut", "no_clouds_32x8_direct", "no_clouds_8"):
+        for pose in ("P_space", "P_limb", "P_ground"):
+            cam = S.Camera.from_pose(w, h, pose)
+            depth = S.depth_ground_sphere(cam)
+            node = make_node(config_name, tex, params, precise_atmosphere=True)
+            got = _gpu_render(node, cam, depth)
+            assert int(node.kernel_name.split("<")[1].split(",")[0]) & 16, node.kernel_name
+            lut = node.read_optical_depth() if _uses_lut(config_name) else None
+            node.close()
+            want, _ = _oracle_render(oracle32, config_name, params, tex, cam, depth, lut)
+            assert np.array_equal(np.all(got == 0.0, axis=-1), np.all(want == 0.0, axis=-1))
+            worst[config_name] = max(worst.get(config_name, 0.0), float(np.abs(got - want).max()))
+    print("\nreference-order v2 march, max |HIP - oracle| on the demo poses:", {k: f"{v:.2e}" for k, v in worst.items()})
+    assert max(worst.values()) <= 1e-5
+    for seed in (55, 91):
+        rng = np.random.default_rng(1000 + seed)
+        p, cam, sun = _random_scene(rng, seed)
+        bn = S.make_blue_noise(seed + 1)
+        depth = S.depth_ground_sphere(cam, radius=p["u_planet_radius"]) if seed % 3 else S.depth_far(cam)
+        errs = {}
+        for precise in (True, False):
+            node = PlanetAtmosphere(blue_noise=bn, view_steps=64, light_mode="direct", light_steps=5, precise_atmosphere=precise)
+            node.custom_shader = load_shader("planet_atmosphere_no_clouds")
+            node.planet_radius, node.atmosphere_height, node.sun_path = p["u_planet_radius"], p["u_atmosphere_height"], sun
+            for k, v in p.items():
+                if "cloud" not in k and k not in ("u_planet_radius", "u_atmosphere_height", "u_world_to_model_matrix"):
+                    node.set(f"shader_params/{k}", v)
+            node._process(0.0, cam, time=0.0)
+            got = _gpu_render(node, cam, depth)
+            node.close()
+            p2 = dict(p, u_atmosphere_modulate=tuple(S.srgb_to_linear(p["u_atmosphere_modulate"]).tolist()),
+                      u_atmosphere_ambient_color=tuple(S.srgb_to_linear(p["u_atmosphere_ambient_color"]).tolist()))
+            want, _ = oracle32.render(p2, dict(blue_noise=bn, optical_depth=None), dict(view_steps=64, light_steps=5),
+                                      make_frame(cam, np.eye(4), sun), depth, nthreads=8)
+            errs[precise] = float(np.abs(got - want).max())
+        print(f"seed {seed}, 64 view steps: reference order {errs[True]:.2e}, default form {errs[False]:.2e}")
+        assert errs[True] <= 1e-5 and errs[True] < 0.2 * errs[False]

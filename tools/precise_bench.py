@@ -1,0 +1,10 @@
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch, bench
+from godot_atmosphere_shader_amd import scene as S
+from godot_atmosphere_shader_amd.demo import demo_params, demo_textures
+tex, params = demo_textures(), demo_params()
+for wl in ("direct32x8", "lut32", "shipped8"):
+    for pa in (False, True):
+        r = bench.run_workload(torch, S, wl, 1920, 1080, "P_space", 60, 8, tex, params, 0, with_frame_stats=False, node_extra=dict(precise_atmosphere=pa))
+        print(wl, "reference order" if pa else "default", round(r["Mrays/s"]), "Mrays/s", round(r["kernel_avg_ms"], 4), "ms", r.get("kernel"))
