@@ -380,7 +380,7 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
 // 5-40 % elsewhere (profiles/round2/ab_lane_split.txt), so "auto" (0) is one lane per ray.
 int choose_split(const AtmoContext *ctx, const AtmoFrame *f) {
     (void)f;
-    if ((ctx->flags & atmo::KF_PRECISE) && !(ctx->flags & (atmo::KF_CLOUDS | atmo::KF_LITE))) return 1;  // the reference-order v2 march has one launch shape
+    if (ctx->flags & atmo::KF_ATMO_REF) return 1;  // the reference-order v2 march has one launch shape
     if (ctx->env_split) return ctx->env_split;
     return ctx->lane_split == 2 ? 2 : 1;
 }
@@ -1128,6 +1128,8 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         // implicit cubemap LOD: needs a mip chain; available for the precise cloud kernels (either light mode), one lane per ray
         if (!(flags & atmo::KF_PRECISE))
             return fail(ctx, ATMO_E_STATE, "atmo_render: the implicit cubemap LOD (atmo_set_sampler_lod 1) needs the precise cloud mode (atmo_set_precision 1)");
+        if (flags & atmo::KF_ATMO_REF)
+            return fail(ctx, ATMO_E_STATE, "atmo_render: atmo_set_precision 2 (reference-order atmosphere march) is not available together with the implicit cubemap LOD (atmo_set_sampler_lod 1)");
         flags |= atmo::KF_CUBE_LOD;
         split = 1;
     }
@@ -1294,11 +1296,12 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
 int atmo_set_precision(AtmoContext *ctx, int mode) {
     if (!ctx) return ATMO_E_ARG;
     if (mode < 0 || mode > 2) return fail(ctx, ATMO_E_ARG, "atmo_set_precision: mode must be 0 (fast), 1 (precise) or 2 (precise, and the v2 atmosphere march of the no-cloud variants in reference order)");
-    const bool v2_no_clouds = !(ctx->flags & (atmo::KF_CLOUDS | atmo::KF_LITE));
-    // 1: reference operation order for the cloud density and the v1 march (their default); 2: also for the v2 atmosphere march of a
-    // no-cloud context (march_atmosphere_v2_precise), which mode 1 leaves in its fast form
-    if ((mode >= 1 && !v2_no_clouds) || (mode == 2 && v2_no_clouds)) ctx->flags |= atmo::KF_PRECISE;
+    // 1: reference operation order for the cloud density and the v1 march (their default); 2: also for the v2 atmosphere march
+    // (march_atmosphere_v2_precise; the v1 variants have no other form), which modes 0 and 1 leave in its fast form
+    if (mode >= 1 && (ctx->flags & (atmo::KF_CLOUDS | atmo::KF_LITE))) ctx->flags |= atmo::KF_PRECISE;
     else ctx->flags &= ~atmo::KF_PRECISE;
+    if (mode == 2 && !(ctx->flags & atmo::KF_LITE)) ctx->flags |= atmo::KF_ATMO_REF;
+    else ctx->flags &= ~atmo::KF_ATMO_REF;
     return ATMO_OK;
 }
 

@@ -101,7 +101,8 @@ struct NoiseCubemapConsts {
 };
 
 // kernel launchers (atmo_kernels.hip)
-enum KernelFlags : int { KF_CLOUDS = 1, KF_CLOUD_LIGHT_RM = 2, KF_LIGHT_DIRECT = 4, KF_LITE = 8, KF_PRECISE = 16, KF_CUBE_LOD = 32 };
+enum KernelFlags : int { KF_CLOUDS = 1, KF_CLOUD_LIGHT_RM = 2, KF_LIGHT_DIRECT = 4, KF_LITE = 8, KF_PRECISE = 16, KF_CUBE_LOD = 32,
+                          KF_ATMO_REF = 64 /* the v2 atmosphere march in the reference's operation order (atmo_set_precision 2) */ };
 
 hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream_t stream);
 hipError_t launch_bake(const BakeConsts &bc, hipStream_t stream);

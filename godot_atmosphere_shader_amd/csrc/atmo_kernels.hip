@@ -922,7 +922,7 @@ __device__ __forceinline__ float4 march_atmosphere_v1(const RenderConsts &rc, V3
 // (atmosphere_funcs_v2.gdshaderinc:60-82).  In fp32 the two drift apart with the number of view steps (1e-4 of alpha after 64 steps on a
 // thin atmosphere: tools/fuzz_debug.py).  This form follows the reference statement by statement -- unfused, IEEE sqrt / divide, expf,
 // the LUT's bilinear filter as mix(mix(), mix()) on clamped texels, the direct light march as get_optical_depth writes it -- at about
-// twice the instructions; it exists so that parity can be had to a few 1e-6 where it matters, not for the benchmarks.
+// two to five times the time; it exists so that parity can be had to 1e-6 where it matters, not for the benchmarks (KF_ATMO_REF).
 __device__ __forceinline__ float precise_density(const RenderConsts &rc, float dist) {  // get_atmosphere_density, atmosphere_common:12-24
     const float sd = dist - rc.planet_radius;
     const float h = fminf(fmaxf(ieee_div(sd, rc.atmosphere_height), 0.0f), 1.0f);
@@ -1588,6 +1588,7 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
     constexpr bool LITE = (FLAGS & KF_LITE) != 0;
     constexpr bool PRECISE = (FLAGS & KF_PRECISE) != 0;
     constexpr bool LOD = (FLAGS & KF_CUBE_LOD) != 0;
+    constexpr bool ATMO_REF = (FLAGS & KF_ATMO_REF) != 0;
     constexpr bool DIET = ATMO_PROLOGUE_DIET && !DIRECT && !((FLAGS & KF_CLOUDS) && (FLAGS & KF_CLOUD_LIGHT_RM));
     constexpr bool FASTMISS = (ATMO_FAST_MISS_MASK >> ((DIRECT ? 1 : 0) + (CLOUDS ? 2 : 0) + (LITE ? 4 : 0))) & 1;
     static_assert(!LOD || (CLOUDS && PRECISE && SPLIT == 1), "implicit cubemap LOD: precise cloud kernels, one lane per ray");
@@ -1683,8 +1684,8 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
         if constexpr (PRECISE) rgba = march_atmosphere_v1_precise(rc, dir, t_begin, t_end);
         else rgba = march_atmosphere_v1<SPLIT>(rc, dir, t_begin, t_end, half);  // main:172-175
     } else {
-        if constexpr (PRECISE && !CLOUDS && SPLIT == 1) {
-            rgba = march_atmosphere_v2_precise<DIRECT>(rc, dir, t_begin, t_end, jitter);  // reference order (atmo_set_precision 1, no-cloud variants)
+        if constexpr (ATMO_REF && SPLIT == 1) {
+            rgba = march_atmosphere_v2_precise<DIRECT>(rc, dir, t_begin, t_end, jitter);  // reference order (atmo_set_precision 2)
         } else {
             const float view_step_len = ieee_div(t_end - t_begin, (float)rc.view_steps);
             rgba = march_atmosphere<DIRECT, LSTEPS, SPLIT>(rc, dir, t_begin, view_step_len, jitter, half);
@@ -2264,9 +2265,14 @@ hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream
     case KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT: return launch_direct<KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT>(rc, split, stream);
     case KF_LITE: return launch_t<KF_LITE, 0>(rc, split, stream);
     case KF_LITE | KF_CLOUDS: return launch_t<KF_LITE | KF_CLOUDS, 0>(rc, split, stream);
-    // the v2 atmosphere in the reference's operation order (atmo_set_precision 1 on a no-cloud context), one lane per ray
-    case KF_PRECISE: return launch_s<KF_PRECISE, 0, 1>(rc, stream);
-    case KF_PRECISE | KF_LIGHT_DIRECT: return launch_s<KF_PRECISE | KF_LIGHT_DIRECT, 0, 1>(rc, stream);
+    // the v2 atmosphere in the reference's operation order (atmo_set_precision 2), one lane per ray, run-time light-step loop
+    case KF_ATMO_REF: return launch_s<KF_ATMO_REF, 0, 1>(rc, stream);
+    case KF_ATMO_REF | KF_LIGHT_DIRECT: return launch_s<KF_ATMO_REF | KF_LIGHT_DIRECT, 0, 1>(rc, stream);
+    case KF_ATMO_REF | KF_PRECISE | KF_CLOUDS: return launch_s<KF_ATMO_REF | KF_PRECISE | KF_CLOUDS, 0, 1>(rc, stream);
+    case KF_ATMO_REF | KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT: return launch_s<KF_ATMO_REF | KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT, 0, 1>(rc, stream);
+    case KF_ATMO_REF | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM: return launch_s<KF_ATMO_REF | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM, 0, 1>(rc, stream);
+    case KF_ATMO_REF | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT:
+        return launch_s<KF_ATMO_REF | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT, 0, 1>(rc, stream);
     // precise cloud density (atmo_set_precision 1, the default of the cloud variants)
     case KF_PRECISE | KF_CLOUDS: return launch_t<KF_PRECISE | KF_CLOUDS, 0>(rc, split, stream);
     case KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT: return launch_direct<KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT>(rc, split, stream);
@@ -2293,7 +2299,7 @@ hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream
 const char *render_kernel_name(int flags, int light_steps, int split) {
     // demangled template name as rocprofv3 prints it: atmo_render_kernel<FLAGS, LSTEPS, SPLIT>
     static thread_local char name[64];
-    const bool v2_precise = (flags & KF_PRECISE) && !(flags & (KF_CLOUDS | KF_LITE));  // its light march is a run-time loop
+    const bool v2_precise = (flags & KF_ATMO_REF) != 0;  // its light march is a run-time loop
     const int lsteps = ((flags & KF_LIGHT_DIRECT) && light_steps == 8 && !v2_precise) ? 8 : 0;
     snprintf(name, sizeof(name), "atmo_render_kernel<%d, %d, %d>", flags, lsteps, split == 2 ? 2 : 1);
     return name;

@@ -211,11 +211,12 @@ int atmo_measure_tile_costs(AtmoContext *ctx, const AtmoFrame *frame, const floa
  * 0 (fast): the well-conditioned part of the density expression runs fused: ~15 % more cloud-kernel throughput, max
  *   deviation 5.1e-5 at 1920x1080 and 6.9e-5 at 3840x2160 on the demo scene, but it grows with u_cloud_density_scale
  *   (1.8e-4 at 10x the demo's value), i.e. the 1e-4 contract is scene-dependent in this mode.
- * 2: as 1, and on the no-cloud v2 variants the atmosphere march itself runs in the reference's operation order (view-space
+ * 2: as 1, and the v2 atmosphere march itself runs in the reference's operation order (view-space
  *   position accumulated and the centre subtracted at every use, alpha built step by step, IEEE sqrt / divide, expf,
  *   unfused): a fifth (direct light march) to a half (8 view steps, baked LUT) of the default form's throughput, deviation
  *   from a scalar fp32 evaluation of the GDShader below 1e-6 whatever the step count.  The default form's running sums drift with the number of view steps (up to 1.1e-4 of alpha
- *   at 64 steps on a thin atmosphere); modes 0 and 1 leave it in place, and so does mode 2 on the cloud variants.
+ *   at 64 steps on a thin atmosphere); modes 0 and 1 leave it in place.  Not available together with atmo_set_sampler_lod 1
+ *   (atmo_render then fails with ATMO_E_STATE); the v1 variants have had the reference order since mode 1.
  */
 int atmo_set_precision(AtmoContext *ctx, int mode);
 

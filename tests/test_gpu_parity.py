@@ -1319,7 +1319,7 @@ def test_degenerate_cloud_layers_follow_the_arithmetic(oracle32, case):
 
 
 def test_reference_order_v2_atmosphere(oracle32):
-    """atmo_set_precision(ctx, 2) on a no-cloud v2 context: the atmosphere march in the reference's operation order (view-space position
+    """atmo_set_precision(ctx, 2): the v2 atmosphere march in the reference's operation order (view-space position
     accumulated, centre subtracted at every use, alpha built step by step, IEEE sqrt / divide, expf).  Held to 1e-5 -- ten times tighter than
     the contract -- on the demo poses in both light modes, and on the two random scenes where the default form's running sums reach 1.07e-4
     with 64 view steps; the default form stays within the 1e-4 contract on the demo poses."""
@@ -1335,7 +1335,7 @@ def test_reference_order_v2_atmosphere(oracle32):
             depth = S.depth_ground_sphere(cam)
             node = make_node(config_name, tex, params, precise_atmosphere=True)
             got = _gpu_render(node, cam, depth)
-            assert int(node.kernel_name.split("<")[1].split(",")[0]) & 16, node.kernel_name
+            assert int(node.kernel_name.split("<")[1].split(",")[0]) & 64, node.kernel_name
             lut = node.read_optical_depth() if _uses_lut(config_name) else None
             node.close()
             want, _ = _oracle_render(oracle32, config_name, params, tex, cam, depth, lut)
@@ -1343,6 +1343,22 @@ def test_reference_order_v2_atmosphere(oracle32):
             worst[config_name] = max(worst.get(config_name, 0.0), float(np.abs(got - want).max()))
     print("\nreference-order v2 march, max |HIP - oracle| on the demo poses:", {k: f"{v:.2e}" for k, v in worst.items()})
     assert max(worst.values()) <= 1e-5
+    # the cloud variants: precise cloud density (their default) + the reference-order atmosphere under it
+    cworst = {}
+    for config_name in ("clouds", "clouds_high", "clouds_high_rm"):
+        for pose in ("P_space", "P_clouds", "P_limb"):
+            cam = S.Camera.from_pose(w, h, pose)
+            depth = S.depth_ground_sphere(cam)
+            node = make_node(config_name, tex, params, precise_atmosphere=True)
+            got = _gpu_render(node, cam, depth)
+            assert int(node.kernel_name.split("<")[1].split(",")[0]) & 64, node.kernel_name
+            lut = node.read_optical_depth()
+            node.close()
+            want, _ = _oracle_render(oracle32, config_name, params, tex, cam, depth, lut)
+            assert np.array_equal(np.all(got == 0.0, axis=-1), np.all(want == 0.0, axis=-1))
+            cworst[config_name] = max(cworst.get(config_name, 0.0), float(np.abs(got - want).max()))
+    print("the same under the cloud variants:", {k: f"{v:.2e}" for k, v in cworst.items()})
+    assert max(cworst.values()) <= 1e-5
     for seed in (55, 91):
         rng = np.random.default_rng(1000 + seed)
         p, cam, sun = _random_scene(rng, seed)

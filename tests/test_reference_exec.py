@@ -761,6 +761,19 @@ def test_hip_reference_order_march_equals_the_executed_reference_to_2e_6(vectors
             got = _gpu_render(node, cam, vectors[f"depth_demo_{pose}"])
             worst[f"{steps} steps"] = max(worst.get(f"{steps} steps", 0.0), float(np.abs(got - r3[f"steps{steps}_rgba_{pose}"]).max()))
         node.close()
+    # the cloud variants (precise cloud density + the reference-order atmosphere under it), demo scene
+    for shader in ("planet_atmosphere_clouds", "planet_atmosphere_clouds_high", "planet_atmosphere_clouds_high_rm"):
+        params, model = _scene("demo")
+        node = make_node(NODE_CONFIG[shader], textures, params, precise_atmosphere=True)
+        node.global_transform = model
+        for pose in RS.POSES:
+            cam = RS.camera_from_fixture(vectors, RS.W, RS.H, pose)
+            node._process(0.0, cam, time=0.0)
+            node.set_shader_parameter("u_cloud_coverage_rotation", np.asarray(params["u_cloud_coverage_rotation"], dtype=np.float32))
+            got = _gpu_render(node, cam, vectors[f"depth_demo_{pose}"])
+            want = vectors[f"rgba_demo_{pose}_{shader}"]
+            worst[shader] = max(worst.get(shader, 0.0), float(np.abs(got - want).max()))
+        node.close()
     print("\nreference-order v2 march vs the executed reference:", {k: f"{v:.2e}" for k, v in worst.items()})
     assert max(worst.values()) <= 2e-6
 
