@@ -375,7 +375,8 @@ def test_parity_random_scenes(oracle32, seed):
     ]
     shader, ocfg, kw = variants[seed % len(variants)]
     depth = S.depth_ground_sphere(cam, radius=params["u_planet_radius"]) if seed % 3 else S.depth_far(cam)
-    node = PlanetAtmosphere(blue_noise=tex["blue_noise"], **kw)
+    ref_order = bool(__import__("os").environ.get("ATMO_FUZZ_PRECISE"))  # ATMO_FUZZ_PRECISE=1: atmo_set_precision 2, tighter bars below
+    node = PlanetAtmosphere(blue_noise=tex["blue_noise"], precise_atmosphere=ref_order, **kw)
     node.custom_shader = load_shader(shader)
     node.planet_radius, node.atmosphere_height, node.sun_path = params["u_planet_radius"], params["u_atmosphere_height"], sun
     for k, v in params.items():
@@ -399,7 +400,9 @@ def test_parity_random_scenes(oracle32, seed):
     assert np.array_equal(np.isfinite(got), finite)
     # clouds are HDR (light unclamped): tolerance is absolute 1e-4 up to 1.0, relative above
     err = np.abs(got - want)[finite] / np.maximum(1.0, np.abs(want[finite]))
-    assert err.size == 0 or err.max() <= TOL, f"seed {seed} {shader} {ocfg}: {err.max():.3e} (hits {hits})"
+    # reference-order atmosphere: 1e-5 on the no-cloud variants; the cloud march keeps its hardware exp2 / rcp and fused light block: 5e-5
+    bar = TOL if not ref_order else (5e-5 if "cloud" in shader.replace("no_clouds", "") else 1e-5)
+    assert err.size == 0 or err.max() <= bar, f"seed {seed} {shader} {ocfg}: {err.max():.3e} (hits {hits})"
 
 
 def test_user_supplied_lut_of_other_size(oracle32):
