@@ -1128,8 +1128,8 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         // implicit cubemap LOD: needs a mip chain; available for the precise cloud kernels (either light mode), one lane per ray
         if (!(flags & atmo::KF_PRECISE))
             return fail(ctx, ATMO_E_STATE, "atmo_render: the implicit cubemap LOD (atmo_set_sampler_lod 1) needs the precise cloud mode (atmo_set_precision 1)");
-        if (flags & atmo::KF_ATMO_REF)
-            return fail(ctx, ATMO_E_STATE, "atmo_render: atmo_set_precision 2 (reference-order atmosphere march) is not available together with the implicit cubemap LOD (atmo_set_sampler_lod 1)");
+        if ((flags & atmo::KF_ATMO_REF) && (flags & atmo::KF_LIGHT_DIRECT))
+            return fail(ctx, ATMO_E_STATE, "atmo_render: atmo_set_precision 2 together with the implicit cubemap LOD (atmo_set_sampler_lod 1) is built for the baked-LUT light mode only");
         flags |= atmo::KF_CUBE_LOD;
         split = 1;
     }

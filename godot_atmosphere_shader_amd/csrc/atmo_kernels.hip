@@ -2273,6 +2273,10 @@ hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream
     case KF_ATMO_REF | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM: return launch_s<KF_ATMO_REF | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM, 0, 1>(rc, stream);
     case KF_ATMO_REF | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT:
         return launch_s<KF_ATMO_REF | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT, 0, 1>(rc, stream);
+    // ... under the declared cubemap sampler (baked-LUT light)
+    case KF_ATMO_REF | KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS: return launch_s<KF_ATMO_REF | KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS, 0, 1>(rc, stream);
+    case KF_ATMO_REF | KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM:
+        return launch_s<KF_ATMO_REF | KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM, 0, 1>(rc, stream);
     // precise cloud density (atmo_set_precision 1, the default of the cloud variants)
     case KF_PRECISE | KF_CLOUDS: return launch_t<KF_PRECISE | KF_CLOUDS, 0>(rc, split, stream);
     case KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT: return launch_direct<KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT>(rc, split, stream);

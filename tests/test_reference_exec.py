@@ -776,6 +776,19 @@ def test_hip_reference_order_march_equals_the_executed_reference_to_2e_6(vectors
         node.close()
     print("\nreference-order v2 march vs the executed reference:", {k: f"{v:.2e}" for k, v in worst.items()})
     assert max(worst.values()) <= 2e-6
+    # ... and under the DECLARED cubemap sampler (implicit LOD; the derivative transform uses a plain v_rcp: lambda moves by ~1e-7)
+    lod = {}
+    for shader in ("planet_atmosphere_clouds_high", "planet_atmosphere_clouds_high_rm"):
+        params, model = _scene("demo")
+        node = make_node(NODE_CONFIG[shader], textures, params, cubemap_lod=True, precise_atmosphere=True)
+        for pose in RS.LOD_POSES:
+            cam = RS.camera_from_fixture(vectors, RS.W, RS.H, pose)
+            got = _gpu_render(node, cam, vectors[f"depth_demo_{pose}"])
+            lod[shader] = max(lod.get(shader, 0.0), _rel_err(got, r3[f"lod_rgba_{pose}_{shader}"]))
+        assert int(node.kernel_name.split("<")[1].split(",")[0]) & 96 == 96  # KF_CUBE_LOD | KF_ATMO_REF
+        node.close()
+    print("the same with the declared sampler:", {k: f"{v:.2e}" for k, v in lod.items()})
+    assert max(lod.values()) <= 1e-5
 
 
 @pytest.mark.gpu
