@@ -227,6 +227,11 @@ def test_c_abi_error_codes():
     assert lib.atmo_render(ctx, C.byref(f), C.c_void_p(depth.data_ptr()), C.c_void_p(out.data_ptr()), None) == N.ATMO_E_ARG
     f.x1 = 16
     assert lib.atmo_render(ctx, C.byref(f), None, C.c_void_p(out.data_ptr()), None) == N.ATMO_E_ARG
+    # precision modes: 0, 1, 2 (2 = the v2 march in reference order: another kernel, same call)
+    assert lib.atmo_set_precision(ctx, 3) == N.ATMO_E_ARG and lib.atmo_set_precision(ctx, -1) == N.ATMO_E_ARG
+    for mode in (2, 1, 0):
+        assert lib.atmo_set_precision(ctx, mode) == N.ATMO_OK
+        assert lib.atmo_render(ctx, C.byref(f), C.c_void_p(depth.data_ptr()), C.c_void_p(out.data_ptr()), None) == N.ATMO_OK
     assert lib.atmo_destroy(ctx) == N.ATMO_OK
     bad = C.c_void_p()
     assert lib.atmo_create(0, 9, 0, 0, 0, 0, C.byref(bad)) == N.ATMO_E_ARG
