@@ -720,6 +720,7 @@ def main():
     # ---- timed region ---------------------------------------------------------------------------------
     bands = None
     no_gather_rate = None
+    dt_ng = None
     run = None
     motion = parse_motion(args.motion)
     if motion is not None and multi:
@@ -824,6 +825,9 @@ def main():
                 "mrays_per_s_no_gather": no_gather_rate,
                 "mrays_per_s_final_gather": (value if args.gather == "final" else final_gather_rate) if multi else None,
                 "mrays_per_s_gather_every": (value if args.gather == "every" else every_gather_rate) if multi else None,
+                # what the collective adds to the K-step region (the same loop with and without it): one gather of a frame per rank in
+                # "final" mode -- a constant, so its share of `value` shrinks with K
+                "gather_ms_in_timed_region": ((dt_max - dt_ng) * 1e3 if (multi and args.gather != "none") else None),
                 "shard": (f"one viewport in row bands of equal {args.band_cost} cost: " + str(bands)) if strong else "one viewport per GPU",
                 "kernel": node.kernel_name,
             },
