@@ -196,8 +196,8 @@ def parse_args():
                     help="N>1: 'viewports' = one full viewport per GPU (weak scaling, default); 'bands' = ONE viewport cut "
                          "into hit-balanced row bands, one per GPU, gathered in place into the frame on rank 0 (strong scaling)")
     ap.add_argument("--also", default="lut32,shipped8,clouds_high,clouds_high_rm,direct32x8@3840x2160,clouds_high_rm@3840x2160,"
-                                      "clouds_high@lod,clouds_high_rm@lod@3840x2160,direct32x8@moving,clouds_high_rm@moving,direct32x8+2vp,noise_cubemap",
-                    help="comma-separated extra workloads (name[@lod][@WxH], name@moving, name+2vp) timed at N=1 after the headline and reported under "
+                                      "clouds_high@lod,clouds_high_rm@lod@3840x2160,direct32x8@moving,clouds_high_rm@moving,direct32x8+2vp,direct32x8@reforder,noise_cubemap",
+                    help="comma-separated extra workloads (name[@lod][@reforder][@WxH], name@moving, name+2vp) timed at N=1 after the headline and reported under "
                          "'extra', each with its own roofline blocks: the reference-exact LUT mode and the shipped 8-step shader "
                          "(SURVEY.md 8d), BASELINE configs[2] (clouds_high 1080p) and configs[3] (clouds_high_rm 3840x2160); '' to skip")
     return ap.parse_args()
@@ -586,8 +586,10 @@ def run_workload(torch, S, name, w, h, pose, steps, warmup, textures, params, lo
     run = time_workload(torch, node, cam, depth, steps, warmup, sequence=sequence)
     kernel_avg_ms = run.kernel_avg_ms
     pmc_name = name + ("@lod" if sampler == "lod" else "")
-    pmc = pmc_summary(pmc_name, w, h) if (pose == "P_space" and motion is None) else None
+    ref_order = bool((node_extra or {}).get("precise_atmosphere"))
+    pmc = pmc_summary(pmc_name, w, h) if (pose == "P_space" and motion is None and not ref_order) else None
     res = {"workload": f"{desc}{workload_suffix(config_name, sampler)}; {w}x{h}; demo scene, pose {pose}"
+                       + ("; atmosphere march in the reference's operation order (atmo_set_precision 2: validation mode)" if ref_order else "")
                        + ("" if motion is None else f", camera motion {motion[0]} {motion[1]:g} deg/frame, a new pose every step, "
                                                     f"{len(sequence)} poses replayed ping-pong, host at most {FRAMES_IN_FLIGHT} frames ahead"),
            "Mrays/s": w * h * steps / run.dt / 1e6,
@@ -860,13 +862,16 @@ def main():
             if "moving" in opts:
                 extra[item] = bench_motion(torch, S, name, w, h, max(64, ex_steps), ex_warm, textures, params, local_rank)
                 continue
-            ew, eh, sampler = w, h, None
+            ew, eh, sampler, node_extra = w, h, None, None
             for o in opts:
                 if o == "lod":
                     sampler = "lod"
+                elif o == "reforder":  # atmo_set_precision 2: the v2 march in the reference's operation order (validation mode)
+                    node_extra = dict(precise_atmosphere=True)
                 else:
                     ew, eh = (int(v) for v in o.split("x"))
-            extra[item] = run_workload(torch, S, name, ew, eh, args.pose, ex_steps, ex_warm, textures, params, local_rank, sampler=sampler)
+            extra[item] = run_workload(torch, S, name, ew, eh, args.pose, ex_steps, ex_warm, textures, params, local_rank, sampler=sampler,
+                                       node_extra=node_extra)
         result["extra"] = extra
     if multi and not strong and args.workload == "direct32x8" and os.environ.get("ATMO_BENCH_NO_CONFIG4") != "1":
         # BASELINE.json configs[4]: independent 3840x2160 clouds_high_rm viewports, one per GPU, gathered to rank 0 over xGMI
