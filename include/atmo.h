@@ -213,7 +213,8 @@ int atmo_measure_tile_costs(AtmoContext *ctx, const AtmoFrame *frame, const floa
  *   (1.8e-4 at 10x the demo's value), i.e. the 1e-4 contract is scene-dependent in this mode.
  * 2: as 1, and the v2 atmosphere march itself runs in the reference's operation order (view-space
  *   position accumulated and the centre subtracted at every use, alpha built step by step, IEEE sqrt / divide, expf,
- *   unfused): a fifth (direct light march) to a half (8 view steps, baked LUT) of the default form's throughput, deviation
+ *   unfused): a fifth (direct light march) to a half (8 view steps, baked LUT) of the default form's throughput on the
+ *   no-cloud variants, 7-10 % less on the cloud variants, deviation
  *   from a scalar fp32 evaluation of the GDShader below 1e-6 whatever the step count.  The default form's running sums drift with the number of view steps (up to 1.1e-4 of alpha
  *   at 64 steps on a thin atmosphere); modes 0 and 1 leave it in place.  Together with atmo_set_sampler_lod 1 it is built for the
  *   baked-LUT light mode only (atmo_render fails with ATMO_E_STATE otherwise); the v1 variants have had the reference order since mode 1.
