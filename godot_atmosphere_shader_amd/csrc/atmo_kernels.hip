@@ -920,7 +920,7 @@ __device__ __forceinline__ float4 march_atmosphere_v1(const RenderConsts &rc, V3
 // The fast form above keeps one running position relative to the planet centre, sums the view optical depth and takes alpha from it in
 // closed form; the reference accumulates the VIEW-SPACE position, subtracts the centre at every use, and builds alpha step by step
 // (atmosphere_funcs_v2.gdshaderinc:60-82).  In fp32 the two drift apart with the number of view steps (1e-4 of alpha after 64 steps on a
-// thin atmosphere: tools/fuzz_debug.py).  This form follows the reference statement by statement -- unfused, IEEE sqrt / divide, expf,
+// thin atmosphere: tests/checks/fuzz_debug.py).  This form follows the reference statement by statement -- unfused, IEEE sqrt / divide, expf,
 // the LUT's bilinear filter as mix(mix(), mix()) on clamped texels, the direct light march as get_optical_depth writes it -- at about
 // two to five times the time; it exists so that parity can be had to 1e-6 where it matters, not for the benchmarks (KF_ATMO_REF).
 __device__ __forceinline__ float precise_density(const RenderConsts &rc, float dist) {  // get_atmosphere_density, atmosphere_common:12-24

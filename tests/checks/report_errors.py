@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Prints the max |HIP - fp32 oracle| per config and pose (needs an MI355X). Used to watch the parity margin."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); import numpy as np, torch
 from godot_atmosphere_shader_amd.demo import CONFIGS, demo_frame, demo_params, demo_textures, make_node
 from godot_atmosphere_shader_amd import scene as S

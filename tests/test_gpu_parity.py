@@ -635,7 +635,7 @@ def test_render_is_hip_graph_capturable():
 @pytest.mark.parametrize("config_name,pose", [("no_clouds_32x8_direct", "P_space"), ("clouds_high_rm", "P_ground"), ("v1_clouds", "P_space")])
 def test_parity_full_resolution_1080p(oracle32, config_name, pose):
     """BASELINE's framebuffer size against the oracle directly (2 M rays; the oracle runs on all host cores).
-    tools/report_errors.py 1920 1080 sweeps all 9 variants x 5 poses: worst 5.1e-5."""
+    tests/checks/report_errors.py 1920 1080 sweeps all 9 variants x 5 poses: worst 5.1e-5."""
     import os
 
     w, h = 1920, 1080

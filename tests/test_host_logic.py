@@ -170,6 +170,20 @@ def test_product_does_not_import_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "liboracle" not in text, f
                 assert "atmo_oracle" not in text, f
+    # the developer tools and the example host stay on the product side as well (checks that need the oracle live under tests/checks/)
+    for sub in ("tools", "examples"):
+        for f in os.listdir(os.path.join(ROOT, sub)):
+            if f.endswith((".py", ".sh", ".cpp", ".hip", ".c")):
+                text = open(os.path.join(ROOT, sub, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "liboracle" not in text, f"{sub}/{f}"
+    # bench.py: only the cpu_baseline leg (and the NoiseCubemap extra's one-core reference figure) may reach for it
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    for node in tree.body:
+        if isinstance(node, (ast.Import, ast.ImportFrom)):
+            assert "oracle" not in ast.dump(node), "bench.py imports the oracle at module level"
+        if isinstance(node, ast.FunctionDef) and "oracle" in ast.dump(node):
+            assert node.name in ("cpu_baseline", "bench_noise_cubemap"), f"bench.{node.name} touches the oracle"
 
 
 def test_host_texture_layouts_against_the_oracle(oracle32):
