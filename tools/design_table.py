@@ -9,7 +9,7 @@ d = sys.argv[1] if len(sys.argv) > 1 else "profiles/round3"
 bench = json.loads(open(os.path.join(d, "bench_default.json")).read().strip().splitlines()[-1])
 live = {"direct32x8_1920x1080": bench}
 for k, v in bench.get("extra", {}).items():
-    if isinstance(v, dict) and "valu_roofline" in v:
+    if isinstance(v, dict) and v.get("valu_roofline") and "reforder" not in k:
         name, *opts = k.split("@")
         size = "1920x1080"
         lod = ""
@@ -30,7 +30,7 @@ for r in rows:
     alg = w * h * 20 / 1e6
     hbm = p["derived"].get("hbm_bytes_per_launch", 0) / 1e6
     b = live.get(r, {})
-    vr = b.get("valu_roofline", {})
+    vr = b.get("valu_roofline") or {}
     bms = b.get("roofline", {}).get("kernel_avg_ms", b.get("kernel_avg_ms"))
     print(f"| {r} | {ms:.4f} | {bms if bms is None else round(bms, 4)} | {c['SQ_INSTS_VALU'] / 1e6:.1f} M | {ms * 2.4e6 * 1024 / c['SQ_INSTS_VALU']:.2f} | "
           f"{vr.get('frac_vs_spec', 0):.2f} | {vr.get('frac_vs_measured', 0):.2f} | {c.get('VALUUtilization', 0):.1f} % | {c.get('SQ_INSTS_SALU', 0) / 1e6:.1f} M | "
