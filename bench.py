@@ -10,12 +10,16 @@ A "step" is one pass of the hot path over one synthetic frame: BASELINE.json con
 scene, pose P_space, analytic ground-sphere depth buffer, all inputs resident in HBM before the timed
 region.  With N > 1 every rank shades its own viewport (weak scaling, BASELINE configs[4] shape: one
 viewport per GPU on an orbit of camera poses).  The path has no exchange step, so frames stay resident in
-each GPU's HBM (like the inputs); `value` includes an RCCL gather of EVERY frame to rank 0 (--gather every,
-default: two frames in flight, overlapped with the next render; root ingress over xGMI then sets the step
-time) and config.mrays_per_s_no_gather is the same loop without the collective (SURVEY.md 8e asks for both);
---gather final gathers only the last frame, --gather none skips the collective.  At N > 1 the headline run is
-followed by BASELINE configs[4] (one 3840x2160 clouds_high_rm viewport per GPU) under extra.
-Rank 0 prints ONE JSON line.
+each GPU's HBM (like the inputs); `value` includes ONE RCCL gather of every rank's last frame to rank 0 inside the
+timed region (--gather final, the default: north_star's "final RCCL gather"); --gather every gathers EVERY frame
+(two in flight, overlapped with the next render; root ingress over xGMI then sets the step time; the default of
+--shard bands, where a frame only exists once it is assembled), --gather none skips the collective; the other
+modes' rates are measured in further loops and reported beside it (SURVEY.md 8e asks for with and without).  At
+N > 1 the headline run is followed by BASELINE configs[4] (one 3840x2160 clouds_high_rm viewport per GPU).
+
+Output: rank 0 prints ONE compact JSON line (<= 6 KB: compact_record) as the LAST line of stdout -- the record the
+driver parses -- and writes everything measured (every extra's roofline blocks, notes, motion cells) to
+bench_detail.json (ATMO_BENCH_DETAIL overrides the path; profiles/round<N>/bench_default.json is a committed copy).
 
 Other workloads (--workload): lut32 (reference-exact LUT light, 32 view steps), shipped8 (the shipped
 no_clouds shader), clouds_high, clouds_high_rm; --width/--height select the framebuffer (3840x2160 for 4K).
@@ -50,19 +54,16 @@ SPEC_CLOCK_GHZ = 2.4
 #      while another wave's fast ops use the second: a mix costs max(4.1 S, 2.2 (S + F)).
 ISSUE_SPEC = {"valu": 2.0, "trans": 8.0}
 ISSUE_MEASURED = {"fast": 2.2, "slow": 4.1, "trans": 8.1, "poison_cycles_per_trans": 3.4}
-PROFILE_DIR = "profiles/round3"
-PROFILE_FALLBACK_DIR = "profiles/round2"  # counters of a workload not re-profiled this round (source says which)
+PROFILE_DIR = "profiles/round4"  # no fallback to earlier rounds: "clouds_high" meant the LOD-0 sampler there
+COMPACT_LIMIT = 6144         # bytes of the final stdout line (the driver keeps the last 8 KB of stdout)
 
 
 def pmc_summary(workload, w, h):
     """rocprofv3 PMC results for the same bench command line (tools/profile.sh -> tools/summarize_pmc.py; collected in their
     own runs, never beside tracing), committed under profiles/round<N>/pmc_<workload>_<W>x<H>.json.  None when this
     workload/size has not been profiled."""
-    for d in (PROFILE_DIR, PROFILE_FALLBACK_DIR):
-        path = f"{d}/pmc_{workload}_{w}x{h}.json"
-        if os.path.exists(os.path.join(ROOT, path)):
-            break
-    else:
+    path = f"{PROFILE_DIR}/pmc_{workload}_{w}x{h}.json"
+    if not os.path.exists(os.path.join(ROOT, path)):
         return None
     with open(os.path.join(ROOT, path)) as f:
         d = json.load(f)
@@ -148,6 +149,87 @@ def hbm_roofline(kernel_avg_ms, launches, launch_rays, pmc, isolated_ms=None):
     }
 
 
+def write_detail(result):
+    """Everything measured, as one JSON document: bench_detail.json in the working directory (ATMO_BENCH_DETAIL overrides; '' = skip).
+    Returns the path written, or None (a read-only working directory must not fail the bench)."""
+    path = os.environ.get("ATMO_BENCH_DETAIL", "bench_detail.json")
+    if not path:
+        return None
+    try:
+        with open(path, "w") as f:
+            json.dump(result, f)
+        return path
+    except OSError:
+        return None
+
+
+def _r(x, digits=6):
+    """Floats rounded to `digits` significant digits (the compact line carries numbers, not their float64 noise)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float(f"{x:.{digits}g}")
+
+
+def _pick(d, keys):
+    return {k: _r(d[k]) for k in keys if d is not None and k in d}
+
+
+def compact_record(result, detail_path=None):
+    """The final stdout line: the contract's keys, the two roofline blocks reduced to their numbers, the CPU baseline, and every extra
+    as name -> [Mrays/s, HBM fraction] -- no prose, <= COMPACT_LIMIT bytes whatever --also holds (round 3's full line was 41.7 KB and the
+    driver, which keeps the last 8 KB of stdout, could not parse it: BENCH_r03.parsed = null).  The detail goes to write_detail()."""
+    rec = {k: _r(result[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "timed_region_ms",
+                                      "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in result}
+    cfg = result.get("config", {})
+    c = _pick(cfg, ("width", "height", "kernel", "hit_fraction", "gather", "shard", "mrays_per_s_feedback_off", "mrays_per_s_no_gather",
+                    "mrays_per_s_final_gather", "mrays_per_s_gather_every", "gather_ms_in_timed_region"))
+    c = {k: v for k, v in c.items() if v is not None}
+    c["workload"] = str(cfg.get("workload", ""))[:200]
+    if isinstance(c.get("shard"), str):
+        c["shard"] = c["shard"][:160]
+    rec["config"] = c
+    rec["roofline"] = _pick(result.get("roofline"), ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_avg_ms",
+                                                     "algorithmic_bytes_per_launch"))
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        rec["roofline"].setdefault(k, None)
+    if result.get("valu_roofline"):
+        rec["valu_roofline"] = _pick(result["valu_roofline"], ("frac_vs_spec", "frac_vs_measured"))
+    if result.get("cpu_baseline"):
+        rec["cpu_baseline"] = _pick(result["cpu_baseline"], ("value", "unit", "cores", "kind"))
+        rec["cpu_baseline"]["sample"] = str(result["cpu_baseline"].get("sample", ""))[:120]
+    extra = {}
+    for name, e in (result.get("extra") or {}).items():
+        if not isinstance(e, dict):
+            continue
+        if "Mrays/s" in e:
+            rf = e.get("roofline") or {}
+            frac = rf.get("frac")
+            if frac is None:  # entries without a roofline block (two viewports): the same 20 B per ray
+                frac = e["Mrays/s"] * 1e6 * BYTES_PER_RAY / 1e9 / HBM_PEAK_GBS
+            extra[name] = [_r(e["Mrays/s"], 5), _r(frac, 4)]
+        elif "Mtexels/s" in e:
+            extra[name] = [_r(e["Mtexels/s"], 5), _r(e.get("hbm_GBps", 0.0) / HBM_PEAK_GBS, 4)]
+        elif any(isinstance(v, dict) and "feedback_on" in v for v in e.values()):  # bench_motion: cells by camera motion
+            for motion, row in e.items():
+                if isinstance(row, dict) and "feedback_on" in row:
+                    on = row["feedback_on"]
+                    extra[f"{name}/{motion}"] = [_r(on["Mrays/s"], 5), _r((on.get("roofline") or {}).get("frac"), 4)]
+        elif any(k.startswith("Mrays/s_") for k in e):  # configs[4]: rates by gather mode
+            extra[name] = {k: _r(v, 5) for k, v in e.items() if k.startswith("Mrays/s_")}
+    if extra:
+        rec["extra"] = extra
+        rec["extra_columns"] = ["Mrays/s (Mtexels/s for noise_cubemap)", "fraction of the 8 TB/s HBM roofline at 20 B/ray"]
+    if detail_path:
+        rec["detail"] = detail_path
+    # whatever --also holds, the line stays under the limit: drop extras from the end until it fits
+    while len(json.dumps(rec)) > COMPACT_LIMIT and rec.get("extra"):
+        rec["extra"].pop(next(reversed(rec["extra"])))
+        rec["extra_truncated"] = True
+    return rec
+
+
 WORKLOADS = {
     # name: (godot_atmosphere_shader_amd.demo.CONFIGS key, description)
     "direct32x8": ("no_clouds_32x8_direct", "planet_atmosphere_no_clouds, 32 view x 8 light steps (direct light march)"),
@@ -164,6 +246,11 @@ WORKLOADS = {
 }
 
 
+def CONFIGS_HAS_CLOUDS(config_name):
+    from godot_atmosphere_shader_amd.demo import CONFIGS
+    return bool(CONFIGS[config_name][1].get("cloud_steps"))
+
+
 def node_kwargs(workload):
     return dict(precise_clouds=False) if workload.endswith("_fast") else {}
 
@@ -177,17 +264,19 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--pose", default="P_space")
-    ap.add_argument("--sampler", default="lod0", choices=["lod0", "lod"],
-                    help="cloud workloads: how the coverage cubemap is sampled -- 'lod0' (level 0; every cloud number of rounds 1-2) or "
-                         "'lod' (the implicit LOD of the linear-mipmap sampler the reference declares, atmo_set_sampler_lod 1)")
+    ap.add_argument("--sampler", default="declared", choices=["declared", "lod0"],
+                    help="cloud workloads: how the coverage cubemap is sampled -- 'declared' (default: the linear-mipmap sampler the reference "
+                         "declares, implicit LOD from the 2x2 pixel quad; the library's default since round 4) or 'lod0' (level 0 only, "
+                         "atmo_set_sampler_lod 0: every cloud number of rounds 1-3)")
     ap.add_argument("--motion", default="", help="orbit:<deg/frame> or pan:<deg/frame>: a new camera pose every step (N = 1); "
                     "all frames and depth buffers are prepared before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--band-cost", default="measured", choices=["measured", "analytic"],
                     help="--shard bands: cut the viewport by MEASURED per-row costs (rank 0 draws the frame once through "
                          "atmo_measure_tile_costs and broadcasts the cuts; default) or by the analytic estimate cloud_row_cost")
-    ap.add_argument("--gather", default="final", choices=["final", "none-then-final", "every", "none"],
-                    help="N>1: 'final' (default since round 3; = 'none-then-final', north_star's \"final RCCL gather\") = frames stay in "
+    ap.add_argument("--gather", default=None, choices=["final", "none-then-final", "every", "none"],
+                    help="N>1 (default: 'final' with --shard viewports, 'every' with --shard bands -- a banded frame only exists once it is "
+                         "assembled): 'final' (= 'none-then-final', north_star's \"final RCCL gather\") = frames stay in "
                          "the HBM of the GPU that rendered them, one gather of every rank's last frame to rank 0 INSIDE the timed region; "
                          "'every' = RCCL gather of EVERY frame to rank 0, two in flight, overlapped with the next render (root ingress "
                          "over xGMI then sets the step time; round 2's default); 'none' = no collective.  Whatever the mode, the other two "
@@ -196,8 +285,9 @@ def parse_args():
                     help="N>1: 'viewports' = one full viewport per GPU (weak scaling, default); 'bands' = ONE viewport cut "
                          "into hit-balanced row bands, one per GPU, gathered in place into the frame on rank 0 (strong scaling)")
     ap.add_argument("--also", default="lut32,shipped8,clouds_high,clouds_high_rm,direct32x8@3840x2160,clouds_high_rm@3840x2160,"
-                                      "clouds_high@lod,clouds_high_rm@lod@3840x2160,direct32x8@moving,clouds_high_rm@moving,direct32x8+2vp,direct32x8@reforder,noise_cubemap",
-                    help="comma-separated extra workloads (name[@lod][@reforder][@WxH], name@moving, name+2vp) timed at N=1 after the headline and reported under "
+                                      "clouds_high@lod0,clouds_high_rm@lod0,clouds_high_rm@lod0@3840x2160,direct32x8@moving,clouds_high_rm@moving,"
+                                      "direct32x8+2vp,direct32x8@reforder,noise_cubemap",
+                    help="comma-separated extra workloads (name[@lod0][@reforder][@WxH], name@moving, name+2vp) timed at N=1 after the headline and reported under "
                          "'extra', each with its own roofline blocks: the reference-exact LUT mode and the shipped 8-step shader "
                          "(SURVEY.md 8d), BASELINE configs[2] (clouds_high 1080p) and configs[3] (clouds_high_rm 3840x2160); '' to skip")
     return ap.parse_args()
@@ -228,15 +318,19 @@ def usable_cores():
     return cores
 
 
-def cpu_baseline(config_name, params, textures, cam, depth_np, lut):
+def cpu_baseline(config_name, params, textures, cam, depth_np, lut, lod0=False):
     """The oracle (a port of the GDShader, not the reference itself: Godot is a GPU-only path) timed on this
-    host's cores over one full frame of the same workload."""
-    from godot_atmosphere_shader_amd.demo import CONFIGS, demo_frame
+    host's cores over one full frame of the same workload (same cubemap sampler as the timed kernels)."""
+    from godot_atmosphere_shader_amd.demo import CONFIGS as DEMO_CONFIGS, demo_frame
     from oracle.oracle import Oracle
 
     cores = usable_cores()
     o = Oracle("f32_fast")
     tex = dict(textures, optical_depth=lut)
+    CONFIGS = {config_name: (None, dict(DEMO_CONFIGS[config_name][1]))}
+    if CONFIGS[config_name][1].get("cloud_steps") and not lod0:
+        CONFIGS[config_name][1]["cube_lod"] = 1
+        tex["cubemap"] = o.cubemap_mip_chain(textures["cubemap"])
     frame = demo_frame(cam)
     w, h = cam.width, cam.height
     # bounded sample: every 4th 8-row band of the frame when the full frame would take too long
@@ -568,14 +662,16 @@ def run_workload(torch, S, name, w, h, pose, steps, warmup, textures, params, lo
                  motion=None, node_extra=None, sampler=None):
     """One single-GPU workload: returns the result dictionary of an `extra` entry (rate, kernel time, both rooflines).
     motion: None or (kind, degrees per frame): a new camera pose every step (time_workload); node_extra: PlanetAtmosphere
-    keyword arguments (tile_feedback=0 ...); sampler: None / "lod0" / "lod" -- the coverage cubemap's sampler mode."""
+    keyword arguments (tile_feedback=0 ...); sampler: None / "declared" (the library's default) or "lod0" -- the coverage cubemap's sampler."""
     import numpy as np  # noqa: F401
     from godot_atmosphere_shader_amd.demo import make_node
 
     config_name, desc = WORKLOADS[name]
     kw = dict(node_kwargs(name), **(node_extra or {}))
-    if sampler == "lod":
-        kw["cubemap_lod"] = True
+    if sampler == "lod0":
+        kw["cubemap_lod"] = False
+    elif os.environ.get("ATMO_BENCH_EXPLICIT_SAMPLER") == "1" and CONFIGS_HAS_CLOUDS(config_name):
+        kw["cubemap_lod"] = True   # tools/ab_bench.sh: the same kernels, selected in the way libraries built before round 4 understand too
     node = make_node(config_name, textures, params, device=local_rank, **kw)
     cam = S.Camera.from_pose(w, h, pose)
     sequence = None
@@ -587,7 +683,7 @@ def run_workload(torch, S, name, w, h, pose, steps, warmup, textures, params, lo
         depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
     run = time_workload(torch, node, cam, depth, steps, warmup, sequence=sequence)
     kernel_avg_ms = run.kernel_avg_ms
-    pmc_name = name + ("@lod" if sampler == "lod" else "")
+    pmc_name = name + ("@lod0" if sampler == "lod0" else "")
     ref_order = bool((node_extra or {}).get("precise_atmosphere"))
     pmc = pmc_summary(pmc_name, w, h) if (pose == "P_space" and motion is None and not ref_order) else None
     res = {"workload": f"{desc}{workload_suffix(config_name, sampler)}; {w}x{h}; demo scene, pose {pose}"
@@ -611,9 +707,9 @@ def workload_suffix(config_name, sampler):
     from godot_atmosphere_shader_amd.demo import CONFIGS
     if not CONFIGS[config_name][1].get("cloud_steps"):
         return ""
-    if sampler == "lod":
-        return "; coverage cubemap sampled with the implicit LOD of a linear-mipmap sampler (the reference's declared sampler)"
-    return "; coverage cubemap sampled at LOD 0"
+    if sampler == "lod0":
+        return "; coverage cubemap sampled at LOD 0 (atmo_set_sampler_lod 0)"
+    return "; coverage cubemap sampled as declared (linear-mipmap, implicit LOD)"
 
 
 def bench_motion(torch, S, name, w, h, steps, warmup, textures, params, local_rank,
@@ -686,6 +782,8 @@ def bench_two_viewports(torch, S, name, w, h, steps, warmup, textures, params, l
 
 def main():
     args = parse_args()
+    if args.gather is None:
+        args.gather = "every" if args.shard == "bands" else "final"
     if args.gather == "none-then-final":
         args.gather = "final"
     import numpy as np
@@ -720,8 +818,11 @@ def main():
     cam = S.Camera.from_pose(w, h, pose)
     depth_np = S.depth_ground_sphere(cam)
     depth = torch.from_numpy(depth_np).cuda()
-    lod = args.sampler == "lod" and bool(__import__("godot_atmosphere_shader_amd.demo", fromlist=["CONFIGS"]).CONFIGS[config_name][1].get("cloud_steps"))
-    node = make_node(config_name, textures, params, device=local_rank, **dict(node_kwargs(args.workload), **(dict(cubemap_lod=True) if lod else {})))
+    cloudy = bool(__import__("godot_atmosphere_shader_amd.demo", fromlist=["CONFIGS"]).CONFIGS[config_name][1].get("cloud_steps"))
+    lod0 = args.sampler == "lod0" and cloudy
+    explicit = os.environ.get("ATMO_BENCH_EXPLICIT_SAMPLER") == "1" and cloudy   # tools/ab_bench.sh against libraries built before round 4
+    node = make_node(config_name, textures, params, device=local_rank,
+                     **dict(node_kwargs(args.workload), **(dict(cubemap_lod=False) if lod0 else (dict(cubemap_lod=True) if explicit else {}))))
     rays = w * h
     device = torch.device("cuda", local_rank)
 
@@ -801,7 +902,7 @@ def main():
         value = (1 if strong else world) * rays * args.steps / dt_max / 1e6
         if no_gather_rate is None:
             no_gather_rate = value
-        pmc = None if (strong or args.pose != "P_space" or motion is not None) else pmc_summary(args.workload + ("@lod" if lod else ""), w, h)
+        pmc = None if (strong or args.pose != "P_space" or motion is not None) else pmc_summary(args.workload + ("@lod0" if lod0 else ""), w, h)
         kernel_avg_ms = kernel_ms / launches if launches else 0.0
         launch_rays = rays if not strong else w * (bands[0][1] - bands[0][0])  # rank 0's kernel shades its band only
         frame_img = node.render(cam, depth)
@@ -810,7 +911,7 @@ def main():
         del frame_img
         result = {
             "metric": f"Mrays/s, {args.workload} at {w}x{h}" + ("; 32 view x 8 light steps" if args.workload == "direct32x8" else "")
-                      + "; % HBM roofline",
+                      + "; % HBM roofline" + (f"; gather {args.gather}" if multi else ""),
             "value": value,
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -824,7 +925,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{desc}{workload_suffix(config_name, 'lod' if lod else None)}; {w}x{h}; demo scene, pose {args.pose}"
+                "workload": f"{desc}{workload_suffix(config_name, 'lod0' if lod0 else None)}; {w}x{h}; demo scene, pose {args.pose}"
                             + ("" if world == 1 or strong else f" on rank 0, orbit poses on ranks 1..{world - 1}; one viewport per GPU"),
                 "width": w, "height": h, "rays_per_step_per_gpu": rays if not strong else None,
                 "hit_fraction": hit_fraction,
@@ -853,6 +954,13 @@ def main():
             result["valu_roofline"] = vr
     node.close()
 
+    # the conservative figure beside the headline: the same workload in row-major tile order (atmo_set_tile_feedback 0) -- what a panning
+    # camera gets on the cloudless kernels (profiles/round3/ab_tile_feedback_motion.txt)
+    if not multi and rank == 0 and motion is None and args.also.strip(", "):  # (not in the single-workload runs of tools/profile.sh: --also "")
+        r_off = run_workload(torch, S, args.workload, w, h, args.pose, args.steps, args.warmup, textures, params, local_rank,
+                             with_frame_stats=False, node_extra=dict(tile_feedback=0), sampler="lod0" if lod0 else None)
+        result["config"]["mrays_per_s_feedback_off"] = r_off["Mrays/s"]
+
     # ---- extras ----------------------------------------------------------------------------------------
     if not multi and args.also and rank == 0:
         extra = {}
@@ -870,8 +978,8 @@ def main():
                 continue
             ew, eh, sampler, node_extra = w, h, None, None
             for o in opts:
-                if o == "lod":
-                    sampler = "lod"
+                if o == "lod0":
+                    sampler = "lod0"
                 elif o == "reforder":  # atmo_set_precision 2: the v2 march in the reference's operation order (validation mode)
                     node_extra = dict(precise_atmosphere=True)
                 else:
@@ -894,8 +1002,9 @@ def main():
                 n2 = make_node(config_name, textures, params, device=local_rank)
                 lut = n2.read_optical_depth()
                 n2.close()
-            result["cpu_baseline"] = cpu_baseline(config_name, params, textures, cam, depth_np, lut)
-        print(json.dumps(result), flush=True)
+            result["cpu_baseline"] = cpu_baseline(config_name, params, textures, cam, depth_np, lut, lod0)
+        detail_path = write_detail(result)
+        print(json.dumps(compact_record(result, detail_path)), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

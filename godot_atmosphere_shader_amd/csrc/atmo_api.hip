@@ -105,7 +105,7 @@ struct AtmoContext {
     int cube_levels = 0;                 // mip levels bound (footprint arrays packed level after level in `cube`)
     DeviceBuffer cube_level_off;         // element offset of every level's footprint array (uint32 x 16, device)
     uint32_t cube_level_off_host[16] = {0};
-    int sampler_lod = 0;                 // atmo_set_sampler_lod: 0 = LOD 0, 1 = implicit LOD from 2x2 pixel quads
+    int sampler_lod = -1;                // atmo_set_sampler_lod: -1 = as the reference declares it (implicit LOD when a mip chain is bound), 0 = LOD 0, 1 = implicit LOD required
     DeviceBuffer staging;                // raw texels on their way into a re-layout kernel (grow-only)
     hipStream_t staging_stream = nullptr;
     bool staging_used = false;
@@ -350,6 +350,8 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
     rc.lut4 = (const float *)ctx->lut4.ptr;
     rc.blue = (const uint8_t *)ctx->blue.ptr;
     rc.shape = (const uint32_t *)ctx->shape.ptr; rc.shape_n = ctx->shape_n;
+    rc.shape_log2n = -1;
+    for (int b = 0; b < 10; ++b) if (ctx->shape_n == (1 << b)) rc.shape_log2n = b;
     rc.cube = (const uint32_t *)ctx->cube.ptr; rc.cube_n = ctx->cube_n;
     rc.cube_levels = ctx->cube_levels;
     rc.cube_level_off = (const uint32_t *)ctx->cube_level_off.ptr;
@@ -372,6 +374,19 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
     rc.out_x0 = f->x0;
     rc.out_y0 = f->y0;
     rc.composite = 0;
+}
+
+// Which coverage-cubemap sampler a draw of this context uses (atmo_set_sampler_lod): 1 = the implicit LOD of the linear-mipmap sampler the
+// reference declares (cloud_funcs.gdshaderinc:15,45; needs a bound mip chain and the precise cloud kernels), 0 = level 0 only.
+// Mode -1 (default) picks 1 whenever it is available; mode 1 demands it: *why_not says what is missing.
+int resolve_sampler_lod(const AtmoContext *ctx, const char **why_not) {
+    if (why_not) *why_not = nullptr;
+    if (ctx->sampler_lod == 0 || !(ctx->flags & atmo::KF_CLOUDS) || !ctx->cube.ptr || ctx->cube_levels <= 1) return 0;  // nothing to choose a level from
+    if (!(ctx->flags & atmo::KF_PRECISE)) {
+        if (why_not) *why_not = "atmo_render: the implicit cubemap LOD (atmo_set_sampler_lod 1) needs the precise cloud mode (atmo_set_precision 1)";
+        return 0;
+    }
+    return 1;
 }
 
 // Lanes per ray for one launch (atmo_set_lane_split; ATMO_LANE_SPLIT, read in atmo_create, overrides for A/B runs).  Two lanes per ray double
@@ -910,7 +925,7 @@ int atmo_read_texture_layout(AtmoContext *ctx, const char *name, void *out_host,
 
 int atmo_set_sampler_lod(AtmoContext *ctx, int mode) {
     if (!ctx) return ATMO_E_ARG;
-    if (mode != 0 && mode != 1) return fail(ctx, ATMO_E_ARG, "atmo_set_sampler_lod: 0 (LOD 0) or 1 (implicit LOD from 2x2 pixel quads)");
+    if (mode < -1 || mode > 1) return fail(ctx, ATMO_E_ARG, "atmo_set_sampler_lod: -1 (as declared: implicit LOD when a mip chain is bound), 0 (LOD 0) or 1 (implicit LOD required)");
     ctx->sampler_lod = mode;
     return ATMO_OK;
 }
@@ -1055,7 +1070,7 @@ int atmo_measure_tile_costs(AtmoContext *ctx, const AtmoFrame *frame, const floa
     atmo::RenderConsts probe;
     std::memset(&probe, 0, sizeof(probe));
     probe.x0 = frame->x0; probe.y0 = frame->y0; probe.x1 = frame->x1; probe.y1 = frame->y1;
-    const int split = (ctx->sampler_lod && (ctx->flags & atmo::KF_CLOUDS) && ctx->cube.ptr && ctx->cube_levels > 1) ? 1 : choose_split(ctx, frame);
+    const int split = resolve_sampler_lod(ctx, nullptr) ? 1 : choose_split(ctx, frame);
     int gx = 0, gy = 0;
     atmo::render_grid(probe, split, &gx, &gy);
     if (tiles_x) *tiles_x = gx;
@@ -1124,14 +1139,14 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     { const int rc0 = tex_order(ctx, s); if (rc0 != ATMO_OK) return rc0; }  // texture updated on another stream
     int split = choose_split(ctx, frame);
     int flags = ctx->flags;
-    if (ctx->sampler_lod && (flags & atmo::KF_CLOUDS) && ctx->cube.ptr && ctx->cube_levels > 1) {
-        // implicit cubemap LOD: needs a mip chain; available for the precise cloud kernels (either light mode), one lane per ray
-        if (!(flags & atmo::KF_PRECISE))
-            return fail(ctx, ATMO_E_STATE, "atmo_render: the implicit cubemap LOD (atmo_set_sampler_lod 1) needs the precise cloud mode (atmo_set_precision 1)");
-        if ((flags & atmo::KF_ATMO_REF) && (flags & atmo::KF_LIGHT_DIRECT))
-            return fail(ctx, ATMO_E_STATE, "atmo_render: atmo_set_precision 2 together with the implicit cubemap LOD (atmo_set_sampler_lod 1) is built for the baked-LUT light mode only");
-        flags |= atmo::KF_CUBE_LOD;
-        split = 1;
+    {   // the coverage cubemap's sampler: as declared (implicit LOD) when a mip chain is bound; one lane per ray
+        const char *why_not = nullptr;
+        const int lod = resolve_sampler_lod(ctx, &why_not);
+        if (ctx->sampler_lod == 1 && why_not) return fail(ctx, ATMO_E_STATE, why_not);
+        if (lod) {
+            flags |= atmo::KF_CUBE_LOD;
+            split = 1;
+        }
     }
     int gx = 0, gy = 0;
     atmo::render_grid(rc, split, &gx, &gy);

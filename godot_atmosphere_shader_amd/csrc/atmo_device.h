@@ -58,6 +58,7 @@ struct RenderConsts {
     const uint8_t *blue;     // u_blue_noise_texture 256x256
     const uint32_t *shape;   // u_cloud_shape_texture: n^3 xy-footprint words (repeat wrap baked in)
     int32_t shape_n;
+    int32_t shape_log2n;     // [host] log2(shape_n) when it is a power of two, else -1 (shape_addr)
     const uint32_t *cube;    // u_cloud_coverage_cubemap: 6 x (n+1)^2 footprint words of the seamless-apron faces; null => 1.0
     int32_t cube_n;
     int32_t cube_levels;             // mip levels bound; level l = (cube_n >> l)-sided faces, footprints at cube + cube_level_off[l]

@@ -45,58 +45,8 @@ constexpr int TILE_H = ATMO_TILE_H;
 #ifndef ATMO_WAVE_W
 #define ATMO_WAVE_W 16
 #endif
-// Ablation knob for the LDS-staging question (profiles/round1/ab_fetch_ablation.txt): 1 replaces every texture
-// gather (LUT, shape, cubemap) by arithmetic on its address, keeping all address and filter math alive.  The speed-up
-// it shows is an upper bound on what ANY cheaper fetch path (LDS staging included) could give.  Never shipped.
-#ifndef ATMO_ABLATE_FETCH
-#define ATMO_ABLATE_FETCH 0
-#endif
-// 1: index the single-dword footprint gathers (shape, cubemap) with unsigned 32-bit element offsets
-#ifndef ATMO_U32_OFFSETS
-#define ATMO_U32_OFFSETS 1
-#endif
-// 1: each of the 6 light taps skips its fetches when it lies outside the cloud layer (divergent branch per tap);
-// 0: taps are evaluated branch-free so the six can overlap (tools/ab_build.sh ... -DATMO_RM_TAPS_EARLY_OUT=0)
-#ifndef ATMO_RM_TAPS_EARLY_OUT
-#define ATMO_RM_TAPS_EARLY_OUT 1
-#endif
-// 1: the coverage-cubemap fetch reproduces the scalar fp32 rounding of its quotient and bilinear filter (its error is
-// amplified x135 by the density ramp: mix(-1.2,1.5,cov) * 50); costs ~13 VALU per density evaluation
-#ifndef ATMO_CUBE_EXACT
-#define ATMO_CUBE_EXACT 0
-#endif
-
-// Direct-light kernel experiments (profiles/round2/ab_direct_kernel.txt):
-// ATMO_TRANS_CLUSTER 1 (shipped): the 7 light-sample square roots (and the 3 exps) are issued back to back from one asm
-//   block, so a transcendental "poisons" the pairing of the following fast ops once per cluster instead of once per
-//   sample (tools/valu_issue.hip: exp x4 + fma x28 clustered 3.36 cycles/instruction, spread 3.69); 2: also pairs the
-//   sample-radius and chord roots (slower: lengthens the dependency chain in front of the light block)
-// ATMO_LIGHT_PK 1: light samples evaluated as packed pairs (v_pk_fma_f32 / v_pk_mul_f32): no gain, a packed op issues
-//   in 4.2 cycles against 2 x 2.2 for the pair it replaces
-// ATMO_CHORD_MAX 1 (shipped): chord length clamped with v_max instead of v_cmp + v_cndmask
-#ifndef ATMO_TRANS_CLUSTER
-#define ATMO_TRANS_CLUSTER 1
-#endif
-#ifndef ATMO_LIGHT_PK
-#define ATMO_LIGHT_PK 0
-#endif
-#ifndef ATMO_CHORD_MAX
-#define ATMO_CHORD_MAX 1
-#endif
-#ifndef ATMO_CUBE_FLOAT_INDEX
-#define ATMO_CUBE_FLOAT_INDEX 1
-#endif
-#ifndef ATMO_LUT_FLOAT_INDEX
-#define ATMO_LUT_FLOAT_INDEX 1
-#endif
-// 1: texture gathers as buffer loads (SRSRC + 32-bit offset) instead of flat 64-bit addresses
-#ifndef ATMO_BUFFER_LOADS
-#define ATMO_BUFFER_LOADS 1
-#endif
-// unroll factor of the view-ray loop (lets the LUT gathers of step i+1 issue under the exps of step i)
-#ifndef ATMO_VIEW_UNROLL
-#define ATMO_VIEW_UNROLL 1
-#endif
+// Retired experiments: the losing arms of the round 1-3 A/B switches were removed in round 4; NOTES.md ("Retired ablation
+// switches") lists each switch, the record under profiles/ that settled it and the last commit that still holds its code.
 constexpr int WAVE_W = ATMO_WAVE_W;
 constexpr int WAVE_H = 64 / WAVE_W;
 static_assert(WAVE_W == 16 || WAVE_W == 8 || WAVE_W == 32, "wave tile");
@@ -133,13 +83,9 @@ __device__ __forceinline__ float exact_sqrt(float x) {
 }
 // The same result from the reciprocal root with one coupled Newton step and a final FMA correction (the sequence hipcc itself emits for
 // sqrtf when denormals are flushed): rsq + 7 fast-class instructions instead of sqrt + 4 fast + 4 slow (compares / selects).  For the
-// cloud chain only, where x = |p|^2 is a normal positive number (x = 0 would give NaN here).  ATMO_SQRT_V2; equal to the IEEE root for every
+// cloud chain only, where x = |p|^2 is a normal positive number (x = 0 would give NaN here).  Equal to the IEEE root for every
 // float from 2^-102 up (tools/sqrt_sweep.py: all 2^23 significands of all 230 binades; profiles/round3/ab_sqrt_v2.txt).
-#ifndef ATMO_SQRT_V2
-#define ATMO_SQRT_V2 1
-#endif
 __device__ __forceinline__ float exact_sqrt_pos(float x) {
-#if ATMO_SQRT_V2
     const float y = hw_rsq(x);
     float g = x * y, h = 0.5f * y;
     const float e = __builtin_fmaf(-h, g, 0.5f);
@@ -147,9 +93,6 @@ __device__ __forceinline__ float exact_sqrt_pos(float x) {
     g = __builtin_fmaf(g, e, g);
     const float d = __builtin_fmaf(-g, g, x);
     return __builtin_fmaf(d, h, g);
-#else
-    return exact_sqrt(x);
-#endif
 }
 // Correctly rounded a / c for a wave-uniform divisor c with rc = RN(1/c) computed on the host (IEEE):
 // two Markstein corrections of a*rc with exact FMA residuals.  5 VALU instead of 11 + v_rcp.
@@ -161,7 +104,7 @@ __device__ __forceinline__ float exact_div_uniform(float a, float c, float rc) {
     return __builtin_fmaf(__builtin_fmaf(-q1, c, a), rc, q1);
 }
 
-// Once-per-pixel prologue with the short exact sequences (ATMO_PROLOGUE_DIET), the same bits as ieee_sqrt / ieee_div:
+// Once-per-pixel prologue with the short exact sequences (DIET), the same bits as ieee_sqrt / ieee_div:
 //   prologue_sqrt  exact_sqrt, 1 + 8 instead of 1 + 15 instructions.  Equal to IEEE for x = 0, every x >= 2^-96, inf and NaN;
 //                  for 0 < x < 2^-96 (the FMA residuals underflow) it may be 1 ulp off -- of a root below 3.6e-15, which
 //                  needs a planet radius below 1e-11 or a camera closer than that to the depth sample;
@@ -169,20 +112,8 @@ __device__ __forceinline__ float exact_div_uniform(float a, float c, float rc) {
 //                  the IEEE quotient for every 0 <= i < n <= 65536, the largest viewport atmo_render accepts (checked exhaustively:
 //                  2.1e9 quotients, tools/uv_division.c);
 //   unorm8_exact   byte / 255 in 2 instead of 12 (already used for every texel).
-#ifndef ATMO_PROLOGUE_DIET
-#define ATMO_PROLOGUE_DIET 1
-#endif
 // Sure-miss test in front of the exact prologue (shade_pixel).  ATMO_FAST_MISS_MASK: bit (direct + 2 clouds + 4 lite) = that kernel
 // family uses it (a measured choice per family, like the prologue diet: profiles/round3/ab_fast_miss.txt).
-#ifndef ATMO_FAST_MISS
-#define ATMO_FAST_MISS 1
-#endif
-#ifndef ATMO_F4_FOOTPRINTS  // 1: the precise samplers read a float copy of the cloud textures' footprints when the context holds one
-#define ATMO_F4_FOOTPRINTS 1
-#endif
-#ifndef ATMO_WORLD_DIV3  // 1: the three world.xyz / world.w quotients share one reciprocal in the DIET kernels (world_div3)
-#define ATMO_WORLD_DIV3 1
-#endif
 #ifndef ATMO_FAST_MISS_MASK
 #define ATMO_FAST_MISS_MASK 0x05  // baked-LUT atmosphere with and without clouds: -1.4 % / -0.7 %; the direct-light kernels lose 11 % (!), v1 1.5 %
 #endif
@@ -271,7 +202,7 @@ __device__ __forceinline__ float2 hit_radius(SphereHit s, float radius) {
 // data, so instruction count, not bytes, is what these layouts buy (profiles/round1).
 
 // Texture gathers through buffer descriptors (buffer_load ... offen: scalar SRSRC base + one 32-bit VGPR byte offset +
-// immediate offset) instead of 64-bit flat addresses: ~5 fewer address instructions per fetch (ATMO_BUFFER_LOADS).
+// immediate offset) instead of 64-bit flat addresses: ~5 fewer address instructions per fetch.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
@@ -310,66 +241,79 @@ __device__ __forceinline__ float lut_sample_fp(const float *__restrict__ lut4, i
     return a + (b - a) * fy;
 }
 
-__device__ __forceinline__ float trilinear_unorm8_exact(uint32_t w0, uint32_t w1, float fx, float fy, float fz);
+// mix(mix(mix(), mix(), fy), ..., fz) of the eight texels of two xy-footprints that are already exact byte / 255 floats, every product and
+// sum rounded on its own like a scalar fp32 evaluation.  A function of its own because `#pragma clang fp contract` is lexical: written
+// inline in shape_sample (round 3, float footprints) the mixes were contracted to mul + fma, 1 ulp away from the oracle's filter.
+__device__ __forceinline__ float trilinear_exact8(f32x4 a, f32x4 b, float fx, float fy, float fz) {
+    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
+    const float c00 = a.x * gx + a.y * fx;
+    const float c10 = a.z * gx + a.w * fx;
+    const float c01 = b.x * gx + b.y * fx;
+    const float c11 = b.z * gx + b.w * fx;
+    const float c0 = c00 * gy + c10 * fy;
+    const float c1 = c01 * gy + c11 * fy;
+    return c0 * gz + c1 * fz;
+}
 __device__ __forceinline__ float unorm8_exact(float b);
 
 // texture(u_cloud_shape_texture, p).r : trilinear, repeat, R8.  PRECISE: exact UNORM8 conversions + unfused mixes.
+// Footprint index ((k * n + j) * n + i) of the repeat-wrapped texel (i, j, k) and of its +z neighbour:
+//   * n a power of two (rc.shape_log2n >= 0; every size the engine's NoiseTexture3D defaults to): masks and two shift-ors --
+//     no integer multiplies (round 4: the 64-bit multiply-adds of the general form were 4 of the ~45 instructions of a sample);
+//   * any other n: floor-division through fp32, q = floor(float(i) / n) with one fix-up on either side -- exact for |i| < 2^24
+//     (float(i) is exact, the quotient is off by at most one) -- instead of four hardware-less `%` expansions (~130 instructions
+//     of cold code per inlined copy of this function, six copies in the raymarched-light kernel).
+struct ShapeAddr {
+    uint32_t e0, e1;
+};
+__device__ __forceinline__ int wrap_general(int i, int n, float nf, float inv_nf) {
+    const int q = (int)floorf((float)i * inv_nf);
+    int r = i - q * n;
+    r = r < 0 ? r + n : r;
+    return r >= n ? r - n : r;
+}
+__device__ __forceinline__ ShapeAddr shape_addr(int n, int log2n, int i, int j, int k) {
+    ShapeAddr a;
+    if (log2n >= 0) {
+        const uint32_t m = (uint32_t)(n - 1);
+        const uint32_t ji = (((uint32_t)j & m) << log2n) | ((uint32_t)i & m);
+        a.e0 = (((uint32_t)k & m) << (2 * log2n)) | ji;
+        a.e1 = (((uint32_t)(k + 1) & m) << (2 * log2n)) | ji;
+    } else {
+        const float nf = (float)n, inv_nf = 1.0f / nf;
+        const int i0 = wrap_general(i, n, nf, inv_nf), j0 = wrap_general(j, n, nf, inv_nf), k0 = wrap_general(k, n, nf, inv_nf);
+        const int k1 = k0 + 1 == n ? 0 : k0 + 1;
+        const uint32_t ji = (uint32_t)(j0 * n + i0);
+        a.e0 = (uint32_t)(k0 * n * n) + ji;
+        a.e1 = (uint32_t)(k1 * n * n) + ji;
+    }
+    return a;
+}
 template <bool PRECISE>
-__device__ __forceinline__ float shape_sample(const uint32_t *__restrict__ fp, int n, float px, float py, float pz, const float *__restrict__ f4 = nullptr) {
+__device__ __forceinline__ float shape_sample(const uint32_t *__restrict__ fp, int n, int log2n, float px, float py, float pz, const float *__restrict__ f4 = nullptr) {
 #pragma clang fp contract(fast)
     const float nf = (float)n;
     const float x = px * nf - 0.5f, y = py * nf - 0.5f, z = pz * nf - 0.5f;
     const float xf = floorf(x), yf = floorf(y), zf = floorf(z);
     const float fx = x - xf, fy = y - yf, fz = z - zf;
-    const int i = (int)xf, j = (int)yf, k = (int)zf;
-    int i0, j0, k0, k1;
-    if ((n & (n - 1)) == 0) {
-        const int m = n - 1;
-        i0 = i & m; j0 = j & m; k0 = k & m; k1 = (k + 1) & m;
-    } else {
-        i0 = ((i % n) + n) % n; j0 = ((j % n) + n) % n; k0 = ((k % n) + n) % n; k1 = (k0 + 1) % n;
-    }
-#if ATMO_F4_FOOTPRINTS && ATMO_BUFFER_LOADS
+    const ShapeAddr ad = shape_addr(n, log2n, (int)xf, (int)yf, (int)zf);
     if (PRECISE) {  // with a float copy of the footprints: two 16-byte gathers, no conversions
         f32x4 a, b;
-        const uint32_t e0 = (uint32_t)((k0 * n + j0) * n + i0), e1 = (uint32_t)((k1 * n + j0) * n + i0);
         if (f4 != nullptr) {
             const __amdgpu_buffer_rsrc_t rs4 = make_rsrc(f4, (uint32_t)(n * n * n) * 16u);
-            a = buf_f32x4(rs4, e0 * 16u);
-            b = buf_f32x4(rs4, e1 * 16u);
+            a = buf_f32x4(rs4, ad.e0 * 16u);
+            b = buf_f32x4(rs4, ad.e1 * 16u);
         } else {
             const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(fp, (uint32_t)(n * n * n) * 4u);
-            const uint32_t w0 = buf_u32(rs1, e0 * 4u), w1 = buf_u32(rs1, e1 * 4u);
+            const uint32_t w0 = buf_u32(rs1, ad.e0 * 4u), w1 = buf_u32(rs1, ad.e1 * 4u);
             a = f32x4{unorm8_exact(ub0(w0)), unorm8_exact(ub1(w0)), unorm8_exact(ub2(w0)), unorm8_exact(ub3(w0))};
             b = f32x4{unorm8_exact(ub0(w1)), unorm8_exact(ub1(w1)), unorm8_exact(ub2(w1)), unorm8_exact(ub3(w1))};
         }
-        const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;  // trilinear_unorm8_exact on converted texels, unfused
-        const float c00 = a.x * gx + a.y * fx;
-        const float c10 = a.z * gx + a.w * fx;
-        const float c01 = b.x * gx + b.y * fx;
-        const float c11 = b.z * gx + b.w * fx;
-        const float c0 = c00 * gy + c10 * fy;
-        const float c1 = c01 * gy + c11 * fy;
-        return c0 * gz + c1 * fz;
+        return trilinear_exact8(a, b, fx, fy, fz);
     }
-#endif
-#if ATMO_ABLATE_FETCH
-    const uint32_t w0 = (uint32_t)((k0 * n + j0) * n + i0) * 2654435761u;
-    const uint32_t w1 = (uint32_t)((k1 * n + j0) * n + i0) * 2246822519u;
-#else
-#if ATMO_BUFFER_LOADS
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(fp, (uint32_t)(n * n * n) * 4u);
-    const uint32_t w0 = buf_u32(rs, (uint32_t)((k0 * n + j0) * n + i0) * 4u);
-    const uint32_t w1 = buf_u32(rs, (uint32_t)((k1 * n + j0) * n + i0) * 4u);
-#elif ATMO_U32_OFFSETS
-    const uint32_t w0 = fp[(uint32_t)((k0 * n + j0) * n + i0)];
-    const uint32_t w1 = fp[(uint32_t)((k1 * n + j0) * n + i0)];
-#else
-    const uint32_t w0 = fp[(k0 * n + j0) * n + i0];
-    const uint32_t w1 = fp[(k1 * n + j0) * n + i0];
-#endif
-#endif
-    if (PRECISE) return trilinear_unorm8_exact(w0, w1, fx, fy, fz);
+    const uint32_t w0 = buf_u32(rs, ad.e0 * 4u);
+    const uint32_t w1 = buf_u32(rs, ad.e1 * 4u);
     const float a00 = ub0(w0), a10 = ub1(w0), a01 = ub2(w0), a11 = ub3(w0);
     const float b00 = ub0(w1), b10 = ub1(w1), b01 = ub2(w1), b11 = ub3(w1);
     const float c00 = a00 + (a10 - a00) * fx;
@@ -410,16 +354,6 @@ __device__ __forceinline__ float bilinear_exact4(float t00, float t10, float t01
     return a * gy + b * fy;
 }
 
-__device__ __forceinline__ float trilinear_unorm8_exact(uint32_t w0, uint32_t w1, float fx, float fy, float fz) {
-    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
-    const float c00 = unorm8_exact(ub0(w0)) * gx + unorm8_exact(ub1(w0)) * fx;
-    const float c10 = unorm8_exact(ub2(w0)) * gx + unorm8_exact(ub3(w0)) * fx;
-    const float c01 = unorm8_exact(ub0(w1)) * gx + unorm8_exact(ub1(w1)) * fx;
-    const float c11 = unorm8_exact(ub2(w1)) * gx + unorm8_exact(ub3(w1)) * fx;
-    const float c0 = c00 * gy + c10 * fy;
-    const float c1 = c01 * gy + c11 * fy;
-    return c0 * gz + c1 * fz;
-}
 
 // texture(u_cloud_coverage_cubemap, d).r : LOD 0, bilinear, seamless.
 // Face selection and the in-face coordinates come from the hardware cube instructions (v_cubeid/sc/tc/ma_f32):
@@ -436,7 +370,7 @@ __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, in
     float qs = sc * r, qt = tc * r;
     qs = fmaf(fmaf(-qs, ma, sc), r, qs);
     qt = fmaf(fmaf(-qt, ma, tc), r, qt);
-    if (PRECISE || ATMO_CUBE_EXACT) {
+    if (PRECISE) {
         qs = fmaf(fmaf(-qs, ma, sc), r, qs);  // second correction: the quotient is now the IEEE one (up to rare ties)
         qt = fmaf(fmaf(-qt, ma, tc), r, qt);
     }
@@ -447,7 +381,6 @@ __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, in
     const float xf = floorf(x), yf = floorf(y);
     const float fx = x - xf, fy = y - yf;
     const int stride = n + 1;
-#if ATMO_CUBE_FLOAT_INDEX && ATMO_BUFFER_LOADS && !ATMO_ABLATE_FETCH
     if (n <= 1024) {
         // byte offset ((face * stride + j) * stride + i) * 4, i = clamp(xf, -1, n-1) + 1, formed in fp32.  Exact although the
         // largest offset, 6 (n+1)^2 * 4 = 25.2 M at n = 1024, exceeds 2^24: every term and every partial sum of the three FMAs
@@ -457,7 +390,6 @@ __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, in
         const float nm1 = (float)(n - 1), s4 = (float)(stride * 4);
         const float ic = __builtin_amdgcn_fmed3f(xf, -1.0f, nm1), jc = __builtin_amdgcn_fmed3f(yf, -1.0f, nm1);
         const float offf = fmaf(fid, s4 * (float)stride, fmaf(jc, s4, fmaf(ic, 4.0f, s4 + 4.0f)));
-#if ATMO_F4_FOOTPRINTS
         if (PRECISE) {  // with a float copy of the footprints: one 16-byte gather at four times the offset, no conversions
             f32x4 t;
             if (f4 != nullptr) {
@@ -468,29 +400,17 @@ __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, in
             }
             return bilinear_exact4(t.x, t.y, t.z, t.w, fx, fy);
         }
-#endif
         const uint32_t off = (uint32_t)offf;
         const uint32_t w = buf_u32(make_rsrc(fp, (uint32_t)(6 * stride * stride) * 4u), off);
-        if (PRECISE || ATMO_CUBE_EXACT) return bilinear_unorm8_exact(w, fx, fy);
+        if (PRECISE) return bilinear_unorm8_exact(w, fx, fy);
         const float t00 = ub0(w), t10 = ub1(w), t01 = ub2(w), t11 = ub3(w);
         const float a = t00 + (t10 - t00) * fx;
         const float b = t01 + (t11 - t01) * fx;
         return (a + (b - a) * fy) * (1.0f / 255.0f);
     }
-#endif
     const int i = min(max((int)xf, -1), n - 1) + 1, j = min(max((int)yf, -1), n - 1) + 1;
-#if ATMO_ABLATE_FETCH
-    const uint32_t w = (uint32_t)(((int)fid * stride + j) * stride + i) * 2654435761u;
-#else
-#if ATMO_BUFFER_LOADS
     const uint32_t w = buf_u32(make_rsrc(fp, (uint32_t)(6 * stride * stride) * 4u), (uint32_t)(((int)fid * stride + j) * stride + i) * 4u);
-#elif ATMO_U32_OFFSETS
-    const uint32_t w = fp[(uint32_t)(((int)fid * stride + j) * stride + i)];
-#else
-    const uint32_t w = fp[((int)fid * stride + j) * stride + i];
-#endif
-#endif
-    if (PRECISE || ATMO_CUBE_EXACT) return bilinear_unorm8_exact(w, fx, fy);
+    if (PRECISE) return bilinear_unorm8_exact(w, fx, fy);
     const float t00 = ub0(w), t10 = ub1(w), t01 = ub2(w), t11 = ub3(w);
     const float a = t00 + (t10 - t00) * fx;
     const float b = t01 + (t11 - t01) * fx;
@@ -651,7 +571,7 @@ __device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3
     const int lo = (int)lf;
     const float c0 = __builtin_fmaf(32.0f * nf, nf, 96.0f * nf);
     const float q1s = qs + 1.0f, q1t = qt + 1.0f;
-    const bool f4 = ATMO_F4_FOOTPRINTS && rc.cube_f4 != nullptr;  // wave-uniform: the float copy of the chain, or the byte footprints
+    const bool f4 = rc.cube_f4 != nullptr;  // wave-uniform: the float copy of the chain, or the byte footprints
     const __amdgpu_buffer_rsrc_t rs = f4 ? make_rsrc(rc.cube_f4, rc.cube_bytes * 4u) : make_rsrc(rc.cube, rc.cube_bytes);
     const float v0 = cube_level_sample_fast(rs, f4, fid, q1s, q1t, nf, c0, lo);
     if (lo + 1 >= rc.cube_levels || fr == 0.0f) return v0;
@@ -668,70 +588,33 @@ struct LightMarchConsts {
     int light_steps;
 };
 template <int LSTEPS>
-__device__ __forceinline__ float sun_od_direct(const LightMarchConsts &k, float r2, float bdot, float y3, float sq_pre) {
+__device__ __forceinline__ float sun_od_direct(const LightMarchConsts &k, float r2, float bdot, float y3) {
 #pragma clang fp contract(fast)
     const float ninv_h = k.ninv_h, c1 = k.c1, dens2 = k.dens2, ratm2 = k.ratm2, inv_light_steps = k.inv_light_steps;
     const int light_steps = k.light_steps;
-    (void)sq_pre;
     // chord from the sample to the outer sphere along the sun direction, then a left Riemann sum.
     // x1 - max(x0, 0) with x0 = -b - sq, x1 = sq - b  ==  min(x1 - x0, x1) = min(2 sq, sq - b)
     const float hh = ratm2 - (r2 - bdot * bdot);
-#if ATMO_TRANS_CLUSTER >= 2
-    const float sq = sq_pre;
-#else
     const float sq = hw_sqrt(fmaxf(hh, 0.0f));
-#endif
-#if ATMO_CHORD_MAX
     // inside the outer sphere the forward exit distance is >= 0; hh < 0 (rounding at the shell) gives sq = 0 and
     // min(0, -b), which the max folds to the reference's 0
     const float ray_len = fmaxf(fminf(sq + sq, sq - bdot), 0.0f);
-#else
-    const float ray_len = (hh < 0.0f) ? 0.0f : fminf(sq + sq, sq - bdot);
-#endif
     const float lstep = ray_len * inv_light_steps;
     float acc = y3;  // sample 0 sits on the view sample itself
-    if (LSTEPS == 8 && (ATMO_TRANS_CLUSTER || ATMO_LIGHT_PK)) {
+    if (LSTEPS == 8) {
         const float lb = lstep * (bdot + bdot), l2 = lstep * lstep;
         float q[8], rr[8];
-#if ATMO_LIGHT_PK
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        const f2 l2v = {l2, l2}, lbv = {lb, lb}, r2v = {r2, r2};
-        const f2 j01 = {0.0f, 1.0f}, j23 = {2.0f, 3.0f}, j45 = {4.0f, 5.0f}, j67 = {6.0f, 7.0f};
-        const f2 s01 = {0.0f, 1.0f}, s23 = {4.0f, 9.0f}, s45 = {16.0f, 25.0f}, s67 = {36.0f, 49.0f};
-        auto quad = [&](f2 jj, f2 ss) { return __builtin_elementwise_fma(ss, l2v, __builtin_elementwise_fma(jj, lbv, r2v)); };
-        const f2 q01 = quad(j01, s01), q23 = quad(j23, s23), q45 = quad(j45, s45), q67 = quad(j67, s67);
-        q[0] = q01.x; q[1] = q01.y; q[2] = q23.x; q[3] = q23.y; q[4] = q45.x; q[5] = q45.y; q[6] = q67.x; q[7] = q67.y;
-#else
 #pragma unroll
         for (int j = 1; j < 8; ++j) q[j] = fmaf((float)(j * j), l2, fmaf((float)j, lb, r2));
-#endif
-#if ATMO_TRANS_CLUSTER
         asm volatile("v_sqrt_f32 %0, %7\n\tv_sqrt_f32 %1, %8\n\tv_sqrt_f32 %2, %9\n\tv_sqrt_f32 %3, %10\n\t"
                      "v_sqrt_f32 %4, %11\n\tv_sqrt_f32 %5, %12\n\tv_sqrt_f32 %6, %13\n\ts_nop 0"
                      : "=&v"(rr[1]), "=&v"(rr[2]), "=&v"(rr[3]), "=&v"(rr[4]), "=&v"(rr[5]), "=&v"(rr[6]), "=&v"(rr[7])
                      : "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]));
-#else
-#pragma unroll
-        for (int j = 1; j < 8; ++j) rr[j] = hw_sqrt(q[j]);
-#endif
-#if ATMO_LIGHT_PK
-        const f2 nh = {ninv_h, ninv_h}, c1v = {c1, c1}, zero = {0.0f, 0.0f}, one = {1.0f, 1.0f};
-        auto dens = [&](f2 r) {
-            f2 y = __builtin_elementwise_fma(r, nh, c1v);
-            y = __builtin_elementwise_min(__builtin_elementwise_max(y, zero), one);
-            return y * y * y;
-        };
-        const f2 d23 = dens(f2{rr[2], rr[3]}), d45 = dens(f2{rr[4], rr[5]}), d67 = dens(f2{rr[6], rr[7]});
-        const float y1 = sat(fmaf(rr[1], ninv_h, c1));
-        const f2 sum = d23 + d45 + d67;
-        acc = fmaf(y1 * y1, y1, acc) + (sum.x + sum.y);
-#else
 #pragma unroll
         for (int j = 1; j < 8; ++j) {
             const float yy = sat(fmaf(rr[j], ninv_h, c1));
             acc = fmaf(yy * yy, yy, acc);
         }
-#endif
     } else if (LSTEPS > 0) {
         // |o + j*l*sun|^2 = r2 + j*(l*2b) + j^2*(l*l), |sun| = 1: two FMAs per sample
         const float lb = lstep * (bdot + bdot), l2 = lstep * lstep;
@@ -792,34 +675,18 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
     const float dstep = dens2 * step_len;
     float lr = 0.0f, lg = 0.0f, lb = 0.0f, view_od = 0.0f;
 
-#pragma unroll ATMO_VIEW_UNROLL
     for (int i = 0; i < steps; ++i) {
         const float r2 = ox * ox + oy * oy + oz * oz;
         const float bdot = ox * sx + oy * sy + oz * sz;
         // LUT mode needs 1/r for the cosine; the direct light march only needs r
         const float inv_r = DIRECT ? 0.0f : hw_rsq(r2);
-#if ATMO_TRANS_CLUSTER >= 2
-        // the sample radius and the sun-chord root issued as one pair (DIRECT only)
-        float r, sq_pre = 0.0f;
-        if (DIRECT) {
-            const float hh_pre = fmaxf(ratm2 - (r2 - bdot * bdot), 0.0f);
-            asm volatile("v_sqrt_f32 %0, %2\n\tv_sqrt_f32 %1, %3\n\ts_nop 0" : "=&v"(r), "=&v"(sq_pre) : "v"(r2), "v"(hh_pre));
-        } else {
-            r = r2 * inv_r;
-        }
-#else
         const float r = DIRECT ? hw_sqrt(r2) : r2 * inv_r;
-#endif
         const float y = sat(fmaf(r, ninv_h, c1));  // 1 - height_ratio
         const float y3 = y * y * y;
 
         float sun_od;
         if (DIRECT) {
-#if ATMO_TRANS_CLUSTER >= 2
-            sun_od = sun_od_direct<LSTEPS>(lmc, r2, bdot, y3, sq_pre);
-#else
-            sun_od = sun_od_direct<LSTEPS>(lmc, r2, bdot, y3, 0.0f);
-#endif
+            sun_od = sun_od_direct<LSTEPS>(lmc, r2, bdot, y3);
         } else {
             // uv = (0.5 + 0.5*cos, height_ratio) -> texel space
             const float x = fmaf(bdot * inv_r, half_w, x_off);
@@ -830,7 +697,6 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
         const float d = y3 * dstep;
         view_od += d;
         const float od = sun_od + view_od;
-#if ATMO_TRANS_CLUSTER
         {
             const float ar = od * kr, ag = od * kg, ab = od * kb;
             float er, eg, eb;
@@ -839,11 +705,6 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
             lg = fmaf(d, eg, lg);
             lb = fmaf(d, eb, lb);
         }
-#else
-        lr = fmaf(d, hw_exp2(od * kr), lr);
-        lg = fmaf(d, hw_exp2(od * kg), lg);
-        lb = fmaf(d, hw_exp2(od * kb), lb);
-#endif
 
         ox += sdx; oy += sdy; oz += sdz;
     }
@@ -1082,12 +943,8 @@ __device__ __forceinline__ float cloud_density_precise(const RenderConsts &rc, f
         const float qz = rc.cov_rot[1] * px + rc.cov_rot[3] * pz;
         if (LOD) {
             auto rot = [&](V3 q) { return V3{rc.cov_rot[0] * q.x + rc.cov_rot[2] * q.z, q.y, rc.cov_rot[1] * q.x + rc.cov_rot[3] * q.z}; };
-#ifdef ATMO_LOD_FAST_ONLY  // static instruction counts of the fast path alone (tools/isa_histogram.py); never shipped
-            coverage = cube_sample_lod_fast(rc, V3{qx, py, qz}, nb->vx, rot(nb->px), nb->vy, rot(nb->py));
-#else
             if (rc.cube_lod_fast) coverage = cube_sample_lod_fast(rc, V3{qx, py, qz}, nb->vx, rot(nb->px), nb->vy, rot(nb->py));
             else coverage = cube_sample_lod(rc, V3{qx, py, qz}, nb->vx, rot(nb->px), nb->vy, rot(nb->py));
-#endif
         } else {
             coverage = cube_sample<true>(rc.cube, rc.cube_n, qx, py, qz, rc.cube_f4);
         }
@@ -1107,7 +964,7 @@ __device__ __forceinline__ float cloud_density_precise(const RenderConsts &rc, f
     }
     DENS_STAT(2);
     const float s = rc.shape_scale;
-    const float tex = shape_sample<true>(rc.shape, rc.shape_n, px * s, py * s, pz * s, rc.shape_f4);
+    const float tex = shape_sample<true>(rc.shape, rc.shape_n, rc.shape_log2n, px * s, py * s, pz * s, rc.shape_f4);
     float shape = 0.5f * (1.0f - rc.shape_factor) + tex * rc.shape_factor;
     if (rc.shape_invert) shape = 1.0f - shape;
     float density = (shape - 0.1f + m) * hc;
@@ -1135,7 +992,7 @@ __device__ __forceinline__ float cloud_density_fast(const RenderConsts &rc, floa
         if (((rc.shape_lo01 + m) * hc) * 50.0f - 20.0f >= 1.0f) return 1.0f;
     }
     const float s = rc.shape_scale;
-    float shape = mixf(0.5f, shape_sample<false>(rc.shape, rc.shape_n, px * s, py * s, pz * s), rc.shape_factor);
+    float shape = mixf(0.5f, shape_sample<false>(rc.shape, rc.shape_n, rc.shape_log2n, px * s, py * s, pz * s), rc.shape_factor);
     if (rc.shape_invert) shape = 1.0f - shape;
     const float density = (shape - 0.1f + m) * hc;
     return sat(density * 50.0f - 20.0f);
@@ -1160,42 +1017,25 @@ __device__ __forceinline__ void cloud_height(const RenderConsts &rc, float px, f
 // A march step at which NO lane of the wave can be inside the cloud layer skips the exact height chain and the density evaluation (28 % of the
 // steps of a 1920x1080 frame at pose P_space: the stretch of a ray between the bottom shell and the ground).  |p|^2 below rc.layer_r2_lo means
 // r < bottom, hr < 0, above rc.layer_r2_hi r > top, hr >= 1 (margins in fill_consts): hc = 0 and the density is 0 in the exact chain as well.
-#ifndef ATMO_SURE_OUTSIDE
-#define ATMO_SURE_OUTSIDE 1
-#endif
 __device__ __forceinline__ bool wave_may_be_in_layer(const RenderConsts &rc, float r2) {
-    return !ATMO_SURE_OUTSIDE || __builtin_amdgcn_ballot_w64(r2 >= rc.layer_r2_lo && r2 <= rc.layer_r2_hi) != 0ull;
+    return __builtin_amdgcn_ballot_w64(r2 >= rc.layer_r2_lo && r2 <= rc.layer_r2_hi) != 0ull;
 }
 
 // get_light_raymarched (cloud_funcs.gdshaderinc:104-151): 6 density taps towards the sun.
 // 1 - prod(exp(-d_i)) = 1 - exp(-sum d_i): one exp instead of six.
 // Tap 0 is the sample itself: pos0 + float(0) * step_len * dir = pos0 (clouds:129 with i = 0), and get_density there is the value
 // raymarch_cloud computes for the same position one line later (clouds:217) -- the same function of the same arguments (both
-// alpha0 branches are, with CLOUDS_ALWAYS_LOW_QUALITY).  The caller passes that density in as d0 (ATMO_RM_TAP0_REUSE): five taps
+// alpha0 branches are, with CLOUDS_ALWAYS_LOW_QUALITY).  The caller passes that density in as d0: five taps
 // are evaluated instead of six, and the one saved is the expensive one -- a lit sample has density > 0, so its tap 0 never takes
 // an early-out and always pays the full exact shape + coverage filters.  Bit-identical.
-#ifndef ATMO_LOD_TAPS_ROLLED
-#define ATMO_LOD_TAPS_ROLLED 1
-#endif
-#ifndef ATMO_RM_TAP_HOST
-#define ATMO_RM_TAP_HOST 1
-#endif
-#ifndef ATMO_RM_TAP0_REUSE
-#define ATMO_RM_TAP0_REUSE 1
-#endif
 template <bool PRECISE, bool LOD = false>
 __device__ __forceinline__ float light_raymarched(const RenderConsts &rc, float px, float py, float pz, float hr0, float d0,
                                                   float sx, float sy, float sz, const QuadNb *nb = nullptr) {
-    float sum = ATMO_RM_TAP0_REUSE ? __builtin_fmaf(d0, rc.rm_weight[0], 0.0f) : 0.0f;
+    float sum = __builtin_fmaf(d0, rc.rm_weight[0], 0.0f);
     auto tap_i = [&](int i) {
         // exact: pos0 + (i*step)*dir, unfused; the product (float(i) * step_len_i) * dir is uniform and comes rounded from the host
-        // (ATMO_RM_TAP_HOST: two SGPR factors would cost a move and a multiply per component and tap)
-#if ATMO_RM_TAP_HOST
+        // (two SGPR factors would cost a move and a multiply per component and tap)
         const float kx = rc.rm_tap[i][0], ky = rc.rm_tap[i][1], kz = rc.rm_tap[i][2];
-#else
-        const float k = rc.rm_offset[i];  // float(i) * step_len_i, step_len_i = step0 * 1.2^i  [host]
-        const float kx = k * sx, ky = k * sy, kz = k * sz;
-#endif
         const float qx = px + kx, qy = py + ky, qz = pz + kz;
         float r, hr;
         cloud_height(rc, qx, qy, qz, r, hr);
@@ -1205,16 +1045,16 @@ __device__ __forceinline__ float light_raymarched(const RenderConsts &rc, float 
             tap.px = V3{nb->px.x + kx, nb->px.y + ky, nb->px.z + kz};
             tap.py = V3{nb->py.x + kx, nb->py.y + ky, nb->py.z + kz};
         }
-        const float d = cloud_density<ATMO_RM_TAPS_EARLY_OUT != 0, PRECISE, LOD>(rc, qx, qy, qz, hr, LOD ? &tap : nullptr DENS_STAT_PASS(1));
+        const float d = cloud_density<true, PRECISE, LOD>(rc, qx, qy, qz, hr, LOD ? &tap : nullptr DENS_STAT_PASS(1));
         sum = __builtin_fmaf(d, rc.rm_weight[i], sum);  // step_len_i * density_scale  [host]
     };
-    if (ATMO_LOD_TAPS_ROLLED && LOD) {  // the LOD sampler inlined five times doubles the kernel's code (8 300 -> 4 200 lines of ISA): rolled, the draw is 6 % faster
+    if (LOD) {  // the LOD sampler inlined five times doubles the kernel's code (8 300 -> 4 200 lines of ISA): rolled, the draw is 6 % faster
         // (instruction cache); the LOD-0 kernel, 3 800 lines either way, is 1-2 % faster unrolled (profiles/round3/ab_lod_taps_rolled.txt)
 #pragma unroll 1
-        for (int i = ATMO_RM_TAP0_REUSE ? 1 : 0; i < 6; ++i) tap_i(i);
+        for (int i = 1; i < 6; ++i) tap_i(i);
     } else {
 #pragma unroll
-        for (int i = ATMO_RM_TAP0_REUSE ? 1 : 0; i < 6; ++i) tap_i(i);
+        for (int i = 1; i < 6; ++i) tap_i(i);
     }
     const float alpha = 1.0f - hw_exp2(-sum * LOG2E);
     return mixf(1.0f, hr0 * 0.2f, alpha);
@@ -1333,7 +1173,7 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
 }
 
 // ---- atmosphere_fragment ---------------------------------------------------------------------------
-// ---- raymarch_cloud with raymarched light, lit samples regrouped through LDS (ATMO_RM_QUEUE) -------------------------------
+// ---- raymarch_cloud with raymarched light, lit samples regrouped through LDS -------------------------------
 // In clouds_high_rm only the samples with density > 0 need get_light_raymarched (6 more density evaluations each), and in a
 // lock-step march they are a changing subset of the wave: 21 % of the issued lanes idle (VALUUtilization 78.7 %,
 // profiles/round2/pmc_clouds_high_rm_1920x1080.json).  The light value does not feed back into the march -- it only scales
@@ -1346,9 +1186,6 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
 //   phase C, end of the chunk: every lane adds its slots in step order.
 // Per ray the arithmetic is fixed (own slots, step order), so the picture does not depend on which rays share a wave.
 // LDS per wave: 6 x 128 queue words + 8 x 64 slots = 5 KB (10 KB per 2-wave workgroup).
-#ifndef ATMO_RM_QUEUE
-#define ATMO_RM_QUEUE 1
-#endif
 // With the implicit cubemap LOD an entry also carries the sample positions of the two quad partners (the light taps of a queued
 // sample difference THEIR tap positions: 6 more words) and, in bits 10-11 of the slot word, whether each partner marches.
 // Steps per chunk of the lit-sample queue = rows of the per-lane slot array in LDS.  8 (round 3; was 16): 5 KB instead of 7 KB per wave,
@@ -1599,7 +1436,7 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
     constexpr bool PRECISE = (FLAGS & KF_PRECISE) != 0;
     constexpr bool LOD = (FLAGS & KF_CUBE_LOD) != 0;
     constexpr bool ATMO_REF = (FLAGS & KF_ATMO_REF) != 0;
-    constexpr bool DIET = ATMO_PROLOGUE_DIET && !DIRECT && !((FLAGS & KF_CLOUDS) && (FLAGS & KF_CLOUD_LIGHT_RM));
+    constexpr bool DIET = !DIRECT && !((FLAGS & KF_CLOUDS) && (FLAGS & KF_CLOUD_LIGHT_RM));
     constexpr bool FASTMISS = (ATMO_FAST_MISS_MASK >> ((DIRECT ? 1 : 0) + (CLOUDS ? 2 : 0) + (LITE ? 4 : 0))) & 1;
     static_assert(!LOD || (CLOUDS && PRECISE && SPLIT == 1), "implicit cubemap LOD: precise cloud kernels, one lane per ray");
 
@@ -1616,7 +1453,6 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
     if (px >= rc.x1 || py >= rc.y1) return;
     float4 *out = rc.out + (size_t)(py - rc.out_y0) * (size_t)rc.out_pitch + (px - rc.out_x0);
 
-#if ATMO_FAST_MISS
     // --- sure-miss test in front of the exact prologue (round 3) ----------------------------------------
     // A ray from the view-space origin along v misses the shell iff (c.v)^2 < (|c|^2 - R^2) |v|^2 (that is h < 0 in ray_sphere,
     // util.gdshaderinc:27-31).  With a projection whose ray direction does not depend on the depth sample (rc.miss_k > 0: the host
@@ -1640,7 +1476,6 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
             return;
         }
     }
-#endif
 
     // --- exact prologue (main:128-169) -----------------------------------------------------------
     // (written out here; pixel_ray() / cloud_gate() above are the same statements packaged for the quad partners of the
@@ -1660,7 +1495,7 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
     const float wz = Vm[2] * vx + Vm[6] * vy + Vm[10] * vz + Vm[14] * vw;
     const float ww = Vm[3] * vx + Vm[7] * vy + Vm[11] * vz + Vm[15] * vw;
     float pwx, pwy, pwz;
-    world_div3<DIET && ATMO_WORLD_DIV3>(wx, wy, wz, ww, pwx, pwy, pwz);
+    world_div3<DIET>(wx, wy, wz, ww, pwx, pwy, pwz);
     const float ddx = rc.cam_pos_world[0] - pwx, ddy = rc.cam_pos_world[1] - pwy, ddz = rc.cam_pos_world[2] - pwz;
     float linear_depth = prologue_sqrt<DIET>(ddx * ddx + ddy * ddy + ddz * ddz);
 
@@ -1724,7 +1559,7 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
                     nbray[1] = pixel_march_ray(rc, px, py ^ 1);
                 }
                 float2 rr;
-                if constexpr (RM && SPLIT == 1 && ATMO_RM_QUEUE != 0) {
+                if constexpr (RM && SPLIT == 1) {
                     __shared__ float rmq[(TILE_W * TILE_H / 64) * rmq_words_per_wave(LOD)];
                     rr = march_clouds_rm_queue<PRECISE, LOD>(rc, dir_m, c0, c1, jitter, rmq + wave * rmq_words_per_wave(LOD), nbray);
                 } else {
@@ -1783,9 +1618,16 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
 // (s_memtime); atmo_tile_order_kernel then sorts the tiles by that cost on a side stream, heaviest first
 // (longest-processing-time-first list scheduling), and blockIdx indexes the sorted list in the draws that follow.  Frames
 // of an animation are coherent, so earlier costs predict this frame's; the picture does not depend on the order.
-// SGPR cap: 256-thread workgroups are admitted 8 per CU only up to 80 SGPRs (81-96 => 7, although the occupancy API and
-// the compiler's "Occupancy" line still say 8: MI355X_MICROARCH.md "Residency").  The atmosphere-only kernels sat at 82
-// after RenderConsts grew, which cost the direct-light kernel 7 %; the cap makes hipcc keep a few uniforms in VGPRs instead.
+// SGPR budget: a SIMD holds 800 SGPRs and a wave is charged its allocation (16-granular) + 16, so waves per SIMD =
+// floor(800 / (ceil(.sgpr_count / 16) * 16 + 16)): .sgpr_count <= 80 => 8, 81-96 => 7, 97-112 => 6, although the occupancy API
+// and the compiler's "Occupancy" line still say 8 (MI355X_MICROARCH.md "Residency").  hipcc has no such rule, so the build
+// states it per kernel family (render_sgpr_cap below; amdgpu_num_sgpr takes a literal, hence the twin kernel):
+//   * direct light, no clouds (the headline <4, 8, 1>): 40 VGPRs would allow 8 waves, the natural 82 SGPRs allow 7.  Capped at
+//     80 (atmo_render_kernel_s80): hipcc keeps two uniforms in VGPRs instead.  profiles/round2/ab_direct_kernel.txt -3 %,
+//     re-measured in profiles/round4/ab_sgpr_cap.txt;
+//   * baked-LUT light, no clouds (<0, 0, *>, v1): already at or below 80;
+//   * cloud kernels: 86-106 SGPRs, and 53-89 VGPRs allow 5-8 waves: the cap moved 10-20 uniforms into VGPRs and cost
+//     5-7 % (same record): uncapped.
 #ifndef ATMO_MIN_WAVES  // __launch_bounds__ second argument: minimum waves per SIMD the register allocation must allow (0 = none).
 #define ATMO_MIN_WAVES 6  // 6: only atmo_render_kernel<19 / 23, ..> change (84 -> 80 VGPRs); see ATMO_RMQ_CHUNK
 #endif
@@ -1803,44 +1645,59 @@ constexpr int render_min_waves(int flags) {
 #else
 #define ATMO_MIN_WAVES_ARG
 #endif
-#ifdef ATMO_SGPR_CAP
-#define ATMO_SGPR_ATTR __attribute__((amdgpu_num_sgpr(ATMO_SGPR_CAP)))
-#else
-#define ATMO_SGPR_ATTR
+// ATMO_SGPR_CAP_MASK: bit (direct + 2 clouds + 4 lite) = that kernel family runs under the cap (A/B: tools/ab_build.sh x -DATMO_SGPR_CAP_MASK=0x..)
+#ifndef ATMO_SGPR_CAP_MASK
+#define ATMO_SGPR_CAP_MASK 0x02  // direct light without clouds
 #endif
+constexpr bool render_sgpr_cap80(int flags) {
+    return (ATMO_SGPR_CAP_MASK >> (((flags & KF_LIGHT_DIRECT) ? 1 : 0) + ((flags & KF_CLOUDS) ? 2 : 0) + ((flags & KF_LITE) ? 4 : 0))) & 1;
+}
+
+// The kernel body, textually the same in both kernels (a shared __forceinline__ function changes hipcc's scheduling of the
+// preamble, and these kernels are sensitive to exactly that: see the note inside).
+#ifdef ATMO_WAVE_TRACE
+#define ATMO_TRACE_ENTRY const uint64_t trace_entry = __builtin_amdgcn_s_memrealtime();
+#define ATMO_SHADE_TRACED                                                                                                          \
+    const uint64_t trace_t0 = __builtin_amdgcn_s_memrealtime();                                                                    \
+    shade_pixel<FLAGS, LSTEPS, SPLIT>(rc, (int)tile_x, (int)tile_y);                                                               \
+    if (rc.wave_trace != nullptr && (threadIdx.x & 63) == 0) {                                                                     \
+        const uint32_t slot = (blockIdx.y * gridDim.x + blockIdx.x) * (TILE_W * TILE_H / 64) + (threadIdx.x >> 6);                 \
+        unsigned long long *w = rc.wave_trace + 4ull * slot;                                                                       \
+        w[0] = trace_t0;                                                                                                           \
+        w[1] = __builtin_amdgcn_s_memrealtime();                                                                                   \
+        w[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); /* HW_REG_HW_ID, 32 bits */                                              \
+        w[3] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu) | ((trace_t0 - trace_entry) << 8); /* XCC_ID, preamble ticks */ \
+    }
+#else
+#define ATMO_TRACE_ENTRY
+#define ATMO_SHADE_TRACED shade_pixel<FLAGS, LSTEPS, SPLIT>(rc, (int)tile_x, (int)tile_y);
+#endif
+// Keep this preamble exactly as it is for every variant.  Measured on the direct-light kernel (same loop ISA in all
+// three builds, profiles/round2/ab_direct_kernel.txt): this form 0.108-0.109 ms; a branch on tile_order in front of
+// the division (which serialises the prologue's scalar loads behind an early s_waitcnt) 0.115 ms; NO preamble at all
+// (blockIdx used directly) 0.115 ms as well -- the few hundred cycles of scalar work in front of the depth load
+// help (an explicit s_sleep stagger by blockIdx does not: +4..6 %).
+#define ATMO_RENDER_KERNEL_BODY                                                                                  \
+    ATMO_TRACE_ENTRY                                                                                             \
+    uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;                                                         \
+    if (rc.tile_order != nullptr) tile = rc.tile_order[tile];                                                    \
+    const uint32_t tile_y = tile / (uint32_t)rc.tiles_x, tile_x = tile - tile_y * (uint32_t)rc.tiles_x;          \
+    uint64_t t0 = 0;                                                                                             \
+    if (rc.tile_cost != nullptr) t0 = __builtin_amdgcn_s_memtime();                                              \
+    ATMO_SHADE_TRACED                                                                                            \
+    if (rc.tile_cost != nullptr && (threadIdx.x & 63) == 0) {                                                    \
+        const uint64_t dt = __builtin_amdgcn_s_memtime() - t0;                                                   \
+        atomicMax(&rc.tile_cost[tile], (uint32_t)(dt > 0xffffffffull ? 0xffffffffull : dt));                     \
+    }
+
 template <int FLAGS, int LSTEPS, int SPLIT = 1>
-__global__ __launch_bounds__(TILE_W *TILE_H ATMO_MIN_WAVES_ARG) ATMO_SGPR_ATTR void atmo_render_kernel(const RenderConsts rc) {
-    // Keep this preamble exactly as it is for every variant.  Measured on the direct-light kernel (same loop ISA in all
-    // three builds, profiles/round2/ab_direct_kernel.txt): this form 0.108-0.109 ms; a branch on tile_order in front of
-    // the division (which serialises the prologue's scalar loads behind an early s_waitcnt) 0.115 ms; NO preamble at all
-    // (blockIdx used directly) 0.115 ms as well -- the few hundred cycles of scalar work in front of the depth load
-    // help (an explicit s_sleep stagger by blockIdx does not: +4..6 %).
-#ifdef ATMO_WAVE_TRACE
-    const uint64_t trace_entry = __builtin_amdgcn_s_memrealtime();
-#endif
-    uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
-    if (rc.tile_order != nullptr) tile = rc.tile_order[tile];
-    const uint32_t tile_y = tile / (uint32_t)rc.tiles_x, tile_x = tile - tile_y * (uint32_t)rc.tiles_x;
-    uint64_t t0 = 0;
-    if (rc.tile_cost != nullptr) t0 = __builtin_amdgcn_s_memtime();
-#ifdef ATMO_WAVE_TRACE
-    const uint64_t trace_t0 = __builtin_amdgcn_s_memrealtime();
-    shade_pixel<FLAGS, LSTEPS, SPLIT>(rc, (int)tile_x, (int)tile_y);
-    if (rc.wave_trace != nullptr && (threadIdx.x & 63) == 0) {
-        const uint32_t slot = (blockIdx.y * gridDim.x + blockIdx.x) * (TILE_W * TILE_H / 64) + (threadIdx.x >> 6);
-        unsigned long long *w = rc.wave_trace + 4ull * slot;
-        w[0] = trace_t0;
-        w[1] = __builtin_amdgcn_s_memrealtime();
-        w[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID, 32 bits
-        w[3] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu) | ((trace_t0 - trace_entry) << 8);  // HW_REG_XCC_ID, preamble ticks
-    }
-#else
-    shade_pixel<FLAGS, LSTEPS, SPLIT>(rc, (int)tile_x, (int)tile_y);
-#endif
-    if (rc.tile_cost != nullptr && (threadIdx.x & 63) == 0) {
-        const uint64_t dt = __builtin_amdgcn_s_memtime() - t0;
-        atomicMax(&rc.tile_cost[tile], (uint32_t)(dt > 0xffffffffull ? 0xffffffffull : dt));
-    }
+__global__ __launch_bounds__(TILE_W *TILE_H ATMO_MIN_WAVES_ARG) void atmo_render_kernel(const RenderConsts rc) {
+    ATMO_RENDER_KERNEL_BODY
+}
+// the same kernel under the 80-SGPR cap (8 waves per SIMD), for the families render_sgpr_cap80 names
+template <int FLAGS, int LSTEPS, int SPLIT = 1>
+__global__ __launch_bounds__(TILE_W *TILE_H ATMO_MIN_WAVES_ARG) __attribute__((amdgpu_num_sgpr(80))) void atmo_render_kernel_s80(const RenderConsts rc) {
+    ATMO_RENDER_KERNEL_BODY
 }
 
 // Stable counting sort of the tiles by the cost a recording draw measured, heaviest class first; clears the costs for
@@ -2035,7 +1892,7 @@ hipError_t launch_layout_shape(const uint8_t *t, int n, uint32_t *out, hipStream
     hipLaunchKernelGGL(atmo_layout_shape_kernel, dim3((n + 63) / 64, (n + 3) / 4, n), dim3(256), 0, stream, t, n, out);
     return hipGetLastError();
 }
-// Footprint words -> four exact byte / 255 floats each (ATMO_F4_FOOTPRINTS): the samplers then skip the 12 conversion instructions.
+// Footprint words -> four exact byte / 255 floats each: the samplers then skip the 12 conversion instructions.
 __global__ __launch_bounds__(256) void atmo_footprints_f4_kernel(const uint32_t *__restrict__ words, size_t n, float4 *__restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -2202,11 +2059,7 @@ __global__ __launch_bounds__(256) void atmo_light_probe_kernel(const float *__re
     const float bdot = ox * sx + oy * sy + oz * sz;
     const float r = hw_sqrt(r2);
     const float y = sat(fmaf(r, k.ninv_h, k.c1));
-    float sq_pre = 0.0f;
-#if ATMO_TRANS_CLUSTER >= 2
-    sq_pre = hw_sqrt(fmaxf(k.ratm2 - (r2 - bdot * bdot), 0.0f));
-#endif
-    out[i] = light_steps == 8 ? sun_od_direct<8>(k, r2, bdot, y * y * y, sq_pre) : sun_od_direct<0>(k, r2, bdot, y * y * y, sq_pre);
+    out[i] = light_steps == 8 ? sun_od_direct<8>(k, r2, bdot, y * y * y) : sun_od_direct<0>(k, r2, bdot, y * y * y);
 }
 
 hipError_t launch_light_probe(const float *pos, const float *dir, int n, float planet_radius, float atmosphere_height, float density,
@@ -2250,7 +2103,10 @@ static hipError_t launch_s(const RenderConsts &rc, hipStream_t stream) {
     int gx, gy;
     render_grid(rc, SPLIT, &gx, &gy);
     if (gx != rc.tiles_x) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((atmo_render_kernel<FLAGS, LSTEPS, SPLIT>), dim3(gx, gy), dim3(TILE_W * TILE_H), 0, stream, rc);
+    if constexpr (render_sgpr_cap80(FLAGS))
+        hipLaunchKernelGGL((atmo_render_kernel_s80<FLAGS, LSTEPS, SPLIT>), dim3(gx, gy), dim3(TILE_W * TILE_H), 0, stream, rc);
+    else
+        hipLaunchKernelGGL((atmo_render_kernel<FLAGS, LSTEPS, SPLIT>), dim3(gx, gy), dim3(TILE_W * TILE_H), 0, stream, rc);
     return hipGetLastError();
 }
 
@@ -2283,10 +2139,14 @@ hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream
     case KF_ATMO_REF | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM: return launch_s<KF_ATMO_REF | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM, 0, 1>(rc, stream);
     case KF_ATMO_REF | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT:
         return launch_s<KF_ATMO_REF | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT, 0, 1>(rc, stream);
-    // ... under the declared cubemap sampler (baked-LUT light)
+    // ... under the declared cubemap sampler
     case KF_ATMO_REF | KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS: return launch_s<KF_ATMO_REF | KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS, 0, 1>(rc, stream);
     case KF_ATMO_REF | KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM:
         return launch_s<KF_ATMO_REF | KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM, 0, 1>(rc, stream);
+    case KF_ATMO_REF | KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT:
+        return launch_s<KF_ATMO_REF | KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT, 0, 1>(rc, stream);
+    case KF_ATMO_REF | KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT:
+        return launch_s<KF_ATMO_REF | KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT, 0, 1>(rc, stream);
     // precise cloud density (atmo_set_precision 1, the default of the cloud variants)
     case KF_PRECISE | KF_CLOUDS: return launch_t<KF_PRECISE | KF_CLOUDS, 0>(rc, split, stream);
     case KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT: return launch_direct<KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT>(rc, split, stream);
@@ -2315,7 +2175,7 @@ const char *render_kernel_name(int flags, int light_steps, int split) {
     static thread_local char name[64];
     const bool v2_precise = (flags & KF_ATMO_REF) != 0;  // its light march is a run-time loop
     const int lsteps = ((flags & KF_LIGHT_DIRECT) && light_steps == 8 && !v2_precise) ? 8 : 0;
-    snprintf(name, sizeof(name), "atmo_render_kernel<%d, %d, %d>", flags, lsteps, split == 2 ? 2 : 1);
+    snprintf(name, sizeof(name), "atmo_render_kernel%s<%d, %d, %d>", render_sgpr_cap80(flags) ? "_s80" : "", flags, lsteps, split == 2 ? 2 : 1);
     return name;
 }
 

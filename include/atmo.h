@@ -117,8 +117,8 @@ int atmo_get_param_f32(AtmoContext *ctx, const char *name, float *v, int n);
  * reference bakes 256 x 256); 3-D: w=h=d=n; cube: w=h=n, d=6.
  * mips (cubemap only; 0 or 1 for the others): number of mip levels in `data`, packed level after level (level l = 6 faces
  * of (n >> l)^2 texels); 1 = level 0 only; 0 = level 0 given, the rest of the chain generated on the device with the 2x2
- * box filter Image.generate_mipmaps applies to L8 (noise_cubemap.gd:107,135).  Levels above 0 are only read in the
- * implicit-LOD sampler mode (atmo_set_sampler_lod).
+ * box filter Image.generate_mipmaps applies to L8 (noise_cubemap.gd:107,135).  Levels above 0 are read by the declared
+ * linear-mipmap sampler (atmo_set_sampler_lod, default), not in its LOD-0 mode.
  * The copy and the re-layout into the kernels' footprint layouts are enqueued on `stream` (hipStream_t, NULL = default
  * stream).  Updates of one context take effect in call order whatever streams they arrive on (a later update is chained
  * behind an earlier one's event), and draws on other streams wait for them (stream-side).  Nothing waits on the host
@@ -136,14 +136,18 @@ int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h,
 int atmo_get_texture_size(AtmoContext *ctx, const char *name, int *w, int *h, int *d, int *mips);
 
 /*
- * Replaces: the implicit level-of-detail of `texture(u_cloud_coverage_cubemap, dir)` (cloud_funcs.gdshaderinc:15,45: a
- * samplerCube with the default linear-mipmap filter).  0 (default) = level 0 only (the stated convention of round 1);
- * 1 = implicit LOD: every 2x2 pixel quad differences the cube directions of its rays at the same march step (what the
- * fragment pipeline's derivatives are), transforms them to the selected face (Vulkan 1.3 cube-map derivative
- * transformation), lambda = log2(max(rho_x, rho_y)) clamped to the bound levels, and the sample is the linear mix of
- * the seamless bilinear samples of the two nearest levels.  Needs a mip chain (atmo_set_texture mips != 1); exact rule
- * in oracle/atmo_oracle.h.  The two quad partners' rays are recomputed by every lane (not exchanged across lanes), so the
- * picture does not depend on which pixels share a wavefront or on the launch rect.
+ * Replaces: the sampler state of `uniform samplerCube u_cloud_coverage_cubemap` (cloud_funcs.gdshaderinc:15,45: no filter hint,
+ * i.e. the default linear-mipmap filter; NoiseCubemap builds the chain, noise_cubemap.gd:107,135).
+ * -1 (default) = as declared: whenever the bound cubemap has a mip chain (atmo_set_texture mips != 1) and the precise cloud
+ *   kernels are selected (atmo_set_precision >= 1, the default), `texture(cubemap, dir)` takes its implicit level of detail:
+ *   every 2x2 pixel quad differences the cube directions of its rays at the same march step (what the fragment pipeline's
+ *   derivatives are), transforms them to the selected face (Vulkan 1.3 cube-map derivative transformation),
+ *   lambda = log2(max(rho_x, rho_y)) clamped to the bound levels, and the sample is the linear mix of the seamless bilinear
+ *   samples of the two nearest levels; exact rule in oracle/atmo_oracle.h.  A partner pixel's ray is a function of that pixel
+ *   alone, so the picture does not depend on which pixels share a wavefront or on the launch rect.  With a single level bound,
+ *   or in the fast cloud mode (atmo_set_precision 0), level 0 is sampled.
+ *  0 = level 0 only, whatever is bound (the stated convention of rounds 1-3; 1.5-2x faster on the cloud variants).
+ *  1 = as -1, but a draw that cannot use the implicit LOD although a chain is bound (fast cloud mode) fails with ATMO_E_STATE.
  */
 int atmo_set_sampler_lod(AtmoContext *ctx, int mode);
 
@@ -216,8 +220,7 @@ int atmo_measure_tile_costs(AtmoContext *ctx, const AtmoFrame *frame, const floa
  *   unfused): a fifth (direct light march) to a half (8 view steps, baked LUT) of the default form's throughput on the
  *   no-cloud variants, 7-10 % less on the cloud variants, deviation
  *   from a scalar fp32 evaluation of the GDShader below 1e-6 whatever the step count.  The default form's running sums drift with the number of view steps (up to 1.1e-4 of alpha
- *   at 64 steps on a thin atmosphere); modes 0 and 1 leave it in place.  Together with atmo_set_sampler_lod 1 it is built for the
- *   baked-LUT light mode only (atmo_render fails with ATMO_E_STATE otherwise); the v1 variants have had the reference order since mode 1.
+ *   at 64 steps on a thin atmosphere); modes 0 and 1 leave it in place.  The v1 variants have had the reference order since mode 1.
  */
 int atmo_set_precision(AtmoContext *ctx, int mode);
 

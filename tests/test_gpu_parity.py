@@ -1213,6 +1213,32 @@ def test_parity_implicit_cubemap_lod(oracle32, config_name):
     assert changed > 1e-3   # the mode does change the picture at these pixel footprints
 
 
+def test_declared_sampler_is_the_default():
+    """Round 4: a context samples the coverage cubemap the way the reference declares it (cloud_funcs.gdshaderinc:15,45: linear-mipmap)
+    whenever a mip chain is bound -- atmo_set_sampler_lod -1, the default -- bit for bit the frames of mode 1; with the fast cloud mode or a
+    single level it draws with the LOD-0 kernels instead of failing; mode 0 states LOD 0."""
+    tex, params = demo_textures(cube_n=64, shape_n=16), demo_params()
+    cam = S.Camera.from_pose(160, 90, "P_space")
+    depth = S.depth_ground_sphere(cam)
+    for config_name in ("clouds_high", "clouds_high_rm"):
+        frames, names = {}, {}
+        for mode in (None, True, False):
+            node = make_node(config_name, tex, params, cubemap_lod=mode)
+            frames[mode] = _gpu_render(node, cam, depth)
+            names[mode] = int(node.kernel_name.split("<")[1].split(",")[0])
+            node.close()
+        assert names[None] & 32 and names[True] & 32 and not names[False] & 32, names
+        assert np.array_equal(frames[None], frames[True])
+        assert np.abs(frames[None] - frames[False]).max() > 1e-3
+        fast = make_node(config_name, tex, params, cubemap_lod=None, precise_clouds=False)   # no declared-sampler form: LOD 0, no error
+        _gpu_render(fast, cam, depth)
+        assert not int(fast.kernel_name.split("<")[1].split(",")[0]) & (32 | 16)
+        fast.close()
+        one = make_node(config_name, dict(tex, cubemap=[tex["cubemap"]]), params, cubemap_lod=None)   # a single level bound
+        assert np.array_equal(_gpu_render(one, cam, depth), frames[False])
+        one.close()
+
+
 def test_implicit_lod_needs_a_chain_and_the_precise_kernels(oracle32):
     """Without mip levels the LOD mode is the LOD-0 sampler; with the fast cloud mode it is refused (ATMO_E_STATE) instead of
     silently sampling level 0; with the direct light march of the atmosphere it runs (round 3) and matches the oracle."""

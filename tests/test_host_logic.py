@@ -374,5 +374,55 @@ def test_bench_motion_helpers():
     cams = bench.motion_cameras(S, 192, 108, ("orbit", 1.0), 8)
     r = [np.hypot(c.inv_view[0, 3], c.inv_view[2, 3]) for c in cams]
     assert np.allclose(r, r[0]) and not np.allclose(cams[1].inv_view[:3, 3], cams[0].inv_view[:3, 3])
-    assert bench.workload_suffix("no_clouds_32x8_direct", None) == "" and bench.workload_suffix("no_clouds_8", "lod") == ""
-    assert "LOD 0" in bench.workload_suffix("clouds_high", None) and "linear-mipmap" in bench.workload_suffix("clouds_high_rm", "lod")
+    assert bench.workload_suffix("no_clouds_32x8_direct", None) == "" and bench.workload_suffix("no_clouds_8", "lod0") == ""
+    assert "LOD 0" in bench.workload_suffix("clouds_high", "lod0") and "linear-mipmap" in bench.workload_suffix("clouds_high_rm", None)
+
+
+def test_bench_final_line_is_compact():
+    """bench.py's LAST stdout line is the record the driver parses, and the driver keeps the last 8 KB of stdout: round 3's single line
+    had grown to 41.7 KB (13 extras with prose) and BENCH_r03.parsed came back null.  compact_record() of that very run -- and of a run with
+    ten times as many extras -- stays under 6 KB, keeps the contract's keys and both mandatory objects, and drops nothing it must carry."""
+    import json
+
+    import bench
+
+    full = json.load(open(os.path.join(ROOT, "profiles", "round3", "bench_default.json")))
+    assert len(json.dumps(full)) > 30000  # the line that broke the driver's parser
+    full["config"]["mrays_per_s_feedback_off"] = 20400.0
+    rec = bench.compact_record(full, "bench_detail.json")
+    line = json.dumps(rec)
+    assert len(line) < bench.COMPACT_LIMIT < 8192, len(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in rec, k
+    assert rec["value"] == pytest.approx(full["value"], rel=1e-5) and rec["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-5)
+    assert set(rec["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_avg_ms", "algorithmic_bytes_per_launch"}
+    assert rec["roofline"]["frac"] == pytest.approx(full["roofline"]["achieved"] / 8000.0, rel=1e-5)
+    assert set(rec["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert rec["config"]["workload"] and rec["config"]["mrays_per_s_feedback_off"] == 20400.0 and "model" not in rec["config"]
+    assert all(isinstance(v, list) and len(v) == 2 for v in rec["extra"].values())   # name -> [Mrays/s, hbm fraction], no prose
+    assert rec["extra"]["lut32"][0] == pytest.approx(full["extra"]["lut32"]["Mrays/s"], rel=1e-4)
+    assert "clouds_high_rm@moving/pan:1" in rec["extra"] and "extra_truncated" not in rec
+    # an --also list of any length cannot push the line over the limit
+    many = dict(full, extra={f"{k}#{i}": v for i in range(10) for k, v in full["extra"].items()})
+    rec2 = bench.compact_record(many, "bench_detail.json")
+    assert len(json.dumps(rec2)) <= bench.COMPACT_LIMIT and rec2.get("extra_truncated") and rec2["value"] == rec["value"]
+    # multi-GPU shape: the gather modes' rates and the configs[4] block survive
+    multi = dict(full, n_gpus=8, extra={"config4_clouds_high_rm_3840x2160": {"Mrays/s_final_gather": 1.0, "Mrays/s_no_gather": 2.0, "workload": "x" * 500}})
+    multi["config"] = dict(full["config"], mrays_per_s_final_gather=1.5, mrays_per_s_gather_every=1.25, shard="y" * 2000)
+    rec3 = bench.compact_record(multi)
+    assert len(json.dumps(rec3)) < bench.COMPACT_LIMIT and rec3["extra"]["config4_clouds_high_rm_3840x2160"]["Mrays/s_no_gather"] == 2.0
+    assert rec3["config"]["mrays_per_s_gather_every"] == 1.25
+
+
+def test_bench_detail_file(tmp_path, monkeypatch):
+    import json
+
+    import bench
+
+    monkeypatch.setenv("ATMO_BENCH_DETAIL", str(tmp_path / "d.json"))
+    assert bench.write_detail({"a": 1}) == str(tmp_path / "d.json") and json.load(open(tmp_path / "d.json")) == {"a": 1}
+    monkeypatch.setenv("ATMO_BENCH_DETAIL", "/nonexistent-dir/x.json")
+    assert bench.write_detail({"a": 1}) is None   # an unwritable place does not fail the bench
+    monkeypatch.setenv("ATMO_BENCH_DETAIL", "")
+    assert bench.write_detail({"a": 1}) is None

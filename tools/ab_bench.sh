@@ -10,8 +10,8 @@ declare -A T
 for r in $(seq 1 ${ROUNDS:-3}); do
   for v in "$@"; do
     if [ "$v" = base ]; then unset ATMO_HIP_LIB; else export ATMO_HIP_LIB=$D/libatmo_hip_$v.so; fi
-    name=${WL%@lod}; samp=lod0; [ "$name" != "$WL" ] && samp=lod
-    ms=$(python bench.py --workload $name --sampler $samp --pose $POSE --width $W --height $H --steps ${STEPS:-60} --warmup 10 --no-cpu-baseline --also "" 2>/dev/null | python -c "import json,sys; print('%.4f' % json.loads(sys.stdin.readline())['roofline']['kernel_avg_ms'])")
+    name=${WL%@lod0}; samp=declared; [ "$name" != "$WL" ] && samp=lod0
+    ms=$(ATMO_BENCH_EXPLICIT_SAMPLER=1 ATMO_BENCH_DETAIL= python bench.py --workload $name --sampler $samp --pose $POSE --width $W --height $H --steps ${STEPS:-60} --warmup 10 --no-cpu-baseline --also "" 2>/dev/null | python -c "import json,sys; print('%.4f' % json.loads(sys.stdin.readline())['roofline']['kernel_avg_ms'])")
     T[$v]="${T[$v]:-} $ms"
   done
 done

@@ -4,7 +4,7 @@
 # Output: gpurun_out/prof_<workload>/{stats,pmc_*}/...csv ; summarise with tools/summarize_pmc.py
 set -u
 WL=${1:-direct32x8}; W=${2:-1920}; H=${3:-1080}; POSE=${4:-P_space}
-SAMPLER=lod0; case "$WL" in *@lod) SAMPLER=lod; WLN=${WL%@lod};; *) WLN=$WL;; esac   # clouds_high@lod = --workload clouds_high --sampler lod
+SAMPLER=declared; case "$WL" in *@lod0) SAMPLER=lod0; WLN=${WL%@lod0};; *) WLN=$WL;; esac   # clouds_high@lod0 = --workload clouds_high --sampler lod0
 R=$PWD
 # the real interpreter binary, resolved BEFORE profiling: a pyenv/conda shim or wrapper script after `--` would be an
 # exec hop behind the profiler's preloaded (GPU-initialising) library, which this pool forbids
