@@ -670,8 +670,8 @@ def run_workload(torch, S, name, w, h, pose, steps, warmup, textures, params, lo
     kw = dict(node_kwargs(name), **(node_extra or {}))
     if sampler == "lod0":
         kw["cubemap_lod"] = False
-    elif os.environ.get("ATMO_BENCH_EXPLICIT_SAMPLER") == "1" and CONFIGS_HAS_CLOUDS(config_name):
-        kw["cubemap_lod"] = True   # tools/ab_bench.sh: the same kernels, selected in the way libraries built before round 4 understand too
+    elif os.environ.get("ATMO_BENCH_EXPLICIT_SAMPLER") == "1":
+        kw["cubemap_lod"] = CONFIGS_HAS_CLOUDS(config_name)   # tools/ab_bench.sh: the same kernels, selected in the way libraries built before round 4 understand too
     node = make_node(config_name, textures, params, device=local_rank, **kw)
     cam = S.Camera.from_pose(w, h, pose)
     sequence = None
@@ -820,9 +820,9 @@ def main():
     depth = torch.from_numpy(depth_np).cuda()
     cloudy = bool(__import__("godot_atmosphere_shader_amd.demo", fromlist=["CONFIGS"]).CONFIGS[config_name][1].get("cloud_steps"))
     lod0 = args.sampler == "lod0" and cloudy
-    explicit = os.environ.get("ATMO_BENCH_EXPLICIT_SAMPLER") == "1" and cloudy   # tools/ab_bench.sh against libraries built before round 4
+    explicit = os.environ.get("ATMO_BENCH_EXPLICIT_SAMPLER") == "1"   # tools/ab_bench.sh against libraries built before round 4
     node = make_node(config_name, textures, params, device=local_rank,
-                     **dict(node_kwargs(args.workload), **(dict(cubemap_lod=False) if lod0 else (dict(cubemap_lod=True) if explicit else {}))))
+                     **dict(node_kwargs(args.workload), **(dict(cubemap_lod=False) if lod0 else (dict(cubemap_lod=cloudy) if explicit else {}))))
     rays = w * h
     device = torch.device("cuda", local_rank)
 

@@ -1620,14 +1620,12 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
 // of an animation are coherent, so earlier costs predict this frame's; the picture does not depend on the order.
 // SGPR budget: a SIMD holds 800 SGPRs and a wave is charged its allocation (16-granular) + 16, so waves per SIMD =
 // floor(800 / (ceil(.sgpr_count / 16) * 16 + 16)): .sgpr_count <= 80 => 8, 81-96 => 7, 97-112 => 6, although the occupancy API
-// and the compiler's "Occupancy" line still say 8 (MI355X_MICROARCH.md "Residency").  hipcc has no such rule, so the build
-// states it per kernel family (render_sgpr_cap below; amdgpu_num_sgpr takes a literal, hence the twin kernel):
-//   * direct light, no clouds (the headline <4, 8, 1>): 40 VGPRs would allow 8 waves, the natural 82 SGPRs allow 7.  Capped at
-//     80 (atmo_render_kernel_s80): hipcc keeps two uniforms in VGPRs instead.  profiles/round2/ab_direct_kernel.txt -3 %,
-//     re-measured in profiles/round4/ab_sgpr_cap.txt;
-//   * baked-LUT light, no clouds (<0, 0, *>, v1): already at or below 80;
-//   * cloud kernels: 86-106 SGPRs, and 53-89 VGPRs allow 5-8 waves: the cap moved 10-20 uniforms into VGPRs and cost
-//     5-7 % (same record): uncapped.
+// and the compiler's "Occupancy" line still say 8 (MI355X_MICROARCH.md "Residency").  What the build does: NOTHING -- no kernel is
+// compiled under an SGPR cap.  The direct-light no-cloud kernels sit at .sgpr_count 82 (7 waves per SIMD; their 40 VGPRs would allow
+// 8); the twin kernel atmo_render_kernel_s80 below compiles them to 78 with the same loop ISA, and that build is 8 % SLOWER at
+// 1920x1080 and 4 % at 3840x2160 (profiles/round4/ab_sgpr_cap.txt, interleaved A/B against the uncapped build and round 3's library;
+// round 2 had measured -3 % on a differently shaped kernel).  The cloud kernels (86-106 SGPRs, 53-89 VGPRs: 5-7 waves either way) lost
+// 5-7 % under a cap in round 2.  The mask below selects families for the next A/B (amdgpu_num_sgpr takes a literal, hence the twin).
 #ifndef ATMO_MIN_WAVES  // __launch_bounds__ second argument: minimum waves per SIMD the register allocation must allow (0 = none).
 #define ATMO_MIN_WAVES 6  // 6: only atmo_render_kernel<19 / 23, ..> change (84 -> 80 VGPRs); see ATMO_RMQ_CHUNK
 #endif
@@ -1645,9 +1643,9 @@ constexpr int render_min_waves(int flags) {
 #else
 #define ATMO_MIN_WAVES_ARG
 #endif
-// ATMO_SGPR_CAP_MASK: bit (direct + 2 clouds + 4 lite) = that kernel family runs under the cap (A/B: tools/ab_build.sh x -DATMO_SGPR_CAP_MASK=0x..)
+// ATMO_SGPR_CAP_MASK: bit number (direct + 2 clouds + 4 lite) set = that kernel family runs under the cap (tools/ab_build.sh x -DATMO_SGPR_CAP_MASK=0x02)
 #ifndef ATMO_SGPR_CAP_MASK
-#define ATMO_SGPR_CAP_MASK 0x02  // direct light without clouds
+#define ATMO_SGPR_CAP_MASK 0x00
 #endif
 constexpr bool render_sgpr_cap80(int flags) {
     return (ATMO_SGPR_CAP_MASK >> (((flags & KF_LIGHT_DIRECT) ? 1 : 0) + ((flags & KF_CLOUDS) ? 2 : 0) + ((flags & KF_LITE) ? 4 : 0))) & 1;
@@ -1694,7 +1692,7 @@ template <int FLAGS, int LSTEPS, int SPLIT = 1>
 __global__ __launch_bounds__(TILE_W *TILE_H ATMO_MIN_WAVES_ARG) void atmo_render_kernel(const RenderConsts rc) {
     ATMO_RENDER_KERNEL_BODY
 }
-// the same kernel under the 80-SGPR cap (8 waves per SIMD), for the families render_sgpr_cap80 names
+// the same kernel under an 80-SGPR cap (8 waves per SIMD), for the families render_sgpr_cap80 names (none in the shipped build)
 template <int FLAGS, int LSTEPS, int SPLIT = 1>
 __global__ __launch_bounds__(TILE_W *TILE_H ATMO_MIN_WAVES_ARG) __attribute__((amdgpu_num_sgpr(80))) void atmo_render_kernel_s80(const RenderConsts rc) {
     ATMO_RENDER_KERNEL_BODY

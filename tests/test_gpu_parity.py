@@ -381,33 +381,42 @@ def test_parity_random_scenes(oracle32, seed):
     shader, ocfg, kw = variants[seed % len(variants)]
     depth = S.depth_ground_sphere(cam, radius=params["u_planet_radius"]) if seed % 3 else S.depth_far(cam)
     ref_order = bool(__import__("os").environ.get("ATMO_FUZZ_PRECISE"))  # ATMO_FUZZ_PRECISE=1: atmo_set_precision 2, tighter bars below
-    node = PlanetAtmosphere(blue_noise=tex["blue_noise"], precise_atmosphere=ref_order, **kw)
-    node.custom_shader = load_shader(shader)
-    node.planet_radius, node.atmosphere_height, node.sun_path = params["u_planet_radius"], params["u_atmosphere_height"], sun
-    for k, v in params.items():
-        if k not in ("u_planet_radius", "u_atmosphere_height", "u_cloud_coverage_rotation", "u_world_to_model_matrix"):
-            node.set(f"shader_params/{k}", v)
-    node._process(0.0, cam, time=0.0)
-    node.set_shader_parameter("u_cloud_coverage_rotation", np.asarray(params["u_cloud_coverage_rotation"], dtype=np.float32))
-    node.set_shader_parameter("u_cloud_shape_texture", tex["shape"])
-    if tex["cubemap"] is not None:
-        node.set_shader_parameter("u_cloud_coverage_cubemap", tex["cubemap"])
-    got = _gpu_render(node, cam, depth)
-    lut = node.read_optical_depth() if "light_steps" not in ocfg else None
-    node.close()
-    # the node took the colours as the inspector holds them (sRGB) and converted them on upload (`source_color`);
-    # the oracle works on linear colours
-    params = dict(params, u_atmosphere_modulate=tuple(S.srgb_to_linear(params["u_atmosphere_modulate"]).tolist()),
-                  u_atmosphere_ambient_color=tuple(S.srgb_to_linear(params["u_atmosphere_ambient_color"]).tolist()))
-    want, hits = oracle32.render(params, dict(tex, optical_depth=lut), ocfg, make_frame(cam, np.eye(4), sun), depth, nthreads=8)
-    assert np.array_equal(np.all(got == 0.0, axis=-1), np.all(want == 0.0, axis=-1))
-    finite = np.isfinite(want)
-    assert np.array_equal(np.isfinite(got), finite)
-    # clouds are HDR (light unclamped): tolerance is absolute 1e-4 up to 1.0, relative above
-    err = np.abs(got - want)[finite] / np.maximum(1.0, np.abs(want[finite]))
-    # reference-order atmosphere: 1e-5 on the no-cloud variants; the cloud march keeps its hardware exp2 / rcp and fused light block: 5e-5
-    bar = TOL if not ref_order else (5e-5 if "cloud" in shader.replace("no_clouds", "") else 1e-5)
-    assert err.size == 0 or err.max() <= bar, f"seed {seed} {shader} {ocfg}: {err.max():.3e} (hits {hits})"
+    cloudy = "cloud_steps" in ocfg and tex["cubemap"] is not None
+    # the cubemap sampler: the library's default (as declared: linear-mipmap, implicit LOD; the oracle gets the chain and cube_lod=1) and,
+    # stated, level 0 only -- every cloud scene under both
+    for lod in ((None, False) if cloudy else (None,)):
+        node = PlanetAtmosphere(blue_noise=tex["blue_noise"], precise_atmosphere=ref_order, cubemap_lod=lod, **kw)
+        node.custom_shader = load_shader(shader)
+        node.planet_radius, node.atmosphere_height, node.sun_path = params["u_planet_radius"], params["u_atmosphere_height"], sun
+        for k, v in params.items():
+            if k not in ("u_planet_radius", "u_atmosphere_height", "u_cloud_coverage_rotation", "u_world_to_model_matrix"):
+                node.set(f"shader_params/{k}", v)
+        node._process(0.0, cam, time=0.0)
+        node.set_shader_parameter("u_cloud_coverage_rotation", np.asarray(params["u_cloud_coverage_rotation"], dtype=np.float32))
+        node.set_shader_parameter("u_cloud_shape_texture", tex["shape"])
+        if tex["cubemap"] is not None:
+            node.set_shader_parameter("u_cloud_coverage_cubemap", tex["cubemap"])
+        got = _gpu_render(node, cam, depth)
+        declared = cloudy and lod is None
+        assert bool(int(node.kernel_name.split("<")[1].split(",")[0]) & 32) == declared, node.kernel_name
+        lut = node.read_optical_depth() if "light_steps" not in ocfg else None
+        node.close()
+        # the node took the colours as the inspector holds them (sRGB) and converted them on upload (`source_color`);
+        # the oracle works on linear colours
+        oparams = dict(params, u_atmosphere_modulate=tuple(S.srgb_to_linear(params["u_atmosphere_modulate"]).tolist()),
+                       u_atmosphere_ambient_color=tuple(S.srgb_to_linear(params["u_atmosphere_ambient_color"]).tolist()))
+        otex = dict(tex, optical_depth=lut)
+        if declared:
+            otex["cubemap"] = oracle32.cubemap_mip_chain(tex["cubemap"])
+        want, hits = oracle32.render(oparams, otex, dict(ocfg, cube_lod=1) if declared else ocfg, make_frame(cam, np.eye(4), sun), depth, nthreads=8)
+        assert np.array_equal(np.all(got == 0.0, axis=-1), np.all(want == 0.0, axis=-1))
+        finite = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), finite)
+        # clouds are HDR (light unclamped): tolerance is absolute 1e-4 up to 1.0, relative above
+        err = np.abs(got - want)[finite] / np.maximum(1.0, np.abs(want[finite]))
+        # reference-order atmosphere: 1e-5 on the no-cloud variants; the cloud march keeps its hardware exp2 / rcp and fused light block: 5e-5
+        bar = TOL if not ref_order else (5e-5 if "cloud" in shader.replace("no_clouds", "") else 1e-5)
+        assert err.size == 0 or err.max() <= bar, f"seed {seed} {shader} {ocfg} sampler {'declared' if declared else 'lod0'}: {err.max():.3e} (hits {hits})"
 
 
 def test_user_supplied_lut_of_other_size(oracle32):
