@@ -286,8 +286,8 @@ def parse_args():
                          "into hit-balanced row bands, one per GPU, gathered in place into the frame on rank 0 (strong scaling)")
     ap.add_argument("--also", default="lut32,shipped8,clouds_high,clouds_high_rm,direct32x8@3840x2160,clouds_high_rm@3840x2160,"
                                       "clouds_high@lod0,clouds_high_rm@lod0,clouds_high_rm@lod0@3840x2160,direct32x8@moving,clouds_high_rm@moving,"
-                                      "direct32x8+2vp,direct32x8@reforder,noise_cubemap",
-                    help="comma-separated extra workloads (name[@lod0][@reforder][@WxH], name@moving, name+2vp) timed at N=1 after the headline and reported under "
+                                      "direct32x8+2vp,direct32x8@reforder,shipped8@cleared,lut32@cleared,noise_cubemap",
+                    help="comma-separated extra workloads (name[@lod0][@reforder][@cleared][@WxH], name@moving, name+2vp) timed at N=1 after the headline and reported under "
                          "'extra', each with its own roofline blocks: the reference-exact LUT mode and the shipped 8-step shader "
                          "(SURVEY.md 8d), BASELINE configs[2] (clouds_high 1080p) and configs[3] (clouds_high_rm 3840x2160); '' to skip")
     return ap.parse_args()
@@ -688,6 +688,7 @@ def run_workload(torch, S, name, w, h, pose, steps, warmup, textures, params, lo
     pmc = pmc_summary(pmc_name, w, h) if (pose == "P_space" and motion is None and not ref_order) else None
     res = {"workload": f"{desc}{workload_suffix(config_name, sampler)}; {w}x{h}; demo scene, pose {pose}"
                        + ("; atmosphere march in the reference's operation order (atmo_set_precision 2: validation mode)" if ref_order else "")
+                       + ("; discarded fragments store nothing (atmo_set_target_cleared 1)" if (node_extra or {}).get("target_cleared") else "")
                        + ("" if motion is None else f", camera motion {motion[0]} {motion[1]:g} deg/frame, a new pose every step, "
                                                     f"{len(sequence)} poses replayed ping-pong, host at most {FRAMES_IN_FLIGHT} frames ahead"),
            "Mrays/s": w * h * steps / run.dt / 1e6,
@@ -982,6 +983,8 @@ def main():
                     sampler = "lod0"
                 elif o == "reforder":  # atmo_set_precision 2: the v2 march in the reference's operation order (validation mode)
                     node_extra = dict(precise_atmosphere=True)
+                elif o == "cleared":  # atmo_set_target_cleared 1: discarded fragments store nothing (the shader's `discard`)
+                    node_extra = dict(target_cleared=True)
                 else:
                     ew, eh = (int(v) for v in o.split("x"))
             extra[item] = run_workload(torch, S, name, ew, eh, args.pose, ex_steps, ex_warm, textures, params, local_rank, sampler=sampler,

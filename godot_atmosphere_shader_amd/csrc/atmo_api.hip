@@ -116,6 +116,7 @@ struct AtmoContext {
     hipStream_t tex_waited_stream = nullptr;  // the last other stream that was ordered behind tex_event ...
     unsigned tex_waited_version = 0;          // ... and for which update (one wait per stream and update, not per launch)
     int host_double_precision = 0;  // DOUBLE_PRECISION (main:25,118-125)
+    int target_cleared = 0;         // atmo_set_target_cleared: discarded fragments write nothing
     int lane_split = 0;             // 0 = choose per launch by size, 1 = one lane per ray, 2 = two lanes per ray
     int last_split = 1;             // what the most recent launch used (atmo_kernel_name)
     int last_flags = -1;
@@ -165,8 +166,10 @@ struct AtmoContext {
     int f4_footprints = 3;                             // ATMO_F4=0..3 (A/B): bit 0 = float copy of the cubemap footprints, bit 1 = of the shape volume's
     int instream = 1;                                  // ATMO_FB_INSTREAM=0: never sort on the draw stream (A/B)
     uint32_t *measure_cost = nullptr;                  // atmo_measure_tile_costs: the next draw records here
-    bool drew = false;                                 // a draw of this context has been enqueued ...
-    hipStream_t last_draw_stream = nullptr;            // ... most recently on this stream (texture updates elsewhere wait)
+    // the streams draws of this context have been enqueued on since the last texture update waited for them: an update arriving on
+    // stream s is stream-ordered behind the draws on s and has to wait, on the host, for those on every OTHER stream of this set
+    std::vector<hipStream_t> draw_streams;
+    DeviceBuffer measure_buf;                          // atmo_measure_tile_costs: the tile costs on their way to the host (grow-only)
 #ifdef ATMO_WAVE_TRACE
     DeviceBuffer wave_trace;                           // diagnostic build only
     size_t wave_trace_waves = 0;
@@ -374,6 +377,7 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
     rc.out_x0 = f->x0;
     rc.out_y0 = f->y0;
     rc.composite = 0;
+    rc.store_discards = ctx->target_cleared ? 0 : 1;
 }
 
 // Which coverage-cubemap sampler a draw of this context uses (atmo_set_sampler_lod): 1 = the implicit LOD of the linear-mipmap sampler the
@@ -663,6 +667,7 @@ int atmo_destroy(AtmoContext *ctx) {
     dev_free(ctx->cube_f4);
     dev_free(ctx->shape_f4);
     dev_free(ctx->staging);
+    dev_free(ctx->measure_buf);
     if (ctx->tex_event) (void)hipEventDestroy(ctx->tex_event);
     if (ctx->fb_stream) {
         (void)hipStreamSynchronize(ctx->fb_stream);
@@ -755,13 +760,17 @@ static int tex_updated(AtmoContext *ctx, hipStream_t s) {
 //   * an earlier update on ANOTHER stream is chained in front (hipStreamWaitEvent on its event), so the updates of a
 //     context happen in call order whatever streams they come in on, and a draw on `s` that finds tex_stream == s is
 //     behind all of them;
-//   * draws still reading the bound copy on another stream are waited for on the host (device-wide: the caller may have
-//     destroyed that stream since).  Updates are rare and normally arrive on the draw stream, where stream order is enough.
+//   * draws still reading the bound copy on ANY other stream are waited for on the host (device-wide: the caller may have
+//     destroyed such a stream since).  Every stream that has carried a draw since the last such wait counts, not only the most
+//     recent one (round 3 remembered one stream: with draws in flight on A and B, an update on B overwrote what A was still
+//     reading).  Updates are rare and normally arrive on the one draw stream, where stream order is enough and nothing waits.
 static int tex_begin_update(AtmoContext *ctx, hipStream_t s) {
     if (ctx->tex_pending && ctx->tex_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->tex_event, 0));
-    if (ctx->drew && ctx->last_draw_stream != s) {
+    bool elsewhere = false;
+    for (hipStream_t d : ctx->draw_streams) elsewhere = elsewhere || d != s;
+    if (elsewhere) {
         HIP_TRY(ctx, hipDeviceSynchronize());
-        ctx->drew = false;
+        ctx->draw_streams.clear();   // nothing of this context is in flight any more
     }
     return ATMO_OK;
 }
@@ -1070,19 +1079,27 @@ int atmo_measure_tile_costs(AtmoContext *ctx, const AtmoFrame *frame, const floa
     atmo::RenderConsts probe;
     std::memset(&probe, 0, sizeof(probe));
     probe.x0 = frame->x0; probe.y0 = frame->y0; probe.x1 = frame->x1; probe.y1 = frame->y1;
-    const int split = resolve_sampler_lod(ctx, nullptr) ? 1 : choose_split(ctx, frame);
+    const int split = (resolve_sampler_lod(ctx, nullptr) || (ctx->view_steps > 32 && !(ctx->flags & (atmo::KF_LITE | atmo::KF_ATMO_REF)))) ? 1 : choose_split(ctx, frame);
     int gx = 0, gy = 0;
     atmo::render_grid(probe, split, &gx, &gy);
     if (tiles_x) *tiles_x = gx;
     if (tiles_y) *tiles_y = gy;
-    if (tile_w) *tile_w = 16;
-    if (tile_h) *tile_h = split == 2 ? 4 : 8;
+    {
+        int tw = 0, th = 0;
+        atmo::render_tile_size(split, &tw, &th);  // what render_grid cuts the rect into (a build knob: ATMO_TILE_H)
+        if (tile_w) *tile_w = tw;
+        if (tile_h) *tile_h = th;
+    }
     if (!cost_host) return ATMO_OK;
     if (capacity_tiles < gx * gy) return fail(ctx, ATMO_E_ARG, "atmo_measure_tile_costs: cost buffer too small (call with cost_host = NULL for the grid)");
-    uint32_t *d = nullptr;
     const size_t bytes = (size_t)gx * gy * sizeof(uint32_t);
-    HIP_TRY(ctx, hipMalloc(&d, bytes));
     hipStream_t s = (hipStream_t)stream;
+    if (ctx->measure_buf.bytes < bytes) {  // grow-only; an earlier measurement on another stream may still be copying out of it
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        const int rc0 = dev_alloc(ctx, ctx->measure_buf, bytes);
+        if (rc0 != ATMO_OK) return rc0;
+    }
+    uint32_t *d = (uint32_t *)ctx->measure_buf.ptr;
     hipError_t e = hipMemsetAsync(d, 0, bytes, s);
     int rc = ATMO_OK;
     if (e != hipSuccess) rc = hip_fail(ctx, e, "hipMemsetAsync");
@@ -1098,7 +1115,6 @@ int atmo_measure_tile_costs(AtmoContext *ctx, const AtmoFrame *frame, const floa
     } else {
         (void)hipStreamSynchronize(s);
     }
-    (void)hipFree(d);
     return rc;
 }
 
@@ -1134,11 +1150,18 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         rc.out_x0 = 0;
         rc.out_y0 = 0;
         rc.composite = 1;
+        rc.store_discards = 0;
     }
     hipStream_t s = (hipStream_t)stream;
     { const int rc0 = tex_order(ctx, s); if (rc0 != ATMO_OK) return rc0; }  // texture updated on another stream
     int split = choose_split(ctx, frame);
     int flags = ctx->flags;
+    if (ctx->view_steps > 32 && !(flags & (atmo::KF_LITE | atmo::KF_ATMO_REF))) {
+        // long view marches accumulate the position in the reference's form (march_atmosphere<VIEWPOS>): the default form's running sum
+        // drifted to 1.08e-4 of alpha at 64 steps on thin atmospheres; up to 32 steps the kernels are the round-3 ones, byte for byte
+        flags |= atmo::KF_VIEW_POS;
+        split = 1;
+    }
     {   // the coverage cubemap's sampler: as declared (implicit LOD) when a mip chain is bound; one lane per ray
         const char *why_not = nullptr;
         const int lod = resolve_sampler_lod(ctx, &why_not);
@@ -1289,8 +1312,11 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         ctx->fb_sorts += 1;
     }
     if (fb) fb->n += 1;
-    ctx->drew = true;
-    ctx->last_draw_stream = s;
+    {
+        bool known = false;
+        for (hipStream_t d : ctx->draw_streams) known = known || d == s;
+        if (!known) ctx->draw_streams.push_back(s);
+    }
     ctx->last_split = split;
     ctx->launch_counter += 1;  // counted only once the launch was accepted
     if (timed) {
@@ -1323,6 +1349,12 @@ int atmo_set_precision(AtmoContext *ctx, int mode) {
 int atmo_set_host_double_precision(AtmoContext *ctx, int enable) {
     if (!ctx) return ATMO_E_ARG;
     ctx->host_double_precision = enable ? 1 : 0;
+    return ATMO_OK;
+}
+
+int atmo_set_target_cleared(AtmoContext *ctx, int cleared) {
+    if (!ctx) return ATMO_E_ARG;
+    ctx->target_cleared = cleared ? 1 : 0;
     return ATMO_OK;
 }
 

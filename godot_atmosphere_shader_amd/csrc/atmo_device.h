@@ -84,6 +84,7 @@ struct RenderConsts {
     const float *cube_f4;           // level 0 of `cube` with every footprint's four texels as exact byte / 255 floats (16 B), or null
     const float *shape_f4;          // the same for `shape`
     float miss_k;                   // [host] (|c|^2 - R_atm^2) (1 - 1e-3)^2 when the test is usable, else 0
+    int32_t store_discards;         // 1: a discarded fragment stores (0,0,0,0); 0: it stores nothing (composite, or atmo_set_target_cleared)
 };
 
 struct BakeConsts {
@@ -103,7 +104,8 @@ struct NoiseCubemapConsts {
 
 // kernel launchers (atmo_kernels.hip)
 enum KernelFlags : int { KF_CLOUDS = 1, KF_CLOUD_LIGHT_RM = 2, KF_LIGHT_DIRECT = 4, KF_LITE = 8, KF_PRECISE = 16, KF_CUBE_LOD = 32,
-                          KF_ATMO_REF = 64 /* the v2 atmosphere march in the reference's operation order (atmo_set_precision 2) */ };
+                          KF_ATMO_REF = 64 /* the v2 atmosphere march in the reference's operation order (atmo_set_precision 2) */,
+                          KF_VIEW_POS = 128 /* view_steps > 32: the fast v2 march accumulates the view-space position like the reference (march_atmosphere<VIEWPOS>) */ };
 
 hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream_t stream);
 hipError_t launch_bake(const BakeConsts &bc, hipStream_t stream);
@@ -117,6 +119,7 @@ hipError_t launch_layout_cube(const uint8_t *faces, int n, uint32_t *out, hipStr
 hipError_t launch_footprints_f4(const uint32_t *words, size_t n_words, float *out4, hipStream_t stream);
 hipError_t launch_cube_mip(const uint8_t *level, int n, uint8_t *next, hipStream_t stream);
 void render_grid(const RenderConsts &rc, int split, int *tiles_x, int *tiles_y);
+void render_tile_size(int split, int *tile_w, int *tile_h);  // pixels per workgroup tile of a launch with `split` lanes per ray
 hipError_t launch_noise_cubemap(const NoiseCubemapConsts &nc, hipStream_t stream);
 const char *render_kernel_name(int flags, int light_steps, int split);
 hipError_t launch_light_probe(const float *pos, const float *dir, int n, float planet_radius, float atmosphere_height, float density,

@@ -648,7 +648,14 @@ __device__ __forceinline__ float sun_od_direct(const LightMarchConsts &k, float 
 // SPLIT = 2: lane `half` integrates its half of the view steps ([0, n0) / [n0, steps)) with the optical depth counted
 // from its own first sample; exp(-(V_A + v) k) = exp(-V_A k) exp(-v k) folds the first half's total V_A into the
 // second half's sum afterwards (same real function, one extra exp per channel per ray).
-template <bool DIRECT, int LSTEPS, int SPLIT>
+// VIEWPOS (KF_VIEW_POS; contexts with more than 32 view steps): the sample position is accumulated the way the reference does it
+// (atmosphere_funcs_v2.gdshaderinc:57-58,81) -- in VIEW space from ray_origin + ray_dir * t_begin, one rounded addition of the rounded
+// ray_dir * step_len per step, the planet centre subtracted at every use -- instead of one running position relative to the centre.  In real
+// arithmetic the same points; in fp32 the two running sums drift apart by a few ulp of the position per step, and on a thin atmosphere
+// (H / R ~ 0.05) 64 steps of that reached 1.08e-4 of alpha (2 of 252 fuzz scenes, round 3).  Three more subtractions per step, 4-7 % on
+// the direct-light loop, so the kernels with up to 32 steps keep the cheaper form (and their ISA): this is a separate instantiation.
+__device__ __forceinline__ V3 scale_unfused(V3 d, float s) { return V3{d.x * s, d.y * s, d.z * s}; }  // no contraction here: products rounded on their own
+template <bool DIRECT, int LSTEPS, int SPLIT, bool VIEWPOS = false>
 __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 dir, float t_begin, float step_len, float jitter, int half) {
 #pragma clang fp contract(fast)
     const int n0 = SPLIT == 2 ? (rc.view_steps + 1) / 2 : rc.view_steps;
@@ -668,14 +675,20 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
     const float half_w = 0.5f * (float)rc.lut_w, x_off = half_w - 0.5f;
     const float lut_hf = (float)rc.lut_h, y_off = lut_hf - 0.5f;
 
+    static_assert(!VIEWPOS || SPLIT == 1, "reference-form position accumulation: one lane per ray");
+    const V3 p0 = scale_unfused(dir, t_begin), sd = scale_unfused(dir, step_len);  // ray_origin (0) + ray_dir * t_begin; ray_dir * step_len
+    float pvx = p0.x, pvy = p0.y, pvz = p0.z;                                      // VIEWPOS: the view-space position
     float ox = fmaf(dir.x, t_begin, -rc.center[0]);
     float oy = fmaf(dir.y, t_begin, -rc.center[1]);
     float oz = fmaf(dir.z, t_begin, -rc.center[2]);
-    const float sdx = dir.x * step_len, sdy = dir.y * step_len, sdz = dir.z * step_len;
+    const float sdx = VIEWPOS ? sd.x : dir.x * step_len, sdy = VIEWPOS ? sd.y : dir.y * step_len, sdz = VIEWPOS ? sd.z : dir.z * step_len;
     const float dstep = dens2 * step_len;
     float lr = 0.0f, lg = 0.0f, lb = 0.0f, view_od = 0.0f;
 
     for (int i = 0; i < steps; ++i) {
+        if (VIEWPOS) {
+            ox = pvx - rc.center[0]; oy = pvy - rc.center[1]; oz = pvz - rc.center[2];
+        }
         const float r2 = ox * ox + oy * oy + oz * oz;
         const float bdot = ox * sx + oy * sy + oz * sz;
         // LUT mode needs 1/r for the cosine; the direct light march only needs r
@@ -706,7 +719,11 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
             lb = fmaf(d, eb, lb);
         }
 
-        ox += sdx; oy += sdy; oz += sdz;
+        if (VIEWPOS) {
+            pvx += sdx; pvy += sdy; pvz += sdz;
+        } else {
+            ox += sdx; oy += sdy; oz += sdz;
+        }
     }
 
     if (SPLIT == 2) {
@@ -1436,6 +1453,8 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
     constexpr bool PRECISE = (FLAGS & KF_PRECISE) != 0;
     constexpr bool LOD = (FLAGS & KF_CUBE_LOD) != 0;
     constexpr bool ATMO_REF = (FLAGS & KF_ATMO_REF) != 0;
+    constexpr bool VIEWPOS = (FLAGS & KF_VIEW_POS) != 0;
+    static_assert(!VIEWPOS || (!LITE && !ATMO_REF && SPLIT == 1), "KF_VIEW_POS: the fast v2 march, one lane per ray");
     constexpr bool DIET = !DIRECT && !((FLAGS & KF_CLOUDS) && (FLAGS & KF_CLOUD_LIGHT_RM));
     constexpr bool FASTMISS = (ATMO_FAST_MISS_MASK >> ((DIRECT ? 1 : 0) + (CLOUDS ? 2 : 0) + (LITE ? 4 : 0))) & 1;
     static_assert(!LOD || (CLOUDS && PRECISE && SPLIT == 1), "implicit cubemap LOD: precise cloud kernels, one lane per ray");
@@ -1472,7 +1491,7 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
         const float cv = rc.center[0] * ax + rc.center[1] * ay + rc.center[2] * az;
         const float vv = ax * ax + ay * ay + az * az;
         if (cv * cv < rc.miss_k * vv) {
-            if (!rc.composite && half == 0) *out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (rc.store_discards && half == 0) *out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             return;
         }
     }
@@ -1509,7 +1528,7 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
     const float2 rs_atmo = hit_radius<DIET>(sh, rc.atmosphere_radius);
 
     if (rs_atmo.x == rs_atmo.y) {  // discard: nothing reaches the blend stage
-        if (!rc.composite && half == 0) *out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (rc.store_discards && half == 0) *out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         return;
     }
     const float t_begin = fmaxf(rs_atmo.x, 0.0f);
@@ -1533,7 +1552,7 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
             rgba = march_atmosphere_v2_precise<DIRECT>(rc, dir, t_begin, t_end, jitter);  // reference order (atmo_set_precision 2)
         } else {
             const float view_step_len = ieee_div(t_end - t_begin, (float)rc.view_steps);
-            rgba = march_atmosphere<DIRECT, LSTEPS, SPLIT>(rc, dir, t_begin, view_step_len, jitter, half);
+            rgba = march_atmosphere<DIRECT, LSTEPS, SPLIT, VIEWPOS>(rc, dir, t_begin, view_step_len, jitter, half);
         }
     }
 
@@ -2090,6 +2109,10 @@ hipError_t launch_selftest(uint32_t first_bits, uint32_t count, float c, float r
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------
+void render_tile_size(int split, int *tile_w, int *tile_h) {
+    *tile_w = TILE_W;
+    *tile_h = TILE_H / (split == 2 ? 2 : 1);
+}
 void render_grid(const RenderConsts &rc, int split, int *tiles_x, int *tiles_y) {
     const int th = TILE_H / (split == 2 ? 2 : 1);  // pixel rows per workgroup
     *tiles_x = (rc.x1 - rc.x0 + TILE_W - 1) / TILE_W;
@@ -2164,15 +2187,39 @@ hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream
     case KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT:
         return rc.light_steps == 8 ? launch_s<KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT, 8, 1>(rc, stream)
                                    : launch_s<KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT, 0, 1>(rc, stream);
-    default: return hipErrorInvalidValue;
+    default: break;
     }
+    // more than 32 view steps (KF_VIEW_POS, set by the host): the fast v2 march with the reference's position accumulation; one lane per ray,
+    // run-time light-step loop
+    if (flags & KF_VIEW_POS) {
+        switch (flags & ~KF_VIEW_POS) {
+#define ATMO_VP_CASE(F) case (F): return launch_s<(F) | KF_VIEW_POS, 0, 1>(rc, stream);
+            ATMO_VP_CASE(0)
+            ATMO_VP_CASE(KF_LIGHT_DIRECT)
+            ATMO_VP_CASE(KF_CLOUDS)
+            ATMO_VP_CASE(KF_CLOUDS | KF_LIGHT_DIRECT)
+            ATMO_VP_CASE(KF_CLOUDS | KF_CLOUD_LIGHT_RM)
+            ATMO_VP_CASE(KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT)
+            ATMO_VP_CASE(KF_PRECISE | KF_CLOUDS)
+            ATMO_VP_CASE(KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT)
+            ATMO_VP_CASE(KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM)
+            ATMO_VP_CASE(KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT)
+            ATMO_VP_CASE(KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS)
+            ATMO_VP_CASE(KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT)
+            ATMO_VP_CASE(KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM)
+            ATMO_VP_CASE(KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM | KF_LIGHT_DIRECT)
+#undef ATMO_VP_CASE
+        default: break;
+        }
+    }
+    return hipErrorInvalidValue;
 }
 
 const char *render_kernel_name(int flags, int light_steps, int split) {
     // demangled template name as rocprofv3 prints it: atmo_render_kernel<FLAGS, LSTEPS, SPLIT>
     static thread_local char name[64];
     const bool v2_precise = (flags & KF_ATMO_REF) != 0;  // its light march is a run-time loop
-    const int lsteps = ((flags & KF_LIGHT_DIRECT) && light_steps == 8 && !v2_precise) ? 8 : 0;
+    const int lsteps = ((flags & KF_LIGHT_DIRECT) && light_steps == 8 && !v2_precise && !(flags & KF_VIEW_POS)) ? 8 : 0;
     snprintf(name, sizeof(name), "atmo_render_kernel%s<%d, %d, %d>", render_sgpr_cap80(flags) ? "_s80" : "", flags, lsteps, split == 2 ? 2 : 1);
     return name;
 }

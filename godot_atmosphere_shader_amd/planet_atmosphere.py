@@ -215,7 +215,7 @@ class PlanetAtmosphere:
     def __init__(self, device: int = 0, light_mode: str = "lut", light_steps: int = 0,
                  view_steps: int | None = None, cloud_steps: int | None = None, blue_noise=None,
                  precise_clouds: bool = True, precise_atmosphere: bool = False, double_precision: bool = False, lane_split: int = 0,
-                 tile_feedback: int = -1, cubemap_lod: bool | None = None):
+                 tile_feedback: int = -1, cubemap_lod: bool | None = None, target_cleared: bool = False):
         self._lib = N.load()
         self._device = int(device)
         self._light_mode = {"lut": N.LIGHT_LUT, "direct": N.LIGHT_DIRECT}[light_mode]
@@ -227,6 +227,7 @@ class PlanetAtmosphere:
         self._double_precision = bool(double_precision)  # `#define DOUBLE_PRECISION` (main:25): engine negates INV_VIEW origin
         self._lane_split = int(lane_split)  # atmo_set_lane_split: 0 auto, 1 / 2 lanes per ray
         self._tile_feedback = int(tile_feedback)  # atmo_set_tile_feedback: -1 default (on), 0 off, 1 on
+        self._target_cleared = bool(target_cleared)  # atmo_set_target_cleared: discarded fragments write nothing (the shader's `discard`)
         # atmo_set_sampler_lod: None = as the shader declares the samplerCube (linear-mipmap: implicit LOD from the 2x2 pixel quad when a mip
         # chain is bound), True = the same, required (an error if the draw cannot use it), False = level 0 only
         self._cubemap_lod = None if cubemap_lod is None else bool(cubemap_lod)
@@ -268,6 +269,8 @@ class PlanetAtmosphere:
         N.check(ctx, self._lib.atmo_set_host_double_precision(ctx, 1 if self._double_precision else 0))
         N.check(ctx, self._lib.atmo_set_lane_split(ctx, self._lane_split))
         N.check(ctx, self._lib.atmo_set_tile_feedback(ctx, self._tile_feedback))
+        if self._target_cleared:  # (an A/B library older than round 4 has no such entry point: only asked for when wanted)
+            N.check(ctx, self._lib.atmo_set_target_cleared(ctx, 1))
         N.check(ctx, self._lib.atmo_set_sampler_lod(ctx, -1 if self._cubemap_lod is None else (1 if self._cubemap_lod else 0)))
 
     def close(self):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ATMO_ABI_VERSION 3
+#define ATMO_ABI_VERSION 4
 
 typedef struct AtmoContext AtmoContext;
 
@@ -231,6 +231,17 @@ int atmo_set_precision(AtmoContext *ctx, int mode);
  * a host passes the engine's matrix unchanged.  0 (default) = single-precision engine build.
  */
 int atmo_set_host_double_precision(AtmoContext *ctx, int enable);
+
+/*
+ * Replaces: what `discard` means to the engine (planet_atmosphere_main.gdshaderinc:189-196, 150-152: a fragment whose ray misses the
+ * atmosphere shell writes NOTHING -- the render target keeps what it held).  atmo_render has no render target of the engine's to leave
+ * alone, so by default (0) it writes (0, 0, 0, 0) into every discarded pixel of the rect: the output buffer then needs no preparation.
+ * 1 = the caller states that rgba_dev already holds what discarded pixels shall show (a target cleared once and re-used: a discarded
+ * pixel stays discarded while the camera stands still; or the caller clears it per frame anyway): discarded fragments retire without a
+ * store, exactly like the shader's -- at pose P_space of the demo 40 % of a 1920x1080 frame's 33 MB store stream.
+ * atmo_render_composite never stores discarded fragments, whatever this is set to.
+ */
+int atmo_set_target_cleared(AtmoContext *ctx, int cleared);
 
 /*
  * Launch order (no reference counterpart): with feedback on, every 8th draw (the first four back to back) records how

@@ -150,3 +150,7 @@ def random_scene(k):
     sun = center + sun / np.linalg.norm(sun) * R * 50.0
     cam_args = dict(eye=eye, target=target, fovy_deg=float(rng.uniform(40, 90)), near=0.05 * H, far=20.0 * R)
     return params, cam_args, tuple(float(v) for v in sun), model, ("ground" if k % 3 else "far")
+
+
+# ---- round 4 vectors (reference_exec_r4.npz): thin atmospheres at 64 view steps; seeds of tests/test_gpu_parity.py::_random_scene ---------
+R4_THIN_SEEDS = (55, 91, 13, 43)

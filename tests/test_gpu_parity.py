@@ -419,6 +419,78 @@ def test_parity_random_scenes(oracle32, seed):
         assert err.size == 0 or err.max() <= bar, f"seed {seed} {shader} {ocfg} sampler {'declared' if declared else 'lod0'}: {err.max():.3e} (hits {hits})"
 
 
+
+def test_cleared_target_mode_stores_nothing_for_discarded_fragments():
+    """atmo_set_target_cleared(ctx, 1): a discarded fragment writes NOTHING, like the shader's `discard`
+    (planet_atmosphere_main.gdshaderinc:189-196); by default it writes (0, 0, 0, 0).  Flag on == flag off on every kept pixel, bit for bit,
+    and a poisoned target is untouched everywhere else -- for the sure-miss lanes (baked-LUT kernels), the exact-prologue discards (every
+    kernel), rect draws, and both cubemap samplers' cloud kernels."""
+    import torch
+
+    tex, params = demo_textures(cube_n=64, shape_n=16), demo_params()
+    poison = 123.25
+    for config_name, kw in (("no_clouds_8", {}), ("no_clouds_32x8_direct", {}), ("clouds_high", {}), ("clouds_high_rm", dict(cubemap_lod=None)),
+                            ("v1_no_clouds", {})):
+        for pose, (w, h), rect in (("P_space", (192, 108), None), ("P_limb", (160, 90), (5, 3, 149, 77))):
+            cam = S.Camera.from_pose(w, h, pose)
+            depth = S.depth_ground_sphere(cam)
+            base = make_node(config_name, tex, params, **kw)
+            want = _gpu_render(base, cam, depth, rect=rect)
+            base.close()
+            node = make_node(config_name, tex, params, target_cleared=True, **kw)
+            rh, rw = want.shape[:2]
+            out = torch.full((rh, rw, 4), poison, dtype=torch.float32, device="cuda")
+            node.render(cam, torch.from_numpy(depth).cuda(), out=out, rect=rect)
+            torch.cuda.synchronize()
+            node.close()
+            got = out.cpu().numpy()
+            discarded = np.all(want == 0.0, axis=-1)
+            assert discarded.any() and not discarded.all(), (config_name, pose)
+            assert np.array_equal(got[~discarded], want[~discarded]), (config_name, pose)
+            assert np.all(got[discarded] == poison), (config_name, pose)
+
+
+
+def test_texture_update_waits_for_draws_on_every_other_stream():
+    """a context may draw on several streams (one feedback state per stream); a same-size texture update overwrites the
+    bound copy in place.  Round 3 remembered only the LAST draw stream: with a long run of draws in flight on stream A, one draw on B and then
+    an update arriving on B, nothing waited and A's draws read a half-written texture.  Now every stream that has carried a draw is waited for."""
+    import torch
+    from godot_atmosphere_shader_amd import _native as N
+
+    tex, params = demo_textures(cube_n=64, shape_n=32), demo_params()
+    shape2 = S.make_shape_texture(32, seed=77)
+    w, h = 1280, 720
+    cam = S.Camera.from_pose(w, h, "P_clouds")   # every ray marches: ~0.5 ms per draw
+    depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
+    small = S.Camera.from_pose(64, 36, "P_clouds")
+    small_depth = torch.from_numpy(S.depth_ground_sphere(small)).cuda()
+    node = make_node("clouds_high_rm", tex, params)
+    want_old = node.render(cam, depth).cpu().numpy()
+    ref = make_node("clouds_high_rm", dict(tex, shape=shape2), params)
+    want_new = ref.render(cam, depth).cpu().numpy()
+    ref.close()
+    assert not np.array_equal(want_old, want_new)
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = [torch.empty((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    n_draws = 24
+    for k in range(n_draws):                      # ~12 ms of draws queued on A ...
+        node.render(cam, depth, out=outs[k % 2], stream=a)
+    node.render(small, small_depth, stream=b)      # ... one draw on B (the most recent draw stream) ...
+    raw = np.ascontiguousarray(shape2, dtype=np.uint8)
+    rc = node._lib.atmo_set_texture(node._ctx, b"u_cloud_shape_texture", N.TEX_3D_R8, 32, 32, 32, 1, raw.ctypes.data_as(C.c_void_p), N.MEM_HOST,
+                                    C.c_void_p(b.cuda_stream))   # ... and the update arrives on B
+    assert rc == N.ATMO_OK
+    torch.cuda.synchronize()
+    for k in (n_draws - 2, n_draws - 1):           # the last draws on A still saw the OLD texture, whole
+        assert np.array_equal(outs[k % 2].cpu().numpy(), want_old), k
+    got_new = node.render(cam, depth, stream=a)     # and a later draw on A is ordered behind the update
+    torch.cuda.synchronize()
+    assert np.array_equal(got_new.cpu().numpy(), want_new)
+    node.close()
+
+
 def test_user_supplied_lut_of_other_size(oracle32):
     """atmo_set_texture with a LUT that is not 256x256 (apron layout with run-time stride)."""
     w, h = 128, 72
@@ -1364,8 +1436,8 @@ def test_degenerate_cloud_layers_follow_the_arithmetic(oracle32, case):
 def test_reference_order_v2_atmosphere(oracle32):
     """atmo_set_precision(ctx, 2): the v2 atmosphere march in the reference's operation order (view-space position
     accumulated, centre subtracted at every use, alpha built step by step, IEEE sqrt / divide, expf).  Held to 1e-5 -- ten times tighter than
-    the contract -- on the demo poses in both light modes, and on the two random scenes where the default form's running sums reach 1.07e-4
-    with 64 view steps; the default form stays within the 1e-4 contract on the demo poses."""
+    the contract -- on the demo poses in both light modes, and on the two random scenes where round 3's default form had reached 1.07e-4
+    with 64 view steps (since round 4 the default form is at a few 1e-6 there as well)."""
     from godot_atmosphere_shader_amd import PlanetAtmosphere, load_shader
     from godot_atmosphere_shader_amd.planet_atmosphere import make_frame
 
@@ -1424,4 +1496,6 @@ def test_reference_order_v2_atmosphere(oracle32):
                                       make_frame(cam, np.eye(4), sun), depth, nthreads=8)
             errs[precise] = float(np.abs(got - want).max())
         print(f"seed {seed}, 64 view steps: reference order {errs[True]:.2e}, default form {errs[False]:.2e}")
-        assert errs[True] <= 1e-5 and errs[True] < 0.2 * errs[False]
+        # round 4: contexts with more than 32 view steps accumulate the position like the reference in the DEFAULT mode too (KF_VIEW_POS):
+        # the two scenes that had reached 1.07e-4 / 1.08e-4 are now at a few 1e-6
+        assert errs[True] <= 1e-5 and errs[False] <= 2e-5

@@ -2,7 +2,7 @@
 """How much of a short render kernel is not shading?  Times the shipped8 configuration (8 view steps, baked LUT) at
 1920x1080 for a camera that sees the planet (P_space: 60 % of the rays shade) and for one that looks away from it (every
 ray leaves after the exact prologue and stores zeros): the second number is launch + wave start-up + prologue + the 33 MB
-store stream.  python tools/floor_probe.py"""
+store stream; "+cleared" = atmo_set_target_cleared(ctx, 1), discarded fragments store nothing.  python tools/floor_probe.py"""
 import os
 import sys
 
@@ -33,13 +33,15 @@ def timed(node, cam, depth, n=300):
 def main():
     w, h = 1920, 1080
     tex = demo_textures()
-    for cfg in ("no_clouds_8", "no_clouds_32_lut", "no_clouds_32x8_direct"):
-        node = make_node(cfg, tex)
+    for cfg, kw in (("no_clouds_8", {}), ("no_clouds_8", dict(target_cleared=True)), ("no_clouds_32_lut", {}), ("no_clouds_32_lut", dict(target_cleared=True)),
+                    ("no_clouds_32x8_direct", {}), ("no_clouds_32x8_direct", dict(target_cleared=True))):
+        node = make_node(cfg, tex, **kw)
+        cfg = cfg + ("+cleared" if kw else "")
         for name, cam in (("P_space", S.Camera.from_pose(w, h, "P_space")),
                           ("away", S.Camera(w, h, eye=(0.0, 0.0, 1000.0), target=(0.0, 1000.0, 1000.0), far=4000.0))):
             depth = torch.from_numpy(S.depth_far(cam)).cuda()
             ms, shaded = timed(node, cam, depth)
-            print(f"{cfg:24s} {name:8s} {ms * 1000:7.1f} us per frame   shaded fraction {shaded:.2f}")
+            print(f"{cfg:32s} {name:8s} {ms * 1000:7.1f} us per frame   shaded fraction {shaded:.2f}")
         node.close()
     # the store stream alone
     out = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
@@ -52,7 +54,7 @@ def main():
         out.zero_()
     e1.record()
     torch.cuda.synchronize()
-    print(f"{'memset 33 MB':24s} {'':8s} {e0.elapsed_time(e1) / 300 * 1000:7.1f} us")
+    print(f"{'memset 33 MB':32s} {'':8s} {e0.elapsed_time(e1) / 300 * 1000:7.1f} us")
 
 
 if __name__ == "__main__":
