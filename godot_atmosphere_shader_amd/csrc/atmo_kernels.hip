@@ -422,6 +422,7 @@ __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, in
 struct QuadNb {
     bool vx, vy;
     V3 px, py;  // horizontal / vertical partner's sample position (model space)
+    const f32x4 *lvl;  // LDS: per mip level {0.5 n_l, 4 n_l + 4, 4 (n_l + 1)^2, byte offset of footprint (0, 0) of face 0} (cube_level_table)
 };
 
 // seamless bilinear sample of mip level `level` on face `face` at face coordinates (s, t); exact UNORM8 + unfused mixes
@@ -483,31 +484,46 @@ __device__ __forceinline__ float cube_sample_lod(const RenderConsts &rc, V3 d, b
     return v0 * (1.0f - fr) + v1 * fr;
 }
 
-// ---- the same sampler on the fast path (round 3): power-of-two faces up to 1024 texels ------------------------------------------
+// ---- the same sampler on the fast path (rounds 3-4): power-of-two faces up to 1024 texels ----------------------------------------
 // What the general form above spends and this one does not: five IEEE divisions per sample (here: one v_rcp + two Markstein
-// steps shared by s and t -- the IEEE quotients, as in cube_sample<true> -- and plain v_rcp for the derivatives, whose
-// relative error of 1e-7 moves lambda by 1e-7), face selection by compares (here: v_cubeid/sc/tc/ma), flat loads with
-// integer address chains and a global load of the level offset (here: one buffer gather per level at a byte offset formed in
-// fp32; the level's base follows from the geometric series of the packed chain).  Bit-for-bit the same s, t, texels and
-// filters as the general form; lambda agrees to a few ulp.
-__device__ __forceinline__ float cube_level_sample_fast(__amdgpu_buffer_rsrc_t rs, bool f4, float fid, float q1s, float q1t, float nf, float c0, int lo) {
-    // level `lo`: faces of nl = n >> lo texels, footprints (nl + 1)^2 per face, packed behind the levels below it:
-    //   words before level l = 6 sum_{k<l} (n_k + 1)^2 = 8 n^2 - 8 nl^2 + 24 n - 24 nl + 6 l        (n a power of two)
-    const float nl = __builtin_amdgcn_ldexpf(nf, -lo);
-    const float hn = 0.5f * nl;
+// steps shared by s and t -- the IEEE quotients, as in cube_sample<true> -- and ONE plain v_rcp for the derivatives of both quad
+// partners, whose relative error of 1e-7 moves lambda by 1e-7), face selection by compares (here: v_cubeid/sc/tc/ma), flat loads
+// with integer address chains and a global load of the level offset (here: one buffer gather per level at a byte offset formed in
+// fp32 from four per-level constants read from a 16-entry LDS table).  Bit-for-bit the same s, t, texels and filters as the general
+// form; lambda agrees to a few ulp.
+//
+// Per-level constants (round 4; were ~12 VALU instructions per level and sample: ldexp, the closed-form level base, strides):
+//   level l of a power-of-two chain: faces of nl = n >> l texels, (nl + 1)^2 footprints per face, packed behind the levels below it;
+//   words before level l = 6 sum_{k<l} (n_k + 1)^2 = 8 n^2 - 8 nl^2 + 24 n - 24 nl + 6 l.
+// Entry l = {hn = nl / 2, s4 = 4 nl + 4 (bytes per footprint row), F = s4 (nl + 1) (bytes per face), G = 4 words_before(l) + s4 + 4
+// (byte offset of the footprint of texel (0, 0) on face 0)}; every entry and every partial sum below is a multiple of 4 below 2^26
+// (33.6 MB for the whole chain at n = 1024), i.e. exact in fp32.  Each wave fills the table itself before it reads it (identical
+// values from both waves of a workgroup: no barrier).
+constexpr int CUBE_LEVEL_TABLE = 16;
+__device__ __forceinline__ void cube_level_table_fill(const RenderConsts &rc, f32x4 *lvl, int lane) {
+    if (lane < CUBE_LEVEL_TABLE) {
+        const float nf = (float)rc.cube_n, l = (float)lane;
+        const float nl = __builtin_amdgcn_ldexpf(nf, -lane);
+        const float s4 = 4.0f * nl + 4.0f;
+        const float c0 = __builtin_fmaf(32.0f * nf, nf, 96.0f * nf);
+        const float base = __builtin_fmaf(-32.0f * nl, nl, __builtin_fmaf(-96.0f, nl, __builtin_fmaf(24.0f, l, c0)));
+        lvl[lane] = f32x4{0.5f * nl, s4, s4 * (nl + 1.0f), base + s4 + 4.0f};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+}
+__device__ __forceinline__ float cube_level_sample_fast(__amdgpu_buffer_rsrc_t rs, bool f4, float fid, float q1s, float q1t, f32x4 k) {
+    const float hn = k.x, s4 = k.y;
     const float x = __builtin_fmaf(q1s, hn, -0.5f), y = __builtin_fmaf(q1t, hn, -0.5f);  // ((q + 1) * 0.5) * nl - 0.5: the scalings are exact
     const float xf = floorf(x), yf = floorf(y);
     const float fx = x - xf, fy = y - yf;
-    const float nm1 = nl - 1.0f, s4 = 4.0f * nl + 4.0f;
+    const float nm1 = __builtin_fmaf(hn, 2.0f, -1.0f);
     const float ic = __builtin_amdgcn_fmed3f(xf, -1.0f, nm1), jc = __builtin_amdgcn_fmed3f(yf, -1.0f, nm1);
-    // byte offsets: every term and partial sum is a multiple of 4 below 2^26 (33.6 MB for the whole chain at n = 1024): exact
-    const float base = __builtin_fmaf(-32.0f * nl, nl, __builtin_fmaf(-96.0f, nl, __builtin_fmaf(24.0f, (float)lo, c0)));
-    const float in_level = __builtin_fmaf(fid, s4 * (nl + 1.0f), __builtin_fmaf(jc, s4, __builtin_fmaf(ic, 4.0f, s4 + 4.0f)));
+    const float off = __builtin_fmaf(fid, k.z, __builtin_fmaf(jc, s4, __builtin_fmaf(ic, 4.0f, k.w)));
     f32x4 t;
     if (f4) {  // `rs` is the chain's float copy: 16-byte footprints at four times the offset (a multiple of 16 below 2^28: exact in fp32)
-        t = buf_f32x4(rs, (uint32_t)((base + in_level) * 4.0f));
+        t = buf_f32x4(rs, (uint32_t)(off * 4.0f));
     } else {
-        const uint32_t w = buf_u32(rs, (uint32_t)(base + in_level));
+        const uint32_t w = buf_u32(rs, (uint32_t)off);
         t = f32x4{unorm8_exact(ub0(w)), unorm8_exact(ub1(w)), unorm8_exact(ub2(w)), unorm8_exact(ub3(w))};
     }
     return bilinear_exact4(t.x, t.y, t.z, t.w, fx, fy);
@@ -531,23 +547,29 @@ __device__ __forceinline__ CubeFaceFrame cube_face_frame(bool isz, bool isy, boo
     f.b2 = f.my * f.sgn;          // +Y: z, -Y: -z
     return f;
 }
-__device__ __forceinline__ float cube_lod_rho2(const CubeFaceFrame &f, float sc, float tc, float ma, V3 d, bool valid, V3 q, float n2, float rho2) {
+// One quad partner's finite difference on the selected face, as numerator and denominator of (2 rho / n)^2:
+//   s' - s = 0.5 (dsc ma - sc dma) / (ma ma') = 0.5 (dsc - (sc / ma) dma) / ma',   ma' = ma + dma      (cancellation-free, qs = sc / ma)
+//   num = (dsc - qs dma)^2 + (dtc - qt dma)^2,   den = ma'^2;   a partner that does not reach the call, or lies beyond the face's half
+//   space (ma' <= 0), contributes num = 0.
+// The difference q - d is rounded like the reference's; the face frame applied to it is exact (one non-zero term per sum, whether the
+// compiler fuses it or not); everything behind it only moves lambda by ulps.
+__device__ __forceinline__ void cube_lod_partner(const CubeFaceFrame &f, float qs, float qt, float ma, V3 d, bool valid, V3 q, float &num, float &den) {
     const V3 dv = {q.x - d.x, q.y - d.y, q.z - d.z};
-    // exact: one non-zero product per sum
-    const float dsc = f.a1 * dv.x + f.a2 * dv.z, dtc = f.b1 * dv.y + f.b2 * dv.z;
-    const float dma = f.sgn * (f.mx * dv.x + f.my * dv.y + f.mz * dv.z);
-    float r2;
-    const float ma2 = ma + dma;
+    float n_, ma2;
     {
 #pragma clang fp contract(fast)
-        const float inv = 0.5f * hw_rcp(ma * ma2);
-        const float ds = (dsc * ma - sc * dma) * inv, dt = (dtc * ma - tc * dma) * inv;
-        r2 = (ds * ds + dt * dt) * n2;
+        const float dsc = f.a1 * dv.x + f.a2 * dv.z, dtc = f.b1 * dv.y + f.b2 * dv.z;
+        const float dma = f.sgn * (f.mx * dv.x + f.my * dv.y + f.mz * dv.z);
+        ma2 = ma + dma;
+        const float ns = dsc - qs * dma, nt = dtc - qt * dma;
+        n_ = ns * ns + nt * nt;
     }
-    return (valid && ma2 > 0.0f) ? fmaxf(rho2, r2) : rho2;
+    const bool ok = valid && ma2 > 0.0f;
+    num = ok ? n_ : 0.0f;
+    den = ok ? ma2 * ma2 : 1.0f;
 }
 
-__device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3 d, bool vx, V3 dx, bool vy, V3 dy) {
+__device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3 d, bool vx, V3 dx, bool vy, V3 dy, const f32x4 *lvl) {
     const float fid = __builtin_amdgcn_cubeid(d.x, d.y, d.z);
     const float sc = __builtin_amdgcn_cubesc(d.x, d.y, d.z);
     const float tc = __builtin_amdgcn_cubetc(d.x, d.y, d.z);
@@ -560,22 +582,29 @@ __device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3
     qs = __builtin_fmaf(__builtin_fmaf(-qs, ma, sc), r, qs);
     qt = __builtin_fmaf(__builtin_fmaf(-qt, ma, tc), r, qt);
     const bool isz = fid >= 4.0f, isy = !isz && fid >= 2.0f, pos = ma2x >= 0.0f;
-    const float nf = (float)rc.cube_n, n2 = nf * nf;
-    float rho2 = 0.0f;
+    const float nf = (float)rc.cube_n;
     const CubeFaceFrame ff = cube_face_frame(isz, isy, pos);
-    rho2 = cube_lod_rho2(ff, sc, tc, ma, d, vx, dx, n2, rho2);
-    rho2 = cube_lod_rho2(ff, sc, tc, ma, d, vy, dy, n2, rho2);
-    float lambda = rho2 > 0.0f ? 0.5f * __builtin_amdgcn_logf(rho2) : 0.0f;  // v_log_f32 = log2
-    lambda = fminf(fmaxf(lambda, 0.0f), (float)(rc.cube_levels - 1));
+    float nx, ex, ny, ey;
+    cube_lod_partner(ff, qs, qt, ma, d, vx, dx, nx, ex);
+    cube_lod_partner(ff, qs, qt, ma, d, vy, dy, ny, ey);
+    float lambda;
+    {
+#pragma clang fp contract(fast)
+        // rho^2 = max(nx / ex, ny / ey) n^2 / 4: the larger quotient chosen by cross-multiplication, one reciprocal for both partners
+        const bool x_wins = nx * ey >= ny * ex;
+        const float num = x_wins ? nx : ny, den = x_wins ? ex : ey;
+        const float rho2 = num * hw_rcp(den) * (0.25f * nf * nf);
+        // clamp(0.5 log2(rho2), 0, levels - 1); rho2 <= 1 (or 0, or NaN) => lambda = 0: the lower clamp as a max in front of the logarithm
+        lambda = fminf(0.5f * __builtin_amdgcn_logf(fmaxf(rho2, 1.0f)), (float)(rc.cube_levels - 1));  // v_log_f32 = log2
+    }
     const float lf = floorf(lambda), fr = lambda - lf;
     const int lo = (int)lf;
-    const float c0 = __builtin_fmaf(32.0f * nf, nf, 96.0f * nf);
     const float q1s = qs + 1.0f, q1t = qt + 1.0f;
     const bool f4 = rc.cube_f4 != nullptr;  // wave-uniform: the float copy of the chain, or the byte footprints
     const __amdgpu_buffer_rsrc_t rs = f4 ? make_rsrc(rc.cube_f4, rc.cube_bytes * 4u) : make_rsrc(rc.cube, rc.cube_bytes);
-    const float v0 = cube_level_sample_fast(rs, f4, fid, q1s, q1t, nf, c0, lo);
+    const float v0 = cube_level_sample_fast(rs, f4, fid, q1s, q1t, lvl[lo]);
     if (lo + 1 >= rc.cube_levels || fr == 0.0f) return v0;
-    const float v1 = cube_level_sample_fast(rs, f4, fid, q1s, q1t, nf, c0, lo + 1);
+    const float v1 = cube_level_sample_fast(rs, f4, fid, q1s, q1t, lvl[lo + 1]);
     return v0 * (1.0f - fr) + v1 * fr;
 }
 
@@ -960,7 +989,7 @@ __device__ __forceinline__ float cloud_density_precise(const RenderConsts &rc, f
         const float qz = rc.cov_rot[1] * px + rc.cov_rot[3] * pz;
         if (LOD) {
             auto rot = [&](V3 q) { return V3{rc.cov_rot[0] * q.x + rc.cov_rot[2] * q.z, q.y, rc.cov_rot[1] * q.x + rc.cov_rot[3] * q.z}; };
-            if (rc.cube_lod_fast) coverage = cube_sample_lod_fast(rc, V3{qx, py, qz}, nb->vx, rot(nb->px), nb->vy, rot(nb->py));
+            if (rc.cube_lod_fast) coverage = cube_sample_lod_fast(rc, V3{qx, py, qz}, nb->vx, rot(nb->px), nb->vy, rot(nb->py), nb->lvl);
             else coverage = cube_sample_lod(rc, V3{qx, py, qz}, nb->vx, rot(nb->px), nb->vy, rot(nb->py));
         } else {
             coverage = cube_sample<true>(rc.cube, rc.cube_n, qx, py, qz, rc.cube_f4);
@@ -1058,7 +1087,7 @@ __device__ __forceinline__ float light_raymarched(const RenderConsts &rc, float 
         cloud_height(rc, qx, qy, qz, r, hr);
         QuadNb tap;
         if (LOD) {  // the quad partners evaluate the same tap from their own sample position
-            tap.vx = nb->vx; tap.vy = nb->vy;
+            tap.vx = nb->vx; tap.vy = nb->vy; tap.lvl = nb->lvl;
             tap.px = V3{nb->px.x + kx, nb->px.y + ky, nb->px.z + kz};
             tap.py = V3{nb->py.x + kx, nb->py.y + ky, nb->py.z + kz};
         }
@@ -1103,7 +1132,7 @@ __device__ __forceinline__ MarchRay cloud_march_ray(const RenderConsts &rc, V3 d
 // position is still advanced one rounded addition per step), so the result is bit-identical; only lane 0's is used.
 template <bool RM, bool PRECISE, int SPLIT, bool LOD = false>
 __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m, float t_begin, float t_end, float jitter, int half,
-                                               const MarchRay *nbray = nullptr) {
+                                               const MarchRay *nbray = nullptr, const f32x4 *lvl = nullptr) {
     const int steps = rc.cloud_steps;
     // exact: positions
     const MarchRay self = cloud_march_ray(rc, dir_m, t_begin, t_end, jitter);
@@ -1116,7 +1145,7 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
     }
     QuadNb nb;
     if (LOD) {
-        nb.vx = nbray[0].valid; nb.vy = nbray[1].valid;
+        nb.vx = nbray[0].valid; nb.vy = nbray[1].valid; nb.lvl = lvl;
         nb.px = V3{nbray[0].px, nbray[0].py, nbray[0].pz};
         nb.py = V3{nbray[1].px, nbray[1].py, nbray[1].pz};
     }
@@ -1219,7 +1248,7 @@ constexpr int rmq_words_per_wave(bool lod) { return (lod ? 12 : 6) * RMQ_CAP + R
 
 template <bool PRECISE, bool LOD = false>
 __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, V3 dir_m, float t_begin, float t_end, float jitter,
-                                                        float *__restrict__ lds, const MarchRay *nbray = nullptr) {
+                                                        float *__restrict__ lds, const MarchRay *nbray = nullptr, const f32x4 *lvl = nullptr) {
     float *qx = lds, *qy = lds + RMQ_CAP, *qz = lds + 2 * RMQ_CAP, *qh = lds + 3 * RMQ_CAP;
     uint32_t *qs = reinterpret_cast<uint32_t *>(lds + 4 * RMQ_CAP);
     float *qd = lds + 5 * RMQ_CAP;  // the sample's own density = light tap 0
@@ -1256,7 +1285,7 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
     const float neg_scale_step_log2e = -scale_step * LOG2E;
     QuadNb nb;
     if (LOD) {
-        nb.vx = nbray[0].valid; nb.vy = nbray[1].valid;
+        nb.vx = nbray[0].valid; nb.vy = nbray[1].valid; nb.lvl = lvl;
         nb.px = V3{nbray[0].px, nbray[0].py, nbray[0].pz};
         nb.py = V3{nbray[1].px, nbray[1].py, nbray[1].pz};
     }
@@ -1271,7 +1300,7 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
             uint32_t sl = qs[e];
             QuadNb enb;
             if (LOD) {
-                enb.vx = (sl >> 10) & 1u; enb.vy = (sl >> 11) & 1u;
+                enb.vx = (sl >> 10) & 1u; enb.vy = (sl >> 11) & 1u; enb.lvl = lvl;
                 enb.px = V3{qn[e], qn[RMQ_CAP + e], qn[2 * RMQ_CAP + e]};
                 enb.py = V3{qn[3 * RMQ_CAP + e], qn[4 * RMQ_CAP + e], qn[5 * RMQ_CAP + e]};
                 sl &= 1023u;
@@ -1460,6 +1489,12 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
     static_assert(!LOD || (CLOUDS && PRECISE && SPLIT == 1), "implicit cubemap LOD: precise cloud kernels, one lane per ray");
 
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    const f32x4 *lvl_table = nullptr;
+    if constexpr (LOD) {  // the declared sampler's per-level constants (cube_level_table_fill), written by every wave before any lane leaves
+        __shared__ f32x4 lvl_lds[CUBE_LEVEL_TABLE];
+        cube_level_table_fill(rc, lvl_lds, lane);
+        lvl_table = lvl_lds;
+    }
     // SPLIT = 2: lanes 2r, 2r+1 share ray r; a wave covers WAVE_W x (32 / WAVE_W) pixels, the workgroup TILE_W x TILE_H / 2
     const int ray = SPLIT == 2 ? lane >> 1 : lane;
     const int half = SPLIT == 2 ? lane & 1 : 0;
@@ -1580,9 +1615,9 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
                 float2 rr;
                 if constexpr (RM && SPLIT == 1) {
                     __shared__ float rmq[(TILE_W * TILE_H / 64) * rmq_words_per_wave(LOD)];
-                    rr = march_clouds_rm_queue<PRECISE, LOD>(rc, dir_m, c0, c1, jitter, rmq + wave * rmq_words_per_wave(LOD), nbray);
+                    rr = march_clouds_rm_queue<PRECISE, LOD>(rc, dir_m, c0, c1, jitter, rmq + wave * rmq_words_per_wave(LOD), nbray, lvl_table);
                 } else {
-                    rr = march_clouds<RM, PRECISE, SPLIT, LOD>(rc, dir_m, c0, c1, jitter, half, nbray);
+                    rr = march_clouds<RM, PRECISE, SPLIT, LOD>(rc, dir_m, c0, c1, jitter, half, nbray, lvl_table);
                 }
                 {
 #pragma clang fp contract(fast)
