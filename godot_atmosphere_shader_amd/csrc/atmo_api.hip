@@ -378,6 +378,8 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
     rc.out_y0 = f->y0;
     rc.composite = 0;
     rc.store_discards = ctx->target_cleared ? 0 : 1;
+    rc.gx0 = f->x0;
+    rc.gy0 = f->y0;
 }
 
 // Which coverage-cubemap sampler a draw of this context uses (atmo_set_sampler_lod): 1 = the implicit LOD of the linear-mipmap sampler the
@@ -1079,6 +1081,9 @@ int atmo_measure_tile_costs(AtmoContext *ctx, const AtmoFrame *frame, const floa
     atmo::RenderConsts probe;
     std::memset(&probe, 0, sizeof(probe));
     probe.x0 = frame->x0; probe.y0 = frame->y0; probe.x1 = frame->x1; probe.y1 = frame->y1;
+    const bool lod_grid = resolve_sampler_lod(ctx, nullptr) != 0;
+    probe.gx0 = lod_grid ? (frame->x0 & ~1) : frame->x0;
+    probe.gy0 = lod_grid ? (frame->y0 & ~1) : frame->y0;
     const int split = (resolve_sampler_lod(ctx, nullptr) || (ctx->view_steps > 32 && !(ctx->flags & (atmo::KF_LITE | atmo::KF_ATMO_REF)))) ? 1 : choose_split(ctx, frame);
     int gx = 0, gy = 0;
     atmo::render_grid(probe, split, &gx, &gy);
@@ -1169,6 +1174,9 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         if (lod) {
             flags |= atmo::KF_CUBE_LOD;
             split = 1;
+            // the 2 x 2 quads are the viewport's: the grid starts on an even pixel, pixels in front of the rect are helper lanes
+            rc.gx0 = frame->x0 & ~1;
+            rc.gy0 = frame->y0 & ~1;
         }
     }
     int gx = 0, gy = 0;

@@ -84,6 +84,7 @@ struct RenderConsts {
     const float *cube_f4;           // level 0 of `cube` with every footprint's four texels as exact byte / 255 floats (16 B), or null
     const float *shape_f4;          // the same for `shape`
     float miss_k;                   // [host] (|c|^2 - R_atm^2) (1 - 1e-3)^2 when the test is usable, else 0
+    int32_t gx0, gy0;               // [host] viewport pixel of the launch grid's first tile: (x0, y0), rounded down to even for the declared-sampler kernels
     int32_t store_discards;         // 1: a discarded fragment stores (0,0,0,0); 0: it stores nothing (composite, or atmo_set_target_cleared)
 };
 

@@ -419,10 +419,90 @@ __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, in
 
 // ---- implicit cubemap LOD (atmo_set_sampler_lod 1; oracle: sample_cube_lod) ----------------------------------------------
 // The positions the two 2x2-quad partners of this pixel pass to the same texture() call; valid = the partner reaches it.
+// Whole-quad exchange (round 4).  In the lock-step part of the cloud march every lane of a wave is at the same march step, and a pixel's two
+// quad partners sit in the same wave (LOD launches map each 2 x 2 pixel quad to four consecutive lanes), so the partners' cube coordinates
+// need not be recomputed from positions maintained per lane (rounds 2-3: 6 additions per step, 12 rotations, 6 differences and the face
+// frame per sample, two more per-pixel prologues per ray): they are read from the partner LANES with v_mov_b32_dpp quad_perm.  A partner
+// that marches but has left the evaluation at this step through an early-out is disabled in EXEC, and DPP cannot read a disabled lane:
+// the exchange runs inside ONE inline-asm block in whole-quad mode (s_wqm_b64 exec, exec: every quad with an active lane is enabled
+// whole, as the graphics pipeline does for derivatives); the re-enabled "helper" lanes compute their own coordinates from their own
+// position registers inside the block, the DPP moves copy them across, and EXEC is restored before the block ends.
+// Helper lanes WRITE the block's registers while the compiler believes them inactive, and the compiler parks values of inactive lanes in
+// any register that is not live on the active path (a variable assigned on both sides of a branch shares one register).  The block's
+// registers are therefore QuadRegs: read-write ("+v") operands of every exchange, defined once at the top of the kernel and used again at
+// its end, so their live range spans every divergent region and nothing can share them; tests/test_host_logic.py checks in the ISA of every
+// LOD kernel that no instruction outside the exchange blocks writes them.
+struct QuadRegs {
+    float fid, sc, tc, mas, qx, qz;                      // own: v_cubeid / sc / tc / ma of the rotated position (qx, p.y, qz)
+    float fidx, scx, tcx, masx, fidy, scy, tcy, masy;    // the same of the horizontal (lane ^ 1) and vertical (lane ^ 2) partner
+};
+__device__ __forceinline__ void quad_regs_define(QuadRegs &q) {
+    asm volatile("; QuadRegs defined" : "=v"(q.fid), "=v"(q.sc), "=v"(q.tc), "=v"(q.mas), "=v"(q.qx), "=v"(q.qz), "=v"(q.fidx), "=v"(q.scx),
+                 "=v"(q.tcx), "=v"(q.masx), "=v"(q.fidy), "=v"(q.scy), "=v"(q.tcy), "=v"(q.masy));
+}
+__device__ __forceinline__ void quad_regs_keep(const QuadRegs &q) {
+    asm volatile("; QuadRegs kept" ::"v"(q.fid), "v"(q.sc), "v"(q.tc), "v"(q.mas), "v"(q.qx), "v"(q.qz), "v"(q.fidx), "v"(q.scx), "v"(q.tcx),
+                 "v"(q.masx), "v"(q.fidy), "v"(q.scy), "v"(q.tcy), "v"(q.masy));
+}
+// coverage = texture(cubemap, vec3(rot * p.xz, p.y)): the rotation (cloud_funcs.gdshaderinc:43, every product and sum rounded on its own)
+// and the hardware cube coordinates of this lane's sample position, and its two partners' -- in whole-quad mode.
+__device__ __forceinline__ void quad_exchange_coords(float px, float py, float pz, float r0, float r1, float r2, float r3, QuadRegs &q) {
+    unsigned long long saved;
+    asm volatile(
+        "s_mov_b64 %[saved], exec\n\t"
+        "s_wqm_b64 exec, exec\n\t"
+        "v_mul_f32_e32 %[qx], %[r0], %[px]\n\t"
+        "v_mul_f32_e32 %[fidx], %[r2], %[pz]\n\t"
+        "v_mul_f32_e32 %[qz], %[r1], %[px]\n\t"
+        "v_mul_f32_e32 %[fidy], %[r3], %[pz]\n\t"
+        "v_add_f32_e32 %[qx], %[qx], %[fidx]\n\t"
+        "v_add_f32_e32 %[qz], %[qz], %[fidy]\n\t"
+        "s_nop 0\n\t"
+        "v_cubeid_f32 %[fid], %[qx], %[py], %[qz]\n\t"
+        "v_cubesc_f32 %[sc], %[qx], %[py], %[qz]\n\t"
+        "v_cubetc_f32 %[tc], %[qx], %[py], %[qz]\n\t"
+        "v_cubema_f32 %[mas], %[qx], %[py], %[qz]\n\t"
+        "s_nop 1\n\t"
+        "v_mov_b32_dpp %[fidx], %[fid] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[scx], %[sc] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[tcx], %[tc] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[masx], %[mas] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[fidy], %[fid] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[scy], %[sc] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[tcy], %[tc] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[masy], %[mas] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[saved]"
+        : [saved] "=&s"(saved), [fid] "+v"(q.fid), [sc] "+v"(q.sc), [tc] "+v"(q.tc), [mas] "+v"(q.mas), [qx] "+v"(q.qx), [qz] "+v"(q.qz),
+          [fidx] "+v"(q.fidx), [scx] "+v"(q.scx), [tcx] "+v"(q.tcx), [masx] "+v"(q.masx), [fidy] "+v"(q.fidy), [scy] "+v"(q.scy),
+          [tcy] "+v"(q.tcy), [masy] "+v"(q.masy)
+        : [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [r0] "s"(r0), [r1] "s"(r1), [r2] "s"(r2), [r3] "s"(r3)
+        : "scc");
+}
+// the partners' sample positions themselves (the lit-sample queue stores them for the light taps, which are not lock-step): into
+// (fidx, scx, tcx) and (fidy, scy, tcy), whose coordinates are dead by then
+__device__ __forceinline__ void quad_exchange_positions(float px, float py, float pz, QuadRegs &q) {
+    unsigned long long saved;
+    asm volatile(
+        "s_mov_b64 %[saved], exec\n\t"
+        "s_wqm_b64 exec, exec\n\t"
+        "v_mov_b32_dpp %[fidx], %[px] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[scx], %[py] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[tcx], %[pz] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[fidy], %[px] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[scy], %[py] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[tcy], %[pz] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[saved]"
+        : [saved] "=&s"(saved), [fidx] "+v"(q.fidx), [scx] "+v"(q.scx), [tcx] "+v"(q.tcx), [fidy] "+v"(q.fidy), [scy] "+v"(q.scy), [tcy] "+v"(q.tcy)
+        : [px] "v"(px), [py] "v"(py), [pz] "v"(pz)
+        : "scc");
+}
+
+// What a texture() call of the declared sampler needs to know about the pixel's two 2x2-quad partners; valid = the partner reaches the call.
 struct QuadNb {
     bool vx, vy;
-    V3 px, py;  // horizontal / vertical partner's sample position (model space)
+    V3 px, py;         // position form (light taps of a queued sample): the horizontal / vertical partner's sample position (model space)
     const f32x4 *lvl;  // LDS: per mip level {0.5 n_l, 4 n_l + 4, 4 (n_l + 1)^2, byte offset of footprint (0, 0) of face 0} (cube_level_table)
+    QuadRegs *regs;    // lock-step form (the march): the whole-quad exchange registers
 };
 
 // seamless bilinear sample of mip level `level` on face `face` at face coordinates (s, t); exact UNORM8 + unfused mixes
@@ -569,24 +649,43 @@ __device__ __forceinline__ void cube_lod_partner(const CubeFaceFrame &f, float q
     den = ok ? ma2 * ma2 : 1.0f;
 }
 
-__device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3 d, bool vx, V3 dx, bool vy, V3 dy, const f32x4 *lvl) {
-    const float fid = __builtin_amdgcn_cubeid(d.x, d.y, d.z);
-    const float sc = __builtin_amdgcn_cubesc(d.x, d.y, d.z);
-    const float tc = __builtin_amdgcn_cubetc(d.x, d.y, d.z);
-    const float ma2x = __builtin_amdgcn_cubema(d.x, d.y, d.z);  // 2 * the signed major component
-    const float ma = 0.5f * fabsf(ma2x);
-    const float r = hw_rcp(ma);
-    float qs = sc * r, qt = tc * r;
-    qs = __builtin_fmaf(__builtin_fmaf(-qs, ma, sc), r, qs);
-    qt = __builtin_fmaf(__builtin_fmaf(-qt, ma, tc), r, qt);
-    qs = __builtin_fmaf(__builtin_fmaf(-qs, ma, sc), r, qs);
-    qt = __builtin_fmaf(__builtin_fmaf(-qt, ma, tc), r, qt);
-    const bool isz = fid >= 4.0f, isy = !isz && fid >= 2.0f, pos = ma2x >= 0.0f;
+// The direction a set of cube coordinates came from (inverse of the Vulkan face table; sc, tc are signed copies of two components and
+// v_cubema is twice the third, so this is exact).  Only for a partner whose direction lies on ANOTHER face than the lane's own.
+__device__ __forceinline__ V3 cube_dir_from_coords(float fid, float sc, float tc, float mas) {
+    const float m = 0.5f * mas;
+    if (fid < 2.0f) return V3{m, -tc, fid < 1.0f ? -sc : sc};   // +X: sc = -z, tc = -y;  -X: sc = +z, tc = -y
+    if (fid < 4.0f) return V3{sc, m, fid < 3.0f ? tc : -tc};    // +Y: sc = +x, tc = +z;  -Y: sc = +x, tc = -z
+    return V3{fid < 5.0f ? sc : -sc, -tc, m};                   // +Z: sc = +x, tc = -y;  -Z: sc = -x, tc = -y
+}
+// cube_lod_partner for a partner given by its cube coordinates.  On the lane's own face -- all but the quads that straddle a cube edge --
+// the differences of the coordinates ARE the face frame applied to the rounded difference of the directions, bit for bit: sc and tc are
+// signed copies of one component each (so scp - sc = +-(q.c - d.c), the same rounding), and 0.5 |v_cubema| is the major component with
+// the face's sign on both.
+__device__ __forceinline__ void cube_lod_partner_coords(const CubeFaceFrame &f, float fid, float sc, float tc, float qs, float qt, float ma, V3 d,
+                                                        bool valid, float fidp, float scp, float tcp, float masp, float &num, float &den) {
+    float dsc = scp - sc, dtc = tcp - tc, dma = 0.5f * fabsf(masp) - ma;
+    if (valid && fidp != fid) {
+        const V3 q = cube_dir_from_coords(fidp, scp, tcp, masp);
+        const V3 dv = {q.x - d.x, q.y - d.y, q.z - d.z};
+        dsc = f.a1 * dv.x + f.a2 * dv.z;
+        dtc = f.b1 * dv.y + f.b2 * dv.z;
+        dma = f.sgn * (f.mx * dv.x + f.my * dv.y + f.mz * dv.z);
+    }
+    float n_, ma2;
+    {
+#pragma clang fp contract(fast)
+        ma2 = ma + dma;
+        const float ns = dsc - qs * dma, nt = dtc - qt * dma;
+        n_ = ns * ns + nt * nt;
+    }
+    const bool ok = valid && ma2 > 0.0f;
+    num = ok ? n_ : 0.0f;
+    den = ok ? ma2 * ma2 : 1.0f;
+}
+
+// lambda from the two partners' (numerator, denominator), then the two nearest levels (cube_sample_lod_fast / _quad)
+__device__ __forceinline__ float cube_lod_finish(const RenderConsts &rc, float fid, float qs, float qt, float nx, float ex, float ny, float ey, const f32x4 *lvl) {
     const float nf = (float)rc.cube_n;
-    const CubeFaceFrame ff = cube_face_frame(isz, isy, pos);
-    float nx, ex, ny, ey;
-    cube_lod_partner(ff, qs, qt, ma, d, vx, dx, nx, ex);
-    cube_lod_partner(ff, qs, qt, ma, d, vy, dy, ny, ey);
     float lambda;
     {
 #pragma clang fp contract(fast)
@@ -606,6 +705,50 @@ __device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3
     if (lo + 1 >= rc.cube_levels || fr == 0.0f) return v0;
     const float v1 = cube_level_sample_fast(rs, f4, fid, q1s, q1t, lvl[lo + 1]);
     return v0 * (1.0f - fr) + v1 * fr;
+}
+// s = sc / ma, t = tc / ma: the IEEE quotients from one v_rcp and two Markstein steps each (as in cube_sample<true>)
+__device__ __forceinline__ void cube_exact_quotients(float sc, float tc, float ma, float &qs, float &qt) {
+    const float r = hw_rcp(ma);
+    qs = sc * r; qt = tc * r;
+    qs = __builtin_fmaf(__builtin_fmaf(-qs, ma, sc), r, qs);
+    qt = __builtin_fmaf(__builtin_fmaf(-qt, ma, tc), r, qt);
+    qs = __builtin_fmaf(__builtin_fmaf(-qs, ma, sc), r, qs);
+    qt = __builtin_fmaf(__builtin_fmaf(-qt, ma, tc), r, qt);
+}
+
+// position form: the partners' (rotated) sample positions are given
+__device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3 d, bool vx, V3 dx, bool vy, V3 dy, const f32x4 *lvl) {
+    const float fid = __builtin_amdgcn_cubeid(d.x, d.y, d.z);
+    const float sc = __builtin_amdgcn_cubesc(d.x, d.y, d.z);
+    const float tc = __builtin_amdgcn_cubetc(d.x, d.y, d.z);
+    const float ma2x = __builtin_amdgcn_cubema(d.x, d.y, d.z);  // 2 * the signed major component
+    const float ma = 0.5f * fabsf(ma2x);
+    float qs, qt;
+    cube_exact_quotients(sc, tc, ma, qs, qt);
+    const bool isz = fid >= 4.0f, isy = !isz && fid >= 2.0f, pos = ma2x >= 0.0f;
+    const CubeFaceFrame ff = cube_face_frame(isz, isy, pos);
+    float nx, ex, ny, ey;
+    cube_lod_partner(ff, qs, qt, ma, d, vx, dx, nx, ex);
+    cube_lod_partner(ff, qs, qt, ma, d, vy, dy, ny, ey);
+    return cube_lod_finish(rc, fid, qs, qt, nx, ex, ny, ey, lvl);
+}
+// lock-step form: own and partners' cube coordinates come out of the whole-quad exchange
+__device__ __forceinline__ float cube_sample_lod_quad(const RenderConsts &rc, float px, float py, float pz, const QuadNb *nb) {
+    QuadRegs &q = *nb->regs;
+    quad_exchange_coords(px, py, pz, rc.cov_rot[0], rc.cov_rot[1], rc.cov_rot[2], rc.cov_rot[3], q);
+    const float fid = q.fid, sc = q.sc, tc = q.tc, ma2x = q.mas;
+    const V3 d = {q.qx, py, q.qz};
+    if (!rc.cube_lod_fast)  // faces that are not a power of two (or above 1024): the general sampler on the partners' directions
+        return cube_sample_lod(rc, d, nb->vx, cube_dir_from_coords(q.fidx, q.scx, q.tcx, q.masx), nb->vy, cube_dir_from_coords(q.fidy, q.scy, q.tcy, q.masy));
+    const float ma = 0.5f * fabsf(ma2x);
+    float qs, qt;
+    cube_exact_quotients(sc, tc, ma, qs, qt);
+    const bool isz = fid >= 4.0f, isy = !isz && fid >= 2.0f, pos = ma2x >= 0.0f;
+    const CubeFaceFrame ff = cube_face_frame(isz, isy, pos);  // only the quads that straddle a cube edge use it
+    float nx, ex, ny, ey;
+    cube_lod_partner_coords(ff, fid, sc, tc, qs, qt, ma, d, nb->vx, q.fidx, q.scx, q.tcx, q.masx, nx, ex);
+    cube_lod_partner_coords(ff, fid, sc, tc, qs, qt, ma, d, nb->vy, q.fidy, q.scy, q.tcy, q.masy, ny, ey);
+    return cube_lod_finish(rc, fid, qs, qt, nx, ex, ny, ey, nb->lvl);
 }
 
 // The direct light march of one view sample (ATMO_LIGHT_DIRECT; SURVEY.md 8d "N view x M light steps"): the quantity the LUT
@@ -967,7 +1110,9 @@ __device__ __forceinline__ float4 march_atmosphere_v1_precise(const RenderConsts
 // (profiles/round3/ab_density_ramp.txt); a NaN fails both tests in either form.
 #define DENSITY_RAMP_ZERO __uint_as_float(0x3ecccccdu)
 #define DENSITY_RAMP_ONE __uint_as_float(0x3ed70a3du)
-template <bool EARLY_OUT, bool LOD = false>
+// QUAD (with LOD): called in lock-step by the lanes of a wave (the march): the partners' coordinates come from the whole-quad exchange;
+// otherwise from the partner positions in *nb (light taps).
+template <bool EARLY_OUT, bool LOD = false, bool QUAD = false>
 __device__ __forceinline__ float cloud_density_precise(const RenderConsts &rc, float px, float py, float pz, float hr, const QuadNb *nb = nullptr DENS_STAT_ARG) {
     DENS_STAT(0);
     const float t = 2.0f * hr - 1.0f;
@@ -984,7 +1129,9 @@ __device__ __forceinline__ float cloud_density_precise(const RenderConsts &rc, f
         if ((rc.shape_hi01 + m_hi) * hc <= DENSITY_RAMP_ZERO) return 0.0f;
     }
     float coverage = 1.0f;
-    if (rc.cube != nullptr) {
+    if (LOD && QUAD) {
+        if (rc.cube != nullptr) coverage = cube_sample_lod_quad(rc, px, py, pz, nb);
+    } else if (rc.cube != nullptr) {
         const float qx = rc.cov_rot[0] * px + rc.cov_rot[2] * pz;
         const float qz = rc.cov_rot[1] * px + rc.cov_rot[3] * pz;
         if (LOD) {
@@ -1047,9 +1194,9 @@ __device__ __forceinline__ float cloud_density_fast(const RenderConsts &rc, floa
 // get_density_full with CLOUDS_ALWAYS_LOW_QUALITY (detail = 0.5).  `hr` = height ratio from the exact chain.
 // EARLY_OUT = false evaluates the fetches unconditionally (result is the same: hc = 0 forces the clamp to 0), which
 // removes the divergent branch so that several independent taps can be interleaved by the scheduler.
-template <bool EARLY_OUT, bool PRECISE, bool LOD = false>
+template <bool EARLY_OUT, bool PRECISE, bool LOD = false, bool QUAD = false>
 __device__ __forceinline__ float cloud_density(const RenderConsts &rc, float px, float py, float pz, float hr, const QuadNb *nb = nullptr DENS_STAT_ARG) {
-    return PRECISE ? cloud_density_precise<EARLY_OUT, LOD>(rc, px, py, pz, hr, nb DENS_STAT_PASS(stat_phase)) : cloud_density_fast<EARLY_OUT>(rc, px, py, pz, hr);
+    return PRECISE ? cloud_density_precise<EARLY_OUT, LOD, QUAD>(rc, px, py, pz, hr, nb DENS_STAT_PASS(stat_phase)) : cloud_density_fast<EARLY_OUT>(rc, px, py, pz, hr);
 }
 
 // exact |p| and (|p| - bottom) / thickness, as a scalar fp32 evaluation would produce them
@@ -1087,7 +1234,7 @@ __device__ __forceinline__ float light_raymarched(const RenderConsts &rc, float 
         cloud_height(rc, qx, qy, qz, r, hr);
         QuadNb tap;
         if (LOD) {  // the quad partners evaluate the same tap from their own sample position
-            tap.vx = nb->vx; tap.vy = nb->vy; tap.lvl = nb->lvl;
+            tap.vx = nb->vx; tap.vy = nb->vy; tap.lvl = nb->lvl; tap.regs = nullptr;
             tap.px = V3{nb->px.x + kx, nb->px.y + ky, nb->px.z + kz};
             tap.py = V3{nb->py.x + kx, nb->py.y + ky, nb->py.z + kz};
         }
@@ -1132,7 +1279,8 @@ __device__ __forceinline__ MarchRay cloud_march_ray(const RenderConsts &rc, V3 d
 // position is still advanced one rounded addition per step), so the result is bit-identical; only lane 0's is used.
 template <bool RM, bool PRECISE, int SPLIT, bool LOD = false>
 __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m, float t_begin, float t_end, float jitter, int half,
-                                               const MarchRay *nbray = nullptr, const f32x4 *lvl = nullptr) {
+                                               QuadRegs *qregs = nullptr, const f32x4 *lvl = nullptr) {
+    static_assert(!(LOD && RM), "raymarched light under the declared sampler runs through the lit-sample queue");
     const int steps = rc.cloud_steps;
     // exact: positions
     const MarchRay self = cloud_march_ray(rc, dir_m, t_begin, t_end, jitter);
@@ -1144,10 +1292,11 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
         px = px + ddx; py = py + ddy; pz = pz + ddz;
     }
     QuadNb nb;
-    if (LOD) {
-        nb.vx = nbray[0].valid; nb.vy = nbray[1].valid; nb.lvl = lvl;
-        nb.px = V3{nbray[0].px, nbray[0].py, nbray[0].pz};
-        nb.py = V3{nbray[1].px, nbray[1].py, nbray[1].pz};
+    if (LOD) {  // a quad partner "reaches the call" iff it marches: the lanes that are active here (2x2 quads = 4 consecutive lanes)
+        const unsigned long long marching = __builtin_amdgcn_ballot_w64(true);
+        const int lane = threadIdx.x & 63;
+        nb.vx = (marching >> (lane ^ 1)) & 1ull; nb.vy = (marching >> (lane ^ 2)) & 1ull;
+        nb.lvl = lvl; nb.regs = qregs;
     }
 
     // pow(dot(ray_dir, sun_dir), 16) is constant along the ray; dp <= 0 => 0
@@ -1184,12 +1333,12 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
             const float r2 = px * px + py * py + pz * pz;
             if (wave_may_be_in_layer(rc, r2)) {
                 cloud_height_r2(rc, r2, r, hr);
-                density = cloud_density<true, PRECISE, LOD>(rc, px, py, pz, hr, LOD ? &nb : nullptr);
+                density = cloud_density<true, PRECISE, LOD, LOD>(rc, px, py, pz, hr, LOD ? &nb : nullptr);
             }
             // the light value of a zero-density sample (6 more density taps in the raymarched variant) is never observed
             if (density > 0.0f) {
 #pragma clang fp contract(fast)
-                la = RM ? light_raymarched<PRECISE, LOD>(rc, px, py, pz, hr, density, sx, sy, sz, LOD ? &nb : nullptr) : hr;
+                la = RM ? light_raymarched<PRECISE, false>(rc, px, py, pz, hr, density, sx, sy, sz, nullptr) : hr;
                 // get_planet_shadow: smoothstep(-0.3, 0.3, dot(normalize(pos), -sun_dir))
                 const float sd = -(px * sx + py * sy + pz * sz) * hw_rcp(r);
                 const float st = sat((sd + 0.3f) * (1.0f / 0.6f));
@@ -1201,10 +1350,6 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
 #pragma unroll
         for (int k = 0; k < SPLIT; ++k) {
             px = px + ddx; py = py + ddy; pz = pz + ddz;
-        }
-        if (LOD) {  // the quad partners advance along their own rays
-            nb.px = V3{nb.px.x + nbray[0].ddx, nb.px.y + nbray[0].ddy, nb.px.z + nbray[0].ddz};
-            nb.py = V3{nb.py.x + nbray[1].ddx, nb.py.y + nbray[1].ddy, nb.py.z + nbray[1].ddz};
         }
         if (SPLIT == 1) {
             integrate(density, la, lb);
@@ -1248,7 +1393,7 @@ constexpr int rmq_words_per_wave(bool lod) { return (lod ? 12 : 6) * RMQ_CAP + R
 
 template <bool PRECISE, bool LOD = false>
 __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, V3 dir_m, float t_begin, float t_end, float jitter,
-                                                        float *__restrict__ lds, const MarchRay *nbray = nullptr, const f32x4 *lvl = nullptr) {
+                                                        float *__restrict__ lds, QuadRegs *qregs = nullptr, const f32x4 *lvl = nullptr) {
     float *qx = lds, *qy = lds + RMQ_CAP, *qz = lds + 2 * RMQ_CAP, *qh = lds + 3 * RMQ_CAP;
     uint32_t *qs = reinterpret_cast<uint32_t *>(lds + 4 * RMQ_CAP);
     float *qd = lds + 5 * RMQ_CAP;  // the sample's own density = light tap 0
@@ -1284,10 +1429,9 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
     const float scale_step = rc.cloud_density_scale * step_len;
     const float neg_scale_step_log2e = -scale_step * LOG2E;
     QuadNb nb;
-    if (LOD) {
-        nb.vx = nbray[0].valid; nb.vy = nbray[1].valid; nb.lvl = lvl;
-        nb.px = V3{nbray[0].px, nbray[0].py, nbray[0].pz};
-        nb.py = V3{nbray[1].px, nbray[1].py, nbray[1].pz};
+    if (LOD) {  // the partners that march (= reach the texture() calls of this march): the quad mates among the active lanes
+        nb.vx = (active >> (lane ^ 1)) & 1ull; nb.vy = (active >> (lane ^ 2)) & 1ull;
+        nb.lvl = lvl; nb.regs = qregs;
     }
 
     auto light_batch = [&](int avail) {  // phase B: lane `rank` lights queue entry qhead + rank
@@ -1300,7 +1444,7 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
             uint32_t sl = qs[e];
             QuadNb enb;
             if (LOD) {
-                enb.vx = (sl >> 10) & 1u; enb.vy = (sl >> 11) & 1u; enb.lvl = lvl;
+                enb.vx = (sl >> 10) & 1u; enb.vy = (sl >> 11) & 1u; enb.lvl = lvl; enb.regs = nullptr;
                 enb.px = V3{qn[e], qn[RMQ_CAP + e], qn[2 * RMQ_CAP + e]};
                 enb.py = V3{qn[3 * RMQ_CAP + e], qn[4 * RMQ_CAP + e], qn[5 * RMQ_CAP + e]};
                 sl &= 1023u;
@@ -1320,7 +1464,7 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
             const float r2 = px * px + py * py + pz * pz;
             if (wave_may_be_in_layer(rc, r2)) {
                 cloud_height_r2(rc, r2, r, hr);
-                density = cloud_density<true, PRECISE, LOD>(rc, px, py, pz, hr, LOD ? &nb : nullptr);
+                density = cloud_density<true, PRECISE, LOD, LOD>(rc, px, py, pz, hr, LOD ? &nb : nullptr);
             }
             const bool lit = density > 0.0f;
             float w = 0.0f;
@@ -1342,8 +1486,11 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
                 const uint32_t sl = (uint32_t)(k * 64 + lane);
                 qx[e] = px; qy[e] = py; qz[e] = pz; qh[e] = hr; qd[e] = density;
                 if (LOD) {
-                    qn[e] = nb.px.x; qn[RMQ_CAP + e] = nb.px.y; qn[2 * RMQ_CAP + e] = nb.px.z;
-                    qn[3 * RMQ_CAP + e] = nb.py.x; qn[4 * RMQ_CAP + e] = nb.py.y; qn[5 * RMQ_CAP + e] = nb.py.z;
+                    // the light taps of this sample difference the partners' tap positions: their sample positions, read from the partner lanes
+                    // (which march in lock-step but may be unlit, i.e. disabled here: whole-quad mode again)
+                    quad_exchange_positions(px, py, pz, *qregs);
+                    qn[e] = qregs->fidx; qn[RMQ_CAP + e] = qregs->scx; qn[2 * RMQ_CAP + e] = qregs->tcx;
+                    qn[3 * RMQ_CAP + e] = qregs->fidy; qn[4 * RMQ_CAP + e] = qregs->scy; qn[5 * RMQ_CAP + e] = qregs->tcy;
                     qs[e] = sl | (nb.vx ? 1024u : 0u) | (nb.vy ? 2048u : 0u);
                 } else {
                     qs[e] = sl;
@@ -1354,10 +1501,6 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
             qcount += __builtin_popcountll(lm);
             // exact: pos += ray_dir * step_len
             px = px + ddx; py = py + ddy; pz = pz + ddz;
-            if (LOD) {  // the quad partners advance along their own rays
-                nb.px = V3{nb.px.x + nbray[0].ddx, nb.px.y + nbray[0].ddy, nb.px.z + nbray[0].ddz};
-                nb.py = V3{nb.py.x + nbray[1].ddx, nb.py.y + nbray[1].ddy, nb.py.z + nbray[1].ddz};
-            }
             // a full batch is waiting -- or the chunk ends and its slots are read next: drain (one partial batch at most)
             const bool last = k == cn - 1;
             while (qcount - qhead >= batch || (last && qcount > qhead)) {  // single call site: one copy of the 6-tap block
@@ -1387,92 +1530,6 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
     return make_float2(total_light, 1.0f - one_minus_alpha);
 }
 
-// The per-pixel set-up of atmosphere_fragment (main:128-169), exact: ray, shell hit, march interval, depth, jitter.
-struct PixelRay {
-    bool hit;
-    V3 dir;
-    SphereHit sh;
-    float t_begin, t_end, linear_depth, jitter;
-};
-__device__ __forceinline__ PixelRay pixel_ray(const RenderConsts &rc, int px, int py) {
-    PixelRay o;
-    const float nonlinear_depth = rc.depth[(size_t)py * rc.w + px];
-    const float uvx = pixel_coord((float)px + 0.5f, rc.vw, rc.rcp_vw);
-    const float uvy = pixel_coord((float)py + 0.5f, rc.vh, rc.rcp_vh);
-    const float nx = uvx * 2.0f - 1.0f, ny = uvy * 2.0f - 1.0f, nz = nonlinear_depth;
-    const float *P = rc.inv_p;
-    const float vx = P[0] * nx + P[4] * ny + P[8] * nz + P[12] * 1.0f;
-    const float vy = P[1] * nx + P[5] * ny + P[9] * nz + P[13] * 1.0f;
-    const float vz = P[2] * nx + P[6] * ny + P[10] * nz + P[14] * 1.0f;
-    const float vw = P[3] * nx + P[7] * ny + P[11] * nz + P[15] * 1.0f;
-    const float *Vm = rc.inv_v;
-    const float wx = Vm[0] * vx + Vm[4] * vy + Vm[8] * vz + Vm[12] * vw;
-    const float wy = Vm[1] * vx + Vm[5] * vy + Vm[9] * vz + Vm[13] * vw;
-    const float wz = Vm[2] * vx + Vm[6] * vy + Vm[10] * vz + Vm[14] * vw;
-    const float ww = Vm[3] * vx + Vm[7] * vy + Vm[11] * vz + Vm[15] * vw;
-    float pwx, pwy, pwz;
-    world_div3(wx, wy, wz, ww, pwx, pwy, pwz);
-    const float ddx = rc.cam_pos_world[0] - pwx, ddy = rc.cam_pos_world[1] - pwy, ddz = rc.cam_pos_world[2] - pwz;
-    float linear_depth = prologue_sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
-
-    // ray_dir = normalize(view_coords.xyz - 0) = v * (1/sqrt(dot(v,v)))
-    const float vvx = vx - 0.0f, vvy = vy - 0.0f, vvz = vz - 0.0f;
-    const float inv_len = ieee_div(1.0f, prologue_sqrt(vvx * vvx + vvy * vvy + vvz * vvz));
-    o.dir = V3{vvx * inv_len, vvy * inv_len, vvz * inv_len};
-    const V3 center = {rc.center[0], rc.center[1], rc.center[2]};
-
-    o.sh = sphere_setup(center, o.dir);
-    const float2 rs_atmo = hit_radius(o.sh, rc.atmosphere_radius);
-    o.hit = rs_atmo.x != rs_atmo.y;
-    o.t_begin = o.t_end = o.jitter = 0.0f;
-    o.linear_depth = linear_depth;
-    if (o.hit) {
-        o.t_begin = fmaxf(rs_atmo.x, 0.0f);
-        float t_end = fmaxf(rs_atmo.y, 0.0f);
-        const float2 rs_ground = hit_radius(o.sh, rc.planet_radius);
-        float gd = 10000000.0f;
-        if (rs_ground.x != rs_ground.y) gd = rs_ground.x;
-        linear_depth = linear_depth * (1.0f - rc.sphere_depth_factor) + gd * rc.sphere_depth_factor;
-        o.t_end = fminf(t_end, linear_depth);
-        o.linear_depth = linear_depth;
-        const float jx = rc.vw * uvx, jy = rc.vh * uvy;
-        const int ji = ((int)jx) & 0xff, jj = ((int)jy) & 0xff;
-        o.jitter = blue_noise_value<true>(rc.blue[jj * 256 + ji]);
-    }
-    return o;
-}
-
-// The gates of render_clouds (cloud_funcs.gdshaderinc:263-278), evaluated exactly; on success the march interval on the
-// top-shell chord and the model-space direction (clouds:285-288).
-__device__ __forceinline__ bool cloud_gate(const RenderConsts &rc, const PixelRay &r, V3 &dir_m, float &c0, float &c1) {
-    const float2 rs_top = hit_radius(r.sh, rc.clouds_top);
-    if (rs_top.x == rs_top.y) return false;
-    const float2 rs_bottom = hit_radius(r.sh, rc.clouds_bottom);
-    c0 = fmaxf(rs_top.x, 0.0f);
-    c1 = fminf(rs_top.y, r.linear_depth);
-    if (!(c0 < r.linear_depth && (r.linear_depth > rs_bottom.y || rs_bottom.x > 0.0f))) return false;
-    const float *M = rc.view_to_model;
-    dir_m.x = M[0] * r.dir.x + M[4] * r.dir.y + M[8] * r.dir.z;
-    dir_m.y = M[1] * r.dir.x + M[5] * r.dir.y + M[9] * r.dir.z;
-    dir_m.z = M[2] * r.dir.x + M[6] * r.dir.y + M[10] * r.dir.z;
-    return true;
-}
-
-// cloud march of pixel (px, py) of the VIEWPORT -- a 2x2-quad partner of the shaded pixel, possibly outside the rect of
-// this launch; invalid when outside the viewport, discarded or gated out
-__device__ __forceinline__ MarchRay pixel_march_ray(const RenderConsts &rc, int px, int py) {
-    MarchRay m;
-    m.valid = false;
-    m.px = m.py = m.pz = m.ddx = m.ddy = m.ddz = m.step_len = 0.0f;
-    if (px < 0 || py < 0 || px >= rc.w || py >= rc.h) return m;
-    const PixelRay r = pixel_ray(rc, px, py);
-    if (!r.hit) return m;
-    V3 dir_m;
-    float c0, c1;
-    if (!cloud_gate(rc, r, dir_m, c0, c1)) return m;
-    return cloud_march_ray(rc, dir_m, c0, c1, r.jitter);
-}
-
 template <int FLAGS, int LSTEPS, int SPLIT>
 __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int tile_x, const int tile_y) {
     constexpr bool CLOUDS = (FLAGS & KF_CLOUDS) != 0;
@@ -1500,11 +1557,19 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
     const int half = SPLIT == 2 ? lane & 1 : 0;
     constexpr int WAVES_X = TILE_W / (WAVE_W > TILE_W ? TILE_W : WAVE_W);
     constexpr int WAVE_ROWS = WAVE_H / SPLIT;
-    const int lx = (wave % WAVES_X) * WAVE_W + ray % WAVE_W;
-    const int ly = (wave / WAVES_X) * WAVE_ROWS + ray / WAVE_W;
-    const int px = rc.x0 + tile_x * TILE_W + lx;
-    const int py = rc.y0 + tile_y * (TILE_H / SPLIT) + ly;
-    if (px >= rc.x1 || py >= rc.y1) return;
+    // LOD: every 2 x 2 pixel quad occupies four consecutive lanes (lane bits: x0, y0, x1..x3, y1), so that the quad partners are
+    // lane ^ 1 and lane ^ 2 (v_mov_b32_dpp quad_perm) -- within a wave's 16 x 4 pixels all the same
+    const int lx = (wave % WAVES_X) * WAVE_W + (LOD ? ((ray >> 2) & 7) * 2 + (ray & 1) : ray % WAVE_W);
+    const int ly = (wave / WAVES_X) * WAVE_ROWS + (LOD ? ((ray >> 5) & 1) * 2 + ((ray >> 1) & 1) : ray / WAVE_W);
+    // LOD: the launch grid starts on an even pixel in x and y (rc.gx0, rc.gy0: the quads are those of the VIEWPORT, whatever the rect), and
+    // a pixel outside the rect but inside the viewport is shaded as a HELPER, like the rasteriser's helper invocations: it marches, its
+    // quad mates difference against it, it stores nothing.  The picture of a rect is the crop of the full frame's, bit for bit.
+    const int px = (LOD ? rc.gx0 : rc.x0) + tile_x * TILE_W + lx;
+    const int py = (LOD ? rc.gy0 : rc.y0) + tile_y * (TILE_H / SPLIT) + ly;
+    QuadRegs qregs;
+    if constexpr (LOD) quad_regs_define(qregs);  // all 64 lanes are still here: nothing else may ever live in these registers
+    if (LOD ? (px >= rc.w || py >= rc.h) : (px >= rc.x1 || py >= rc.y1)) return;
+    const bool helper = LOD && (px < rc.x0 || py < rc.y0 || px >= rc.x1 || py >= rc.y1);
     float4 *out = rc.out + (size_t)(py - rc.out_y0) * (size_t)rc.out_pitch + (px - rc.out_x0);
 
     // --- sure-miss test in front of the exact prologue (round 3) ----------------------------------------
@@ -1526,14 +1591,12 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
         const float cv = rc.center[0] * ax + rc.center[1] * ay + rc.center[2] * az;
         const float vv = ax * ax + ay * ay + az * az;
         if (cv * cv < rc.miss_k * vv) {
-            if (rc.store_discards && half == 0) *out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (rc.store_discards && half == 0 && !helper) *out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             return;
         }
     }
 
     // --- exact prologue (main:128-169) -----------------------------------------------------------
-    // (written out here; pixel_ray() / cloud_gate() above are the same statements packaged for the quad partners of the
-    //  LOD mode -- routing this path through them changed hipcc's block layout and cost the direct-light kernel 6 %)
     const float nonlinear_depth = rc.depth[(size_t)py * rc.w + px];
     const float uvx = pixel_coord<DIET>((float)px + 0.5f, rc.vw, rc.rcp_vw);
     const float uvy = pixel_coord<DIET>((float)py + 0.5f, rc.vh, rc.rcp_vh);
@@ -1563,7 +1626,7 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
     const float2 rs_atmo = hit_radius<DIET>(sh, rc.atmosphere_radius);
 
     if (rs_atmo.x == rs_atmo.y) {  // discard: nothing reaches the blend stage
-        if (rc.store_discards && half == 0) *out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (rc.store_discards && half == 0 && !helper) *out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         return;
     }
     const float t_begin = fmaxf(rs_atmo.x, 0.0f);
@@ -1604,20 +1667,12 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
                 dir_m.x = M[0] * dir.x + M[4] * dir.y + M[8] * dir.z;
                 dir_m.y = M[1] * dir.x + M[5] * dir.y + M[9] * dir.z;
                 dir_m.z = M[2] * dir.x + M[6] * dir.y + M[10] * dir.z;
-                MarchRay nbray[2];
-                if (LOD) {
-                    // The quad partners (px ^ 1, py) and (px, py ^ 1) in absolute viewport coordinates: their march rays
-                    // are recomputed here (two more per-pixel prologues, ~5 % of a cloud ray) rather than exchanged
-                    // across lanes, so the result does not depend on which pixels share a wave or on the launch rect.
-                    nbray[0] = pixel_march_ray(rc, px ^ 1, py);
-                    nbray[1] = pixel_march_ray(rc, px, py ^ 1);
-                }
                 float2 rr;
                 if constexpr (RM && SPLIT == 1) {
                     __shared__ float rmq[(TILE_W * TILE_H / 64) * rmq_words_per_wave(LOD)];
-                    rr = march_clouds_rm_queue<PRECISE, LOD>(rc, dir_m, c0, c1, jitter, rmq + wave * rmq_words_per_wave(LOD), nbray, lvl_table);
+                    rr = march_clouds_rm_queue<PRECISE, LOD>(rc, dir_m, c0, c1, jitter, rmq + wave * rmq_words_per_wave(LOD), &qregs, lvl_table);
                 } else {
-                    rr = march_clouds<RM, PRECISE, SPLIT, LOD>(rc, dir_m, c0, c1, jitter, half, nbray, lvl_table);
+                    rr = march_clouds<RM, PRECISE, SPLIT, LOD>(rc, dir_m, c0, c1, jitter, half, &qregs, lvl_table);
                 }
                 {
 #pragma clang fp contract(fast)
@@ -1644,7 +1699,9 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
             }
         }
     }
+    if constexpr (LOD) quad_regs_keep(qregs);
     if (SPLIT == 2 && half) return;  // lane 0 of the pair holds the ray's result
+    if (helper) return;              // outside the rect: shaded for its quad mates only
     if (rc.composite) {
         // What the engine's blend stage does with ALBEDO/ALPHA of an unshaded, blend_mix spatial material:
         // colour: SRC_ALPHA, ONE_MINUS_SRC_ALPHA; alpha: ONE, ONE_MINUS_SRC_ALPHA.
@@ -2150,8 +2207,8 @@ void render_tile_size(int split, int *tile_w, int *tile_h) {
 }
 void render_grid(const RenderConsts &rc, int split, int *tiles_x, int *tiles_y) {
     const int th = TILE_H / (split == 2 ? 2 : 1);  // pixel rows per workgroup
-    *tiles_x = (rc.x1 - rc.x0 + TILE_W - 1) / TILE_W;
-    *tiles_y = (rc.y1 - rc.y0 + th - 1) / th;
+    *tiles_x = (rc.x1 - rc.gx0 + TILE_W - 1) / TILE_W;  // (rc.gx0, rc.gy0): the grid's origin, set by the host before this call
+    *tiles_y = (rc.y1 - rc.gy0 + th - 1) / th;
 }
 
 template <int FLAGS, int LSTEPS, int SPLIT>

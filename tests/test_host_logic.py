@@ -426,3 +426,18 @@ def test_bench_detail_file(tmp_path, monkeypatch):
     assert bench.write_detail({"a": 1}) is None   # an unwritable place does not fail the bench
     monkeypatch.setenv("ATMO_BENCH_DETAIL", "")
     assert bench.write_detail({"a": 1}) is None
+
+
+def test_whole_quad_exchange_registers_are_private():
+    """The declared-sampler kernels read their quad partners' cube coordinates from the partner LANES inside inline-asm blocks that run in
+    whole-quad mode (s_wqm_b64): lanes the compiler believes inactive write the blocks' registers.  tools/check_quad_regs.py compiles the
+    kernels to ISA (hipcc -S, ~20 s) and verifies that in every kernel with an exchange block no instruction outside the blocks writes
+    those VGPRs -- the property the source's QuadRegs (read-write operands spanning the kernel) is there to guarantee."""
+    import subprocess
+    import sys as _sys
+
+    p = subprocess.run([_sys.executable, os.path.join(ROOT, "tools", "check_quad_regs.py")], capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if "exchange blocks" in ln]
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert len(lines) >= 11 and all(ln.rstrip().endswith("ok") for ln in lines), p.stdout   # every KF_CUBE_LOD instantiation
+    assert any("<49, 0, 1>" in ln and " 1 exchange" in ln for ln in lines) and any("<51, 0, 1>" in ln and " 2 exchange" in ln for ln in lines)
