@@ -627,28 +627,12 @@ __device__ __forceinline__ CubeFaceFrame cube_face_frame(bool isz, bool isy, boo
     f.b2 = f.my * f.sgn;          // +Y: z, -Y: -z
     return f;
 }
-// One quad partner's finite difference on the selected face, as numerator and denominator of (2 rho / n)^2:
+// One quad partner's finite difference (cube_lod_partner_coords below) on the selected face, as numerator and denominator of (2 rho / n)^2:
 //   s' - s = 0.5 (dsc ma - sc dma) / (ma ma') = 0.5 (dsc - (sc / ma) dma) / ma',   ma' = ma + dma      (cancellation-free, qs = sc / ma)
 //   num = (dsc - qs dma)^2 + (dtc - qt dma)^2,   den = ma'^2;   a partner that does not reach the call, or lies beyond the face's half
 //   space (ma' <= 0), contributes num = 0.
 // The difference q - d is rounded like the reference's; the face frame applied to it is exact (one non-zero term per sum, whether the
 // compiler fuses it or not); everything behind it only moves lambda by ulps.
-__device__ __forceinline__ void cube_lod_partner(const CubeFaceFrame &f, float qs, float qt, float ma, V3 d, bool valid, V3 q, float &num, float &den) {
-    const V3 dv = {q.x - d.x, q.y - d.y, q.z - d.z};
-    float n_, ma2;
-    {
-#pragma clang fp contract(fast)
-        const float dsc = f.a1 * dv.x + f.a2 * dv.z, dtc = f.b1 * dv.y + f.b2 * dv.z;
-        const float dma = f.sgn * (f.mx * dv.x + f.my * dv.y + f.mz * dv.z);
-        ma2 = ma + dma;
-        const float ns = dsc - qs * dma, nt = dtc - qt * dma;
-        n_ = ns * ns + nt * nt;
-    }
-    const bool ok = valid && ma2 > 0.0f;
-    num = ok ? n_ : 0.0f;
-    den = ok ? ma2 * ma2 : 1.0f;
-}
-
 // The direction a set of cube coordinates came from (inverse of the Vulkan face table; sc, tc are signed copies of two components and
 // v_cubema is twice the third, so this is exact).  Only for a partner whose direction lies on ANOTHER face than the lane's own.
 __device__ __forceinline__ V3 cube_dir_from_coords(float fid, float sc, float tc, float mas) {
@@ -716,7 +700,9 @@ __device__ __forceinline__ void cube_exact_quotients(float sc, float tc, float m
     qt = __builtin_fmaf(__builtin_fmaf(-qt, ma, tc), r, qt);
 }
 
-// position form: the partners' (rotated) sample positions are given
+// position form: the partners' (rotated) sample positions are given (the light taps of a queued sample).  Their cube coordinates come from
+// the hardware cube instructions as well (4 instructions instead of the face frame applied to a difference: 13), and
+// cube_lod_partner_coords takes it from there -- the same bits as the frame form on the lane's own face, the frame form itself elsewhere.
 __device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3 d, bool vx, V3 dx, bool vy, V3 dy, const f32x4 *lvl) {
     const float fid = __builtin_amdgcn_cubeid(d.x, d.y, d.z);
     const float sc = __builtin_amdgcn_cubesc(d.x, d.y, d.z);
@@ -726,10 +712,12 @@ __device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3
     float qs, qt;
     cube_exact_quotients(sc, tc, ma, qs, qt);
     const bool isz = fid >= 4.0f, isy = !isz && fid >= 2.0f, pos = ma2x >= 0.0f;
-    const CubeFaceFrame ff = cube_face_frame(isz, isy, pos);
+    const CubeFaceFrame ff = cube_face_frame(isz, isy, pos);  // only the quads that straddle a cube edge use it
     float nx, ex, ny, ey;
-    cube_lod_partner(ff, qs, qt, ma, d, vx, dx, nx, ex);
-    cube_lod_partner(ff, qs, qt, ma, d, vy, dy, ny, ey);
+    cube_lod_partner_coords(ff, fid, sc, tc, qs, qt, ma, d, vx, __builtin_amdgcn_cubeid(dx.x, dx.y, dx.z), __builtin_amdgcn_cubesc(dx.x, dx.y, dx.z),
+                            __builtin_amdgcn_cubetc(dx.x, dx.y, dx.z), __builtin_amdgcn_cubema(dx.x, dx.y, dx.z), nx, ex);
+    cube_lod_partner_coords(ff, fid, sc, tc, qs, qt, ma, d, vy, __builtin_amdgcn_cubeid(dy.x, dy.y, dy.z), __builtin_amdgcn_cubesc(dy.x, dy.y, dy.z),
+                            __builtin_amdgcn_cubetc(dy.x, dy.y, dy.z), __builtin_amdgcn_cubema(dy.x, dy.y, dy.z), ny, ey);
     return cube_lod_finish(rc, fid, qs, qt, nx, ex, ny, ey, lvl);
 }
 // lock-step form: own and partners' cube coordinates come out of the whole-quad exchange
