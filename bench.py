@@ -149,6 +149,18 @@ def hbm_roofline(kernel_avg_ms, launches, launch_rays, pmc, isolated_ms=None):
     }
 
 
+def print_final_line(rec):
+    """The compact record as the LAST line of stdout: whatever native libraries have buffered on C stdio (RCCL prints its version banner
+    there when a communicator is created, and the C buffer is flushed at exit, i.e. AFTER everything Python printed) is flushed first."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(rec), flush=True)
+
+
 def write_detail(result):
     """Everything measured, as one JSON document: bench_detail.json in the working directory (ATMO_BENCH_DETAIL overrides; '' = skip).
     Returns the path written, or None (a read-only working directory must not fail the bench)."""
@@ -281,9 +293,14 @@ def parse_args():
                          "'every' = RCCL gather of EVERY frame to rank 0, two in flight, overlapped with the next render (root ingress "
                          "over xGMI then sets the step time; round 2's default); 'none' = no collective.  Whatever the mode, the other two "
                          "rates are measured in further loops and reported as config.mrays_per_s_no_gather / _final_gather / _gather_every.")
-    ap.add_argument("--shard", default="viewports", choices=["viewports", "bands"],
+    ap.add_argument("--shard", default="viewports", choices=["viewports", "bands", "tiles"],
                     help="N>1: 'viewports' = one full viewport per GPU (weak scaling, default); 'bands' = ONE viewport cut "
-                         "into hit-balanced row bands, one per GPU, gathered in place into the frame on rank 0 (strong scaling)")
+                         "into hit-balanced row bands, one per GPU, gathered in place into the frame on rank 0 (strong scaling); "
+                         "'tiles' = ONE viewport's 16-row tile strips dealt to the GPUs longest-processing-time-first by measured cost, "
+                         "each GPU draws its tiles in one launch (atmo_render_tiles), strips gathered into the frame on rank 0 every frame")
+    ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2],
+                    help="--shard tiles: lanes per ray of every rank's draw (atmo_set_lane_split; 2 halves the longest wavefronts of a share -- "
+                         "what bounds a strong-scaled cloud frame -- for 13-29 %% more work; LOD-0 sampler only)")
     ap.add_argument("--also", default="lut32,shipped8,clouds_high,clouds_high_rm,direct32x8@3840x2160,clouds_high_rm@3840x2160,"
                                       "clouds_high@lod0,clouds_high_rm@lod0,clouds_high_rm@lod0@3840x2160,direct32x8@moving,clouds_high_rm@moving,"
                                       "direct32x8+2vp,direct32x8@reforder,shipped8@cleared,lut32@cleared,noise_cubemap",
@@ -815,6 +832,8 @@ def main():
     textures = demo_textures()
     params = demo_params()
     strong = args.shard == "bands" and multi
+    if args.shard == "tiles" and multi:
+        return main_tile_strips(args, torch, dist, S, textures, params, config_name, desc, world, rank, local_rank)
     pose = args.pose if (world == 1 or rank == 0 or strong) else S.orbit_pose(rank, world)
     cam = S.Camera.from_pose(w, h, pose)
     depth_np = S.depth_ground_sphere(cam)
@@ -1006,11 +1025,115 @@ def main():
                 lut = n2.read_optical_depth()
                 n2.close()
             result["cpu_baseline"] = cpu_baseline(config_name, params, textures, cam, depth_np, lut, lod0)
-        detail_path = write_detail(result)
-        print(json.dumps(compact_record(result, detail_path)), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        print_final_line(compact_record(result, write_detail(result)))
+
+
+def main_tile_strips(args, torch, dist, S, textures, params, config_name, desc, world, rank, local_rank):
+    """--shard tiles: ONE viewport, its 16-row tile strips dealt to the ranks longest-processing-time-first by MEASURED tile costs (rank 0
+    measures, everybody gets the costs by broadcast and computes the same deal); every step each rank draws its tiles in one launch, heaviest
+    first (atmo_render_tiles), and the strips are gathered into the frame on rank 0 (a frame only exists once it is assembled: the gather
+    of every frame is inside the timed region).  Strong scaling; `value` = the viewport's rays per second of assembled frames."""
+    import numpy as np
+    from godot_atmosphere_shader_amd.demo import make_node
+    from godot_atmosphere_shader_amd.sharding import STRIP_TILE_ROWS, StripGather, lpt_strips
+
+    w, h = args.width, args.height
+    device = torch.device("cuda", local_rank)
+    cam = S.Camera.from_pose(w, h, args.pose)
+    depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
+    lod0 = args.sampler == "lod0" and CONFIGS_HAS_CLOUDS(config_name)
+    node = make_node(config_name, textures, params, device=local_rank,
+                     **dict(node_kwargs(args.workload), **(dict(cubemap_lod=False) if lod0 else {}), **(dict(lane_split=args.lanes) if args.lanes else {})))
+    shape = torch.zeros(4, dtype=torch.int64, device=device)
+    if rank == 0:
+        for _ in range(3):  # the last of three measurements counts (clocks and caches warm)
+            cost, tw, th = node.measure_tile_costs(cam, depth)
+        shape.copy_(torch.tensor([cost.shape[0], cost.shape[1], tw, th]))
+    dist.broadcast(shape, src=0)
+    ty, tx, tw, th = (int(v) for v in shape.tolist())
+    cost_t = torch.zeros((ty, tx), dtype=torch.int64, device=device)
+    if rank == 0:
+        cost_t.copy_(torch.from_numpy(cost.astype(np.int64)))
+    dist.broadcast(cost_t, src=0)
+    strips, tiles = lpt_strips(cost_t.cpu().numpy(), world)
+    my_tiles = torch.from_numpy(tiles[rank].astype(np.int32)).to(device)
+    g = StripGather(h, w, strips, STRIP_TILE_ROWS * th, device, dst=0)
+    frame = node.prepare_frame(cam)
+    stream = torch.cuda.current_stream().cuda_stream
+    target = g.render_target()
+
+    def draw():
+        node.render_tiles_prepared(frame, depth.data_ptr(), target.data_ptr(), my_tiles.data_ptr(), my_tiles.numel(), stream)
+
+    def loop(n, gather):
+        for _ in range(n):
+            draw()
+            if gather:
+                g.gather()
+
+    def timed(n, gather):
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        loop(n, gather)
+        e1.record()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        dist.barrier()
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item()), e0.elapsed_time(e1)
+
+    loop(max(2, args.warmup), True)
+    t_warm = time.perf_counter()
+    while time.perf_counter() - t_warm < 0.025:   # sustained clocks (see time_workload)
+        loop(8, False)
+        torch.cuda.synchronize()
+    dt, _ = timed(args.steps, True)
+    dt_ng, ev_ng = timed(args.steps, False)
+    # what every rank's launch took, without the collective (HIP events around its K un-bracketed launches)
+    per_rank = torch.zeros(world, dtype=torch.float64, device=device)
+    per_rank[rank] = ev_ng / args.steps
+    dist.all_reduce(per_rank)
+    if rank == 0:
+        assembled = g.gather()
+    else:
+        g.gather()
+    result = None
+    if rank == 0:
+        want = node.render(cam, depth)
+        torch.cuda.synchronize()
+        identical = bool(torch.equal(assembled, want))
+        rays = w * h
+        value = rays * args.steps / dt / 1e6
+        k_ms = float(per_rank.max().item())
+        result = {
+            "metric": f"Mrays/s, {args.workload} at {w}x{h}; % HBM roofline; one viewport in tile strips over {world} GPUs, gather every",
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "timed_region_ms": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{desc}{workload_suffix(config_name, 'lod0' if lod0 else None)}; {w}x{h}; demo scene, pose {args.pose}",
+                       "width": w, "height": h, "kernel": node.kernel_name, "gather": "strips of every frame gathered into the frame on rank 0, inside the timed region",
+                       "shard": f"{len(strips[0]) and sum(len(s) for s in strips)} strips of {STRIP_TILE_ROWS * th} rows dealt LPT by measured cost: "
+                                f"{[len(s) for s in strips]} strips per rank, {[int(t.size) for t in tiles]} tiles",
+                       "mrays_per_s_no_gather": rays * args.steps / dt_ng / 1e6, "mrays_per_s_gather_every": value,
+                       "gather_ms_in_timed_region": (dt - dt_ng) * 1e3,
+                       "kernel_ms_per_rank": [float(v) for v in per_rank.tolist()], "assembled_frame_equals_single_gpu_frame": identical},
+            "roofline": hbm_roofline(k_ms, args.steps, int(tiles[int(per_rank.argmax().item())].size) * tw * th, None),
+        }
+        result["roofline"]["kernel_timing"] = "HIP events around the K un-bracketed tile-list launches of the slowest rank (loop without the collective)"
+    node.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print_final_line(compact_record(result, write_detail(result)))
+    return result
 
 
 def bench_config4(torch, dist, S, textures, params, local_rank, rank, world, steps, warmup):

@@ -21,7 +21,7 @@ ABI_VERSION = 4
 CORE_SYMBOLS = (
     "atmo_abi_version", "atmo_device_count", "atmo_create", "atmo_destroy", "atmo_set_param_f32", "atmo_get_param_f32",
     "atmo_set_texture", "atmo_get_texture_size", "atmo_set_sampler_lod", "atmo_bake_optical_depth",
-    "atmo_generate_noise_cubemap", "atmo_read_optical_depth", "atmo_render", "atmo_render_composite", "atmo_measure_tile_costs", "atmo_set_precision",
+    "atmo_generate_noise_cubemap", "atmo_read_optical_depth", "atmo_render", "atmo_render_composite", "atmo_render_tiles", "atmo_measure_tile_costs", "atmo_set_precision",
     "atmo_set_host_double_precision", "atmo_set_target_cleared", "atmo_set_tile_feedback", "atmo_last_error_string",
 )
 # every symbol include/atmo_debug.h declares: experiment knobs and diagnostics (tests, bench.py, tools/)
@@ -92,6 +92,7 @@ def load() -> C.CDLL:
         "atmo_read_optical_depth": (ip, [vp, vp, vp, ip, vp]),
         "atmo_render": (ip, [vp, C.POINTER(AtmoFrame), vp, vp, vp]),
         "atmo_render_composite": (ip, [vp, C.POINTER(AtmoFrame), vp, vp, vp]),
+        "atmo_render_tiles": (ip, [vp, C.POINTER(AtmoFrame), vp, vp, vp, ip, vp]),
         "atmo_measure_tile_costs": (ip, [vp, C.POINTER(AtmoFrame), vp, vp, vp, vp, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(ip), C.POINTER(ip)]),
         "atmo_set_precision": (ip, [vp, ip]),
         "atmo_set_host_double_precision": (ip, [vp, ip]),

@@ -1061,7 +1061,8 @@ int atmo_read_optical_depth(AtmoContext *ctx, float *lut_host, uint8_t *rgba8_ho
     return ATMO_OK;
 }
 
-static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, void *stream, bool composite);
+static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, void *stream, bool composite,
+                       const uint32_t *tiles_dev = nullptr, int n_tiles = 0);
 
 int atmo_render(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, void *stream) {
     return render_impl(ctx, frame, depth_dev, rgba_dev, stream, false);
@@ -1069,6 +1070,14 @@ int atmo_render(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev
 
 int atmo_render_composite(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *scene_rgba_dev, void *stream) {
     return render_impl(ctx, frame, depth_dev, scene_rgba_dev, stream, true);
+}
+
+int atmo_render_tiles(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, const uint32_t *tiles_dev, int n_tiles,
+                      void *stream) {
+    if (!ctx) return ATMO_E_ARG;
+    if (n_tiles < 0 || (n_tiles > 0 && !tiles_dev)) return fail(ctx, ATMO_E_ARG, "atmo_render_tiles: bad tile list");
+    if (n_tiles == 0) return ATMO_OK;  // an empty share of the frame: nothing to shade
+    return render_impl(ctx, frame, depth_dev, rgba_dev, stream, false, tiles_dev, n_tiles);
 }
 
 int atmo_measure_tile_costs(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, void *stream,
@@ -1123,7 +1132,8 @@ int atmo_measure_tile_costs(AtmoContext *ctx, const AtmoFrame *frame, const floa
     return rc;
 }
 
-static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, void *stream, bool composite) {
+static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, void *stream, bool composite,
+                       const uint32_t *tiles_dev, int n_tiles) {
     if (!ctx) return ATMO_E_ARG;
     if (!frame) return fail(ctx, ATMO_E_ARG, "atmo_render: null frame");
     if (frame->viewport_w < 1 || frame->viewport_h < 1 || frame->viewport_w > 65536 || frame->viewport_h > 65536)
@@ -1185,6 +1195,7 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     // default (-1): on for every variant since the sort no longer costs the draws anything (profiles/round2/ab_tile_feedback.txt)
     bool feedback = ctx->env_feedback >= 0 ? ctx->env_feedback != 0 : ctx->tile_feedback != 0;
     if (ctx->measure_cost) feedback = false;  // a measuring draw: plain row-major launch that records into the caller's buffer
+    if (tiles_dev) feedback = false;          // a tile-list draw: the caller's order
     if (feedback && (long long)gx * gy < 512) feedback = false;  // tiny launches: nothing to schedule
     if (feedback) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -1303,7 +1314,8 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         HIP_TRY(ctx, hipEventCreate(&ev.e1));
         HIP_TRY(ctx, hipEventRecord(ev.e0, s));
     }
-    HIP_TRY(ctx, atmo::launch_render(flags, split, rc, s));
+    if (tiles_dev) rc.tile_order = tiles_dev;
+    HIP_TRY(ctx, atmo::launch_render(flags, split, rc, s, tiles_dev ? n_tiles : 0));
     ctx->last_flags = flags;
     if (fb_record) {
         // Sort on the side stream as soon as this draw is done (the sort also clears the costs for the next recording).

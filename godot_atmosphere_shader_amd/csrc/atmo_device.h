@@ -108,7 +108,7 @@ enum KernelFlags : int { KF_CLOUDS = 1, KF_CLOUD_LIGHT_RM = 2, KF_LIGHT_DIRECT =
                           KF_ATMO_REF = 64 /* the v2 atmosphere march in the reference's operation order (atmo_set_precision 2) */,
                           KF_VIEW_POS = 128 /* view_steps > 32: the fast v2 march accumulates the view-space position like the reference (march_atmosphere<VIEWPOS>) */ };
 
-hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream_t stream);
+hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream_t stream, int tile_list_blocks = 0);  // > 0: rc.tile_order lists that many tiles of the rect's grid
 hipError_t launch_bake(const BakeConsts &bc, hipStream_t stream);
 hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int tiles_x, int tiles_y, int rx, int ry, uint32_t *tmp1, uint32_t *tmp2,
                              uint32_t *scratch, hipStream_t stream);

@@ -2199,15 +2199,25 @@ void render_grid(const RenderConsts &rc, int split, int *tiles_x, int *tiles_y) 
     *tiles_y = (rc.y1 - rc.gy0 + th - 1) / th;
 }
 
+// Blocks of the launch in flight: 0 = the whole grid of the rect; n > 0 = a tile-list draw (atmo_render_tiles): n blocks, block b shades
+// tile rc.tile_order[b] of that grid.  (A plain variable instead of a parameter threaded through the 80-case dispatch below; the host API
+// is single-threaded per context and sets it around one launch_render call.)
+static thread_local int g_launch_blocks = 0;
+
 template <int FLAGS, int LSTEPS, int SPLIT>
 static hipError_t launch_s(const RenderConsts &rc, hipStream_t stream) {
     int gx, gy;
     render_grid(rc, SPLIT, &gx, &gy);
     if (gx != rc.tiles_x) return hipErrorInvalidValue;
+    dim3 grid(gx, gy);
+    if (g_launch_blocks > 0) {
+        if (rc.tile_order == nullptr) return hipErrorInvalidValue;
+        grid = dim3(g_launch_blocks, 1);
+    }
     if constexpr (render_sgpr_cap80(FLAGS))
-        hipLaunchKernelGGL((atmo_render_kernel_s80<FLAGS, LSTEPS, SPLIT>), dim3(gx, gy), dim3(TILE_W * TILE_H), 0, stream, rc);
+        hipLaunchKernelGGL((atmo_render_kernel_s80<FLAGS, LSTEPS, SPLIT>), grid, dim3(TILE_W * TILE_H), 0, stream, rc);
     else
-        hipLaunchKernelGGL((atmo_render_kernel<FLAGS, LSTEPS, SPLIT>), dim3(gx, gy), dim3(TILE_W * TILE_H), 0, stream, rc);
+        hipLaunchKernelGGL((atmo_render_kernel<FLAGS, LSTEPS, SPLIT>), grid, dim3(TILE_W * TILE_H), 0, stream, rc);
     return hipGetLastError();
 }
 
@@ -2222,7 +2232,14 @@ static hipError_t launch_direct(const RenderConsts &rc, int split, hipStream_t s
     return rc.light_steps == 8 ? launch_t<FLAGS, 8>(rc, split, stream) : launch_t<FLAGS, 0>(rc, split, stream);
 }
 
-hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream_t stream) {
+static hipError_t launch_render_grid(int flags, int split, const RenderConsts &rc, hipStream_t stream);
+hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream_t stream, int tile_list_blocks) {
+    g_launch_blocks = tile_list_blocks;
+    const hipError_t e = launch_render_grid(flags, split, rc, stream);
+    g_launch_blocks = 0;
+    return e;
+}
+static hipError_t launch_render_grid(int flags, int split, const RenderConsts &rc, hipStream_t stream) {
     switch (flags) {
     case 0: return launch_t<0, 0>(rc, split, stream);
     case KF_LIGHT_DIRECT: return launch_direct<KF_LIGHT_DIRECT>(rc, split, stream);

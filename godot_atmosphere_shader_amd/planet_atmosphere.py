@@ -608,6 +608,21 @@ class PlanetAtmosphere:
         rc = self._lib.atmo_render(self._ctx, C.byref(nf), C.c_void_p(depth_ptr), C.c_void_p(out_ptr), C.c_void_p(stream or 0))
         N.check(self._ctx, rc)
 
+    def render_tiles_prepared(self, native_frame: N.AtmoFrame, depth_ptr: int, out_ptr: int, tiles_ptr: int, n_tiles: int, stream: int = 0):
+        """atmo_render_tiles: draw only the listed tiles (uint32 indices in device memory, row-major in the grid of
+        measure_tile_costs) of the frame's rect, in list order; `out_ptr` is addressed like render_prepared's."""
+        self._bake_if_needed(stream)
+        rc = self._lib.atmo_render_tiles(self._ctx, C.byref(native_frame), C.c_void_p(depth_ptr), C.c_void_p(out_ptr), C.c_void_p(tiles_ptr),
+                                         int(n_tiles), C.c_void_p(stream or 0))
+        N.check(self._ctx, rc)
+
+    def measure_tile_costs(self, camera, depth, rect=None, stream=None, time: float = 0.0):
+        """One draw through atmo_measure_tile_costs: ((tiles_y, tiles_x) uint32 costs -- every tile's longest wavefront in shader cycles --,
+        tile_w, tile_h).  sharding.lpt_strips deals them to the GPUs of a node."""
+        rows = self.measure_row_costs(camera, depth, rect=rect, stream=stream, time=time)
+        del rows
+        return self._last_tile_costs, self._last_tile_size[0], self._last_tile_size[1]
+
     def measure_row_costs(self, camera, depth, rect=None, stream=None, time: float = 0.0):
         """Measured cost of every pixel row of `rect` (default: the whole viewport): one draw through atmo_measure_tile_costs,
         each tile's cost (longest wavefront, shader cycles) spread over its pixel rows and summed along the row.  Feed it to
@@ -630,6 +645,7 @@ class PlanetAtmosphere:
         N.check(self._ctx, self._lib.atmo_measure_tile_costs(*args, cost.ctypes.data_as(C.c_void_p), cost.size, C.byref(gx), C.byref(gy),
                                                             C.byref(tw), C.byref(th)))
         self._last_tile_costs = cost  # (tiles_y, tiles_x) uint32, for diagnostics (tools/xcd_balance.py)
+        self._last_tile_size = (tw.value, th.value)
         rows = np.repeat(cost.astype(np.float64).sum(axis=1) / th.value, th.value)[: y1 - y0]
         return rows
 

@@ -7,6 +7,10 @@ GPU), so there is no exchange during compute.  Two partitions are
   * row bands: one viewport cut into contiguous bands of rows, one per rank, so that each rank's output
     is one contiguous slab of the frame (strong scaling).  `balanced_row_bands` cuts by per-row hit
     counts instead of row counts when bands would otherwise be unequal work (P_space has empty rows).
+  * tile strips (round 4): one viewport cut into strips of STRIP_TILE_ROWS tile rows (16 pixel rows), dealt to the
+    ranks longest-processing-time-first by their MEASURED cost (`lpt_strips`), so that every rank gets a mix of
+    heavy and cheap tiles instead of one neighbourhood of the picture; a rank draws the tiles of its strips in ONE
+    launch (atmo_render_tiles, heaviest tile first) and `StripGather` puts the strips back in place on the root.
 
 The only collective is the final gather of RGBA32F pixels to the root rank (`torch.distributed`, backend
 "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).  Root ingress is per-link bound
@@ -161,3 +165,89 @@ class FrameGather:
         for k, (y0, y1) in enumerate(self.bands):
             frame[y0:y1] = self.recv[last][k, : y1 - y0]
         return frame
+
+
+# ---- tile strips (BASELINE north_star: "independent framebuffer tiles shard embarrassingly across the 8 GPUs") -------------------------
+STRIP_TILE_ROWS = 2  # tile rows per strip: 2 x 8 = 16 pixel rows
+
+
+def lpt_strips(tile_cost, world_size: int, strip_tile_rows: int = STRIP_TILE_ROWS):
+    """Deals the strips of a tile grid to `world_size` ranks, longest processing time first.
+
+    tile_cost: (tiles_y, tiles_x) measured costs (PlanetAtmosphere.measure_tile_costs).  A strip is `strip_tile_rows` consecutive
+    tile rows; its cost the sum of its tiles'.  Strips are sorted by cost, heaviest first, and each goes to the rank with the least
+    work so far (ties: the lowest rank) -- deterministic, so every rank computes the same deal from the same costs.
+    Returns (strips_of_rank, tiles_of_rank): per rank the strip indices in ascending order, and the tile indices (row-major in the
+    grid) of those strips sorted by tile cost, heaviest first (the order atmo_render_tiles draws them in)."""
+    cost = np.asarray(tile_cost, dtype=np.float64)
+    ty, tx = cost.shape
+    if world_size < 1:
+        raise ValueError("world_size must be >= 1")
+    n_strips = (ty + strip_tile_rows - 1) // strip_tile_rows
+    strip_cost = np.array([cost[k * strip_tile_rows:(k + 1) * strip_tile_rows].sum() for k in range(n_strips)])
+    order = sorted(range(n_strips), key=lambda k: (-strip_cost[k], k))
+    load = [0.0] * world_size
+    strips = [[] for _ in range(world_size)]
+    for k in order:
+        r = min(range(world_size), key=lambda q: (load[q], q))
+        strips[r].append(k)
+        load[r] += float(strip_cost[k]) + 1e-9  # (all-zero costs still deal round-robin)
+    tiles = []
+    for r in range(world_size):
+        strips[r].sort()
+        ids = [t for k in strips[r] for row in range(k * strip_tile_rows, min((k + 1) * strip_tile_rows, ty)) for t in range(row * tx, (row + 1) * tx)]
+        ids.sort(key=lambda t: (-cost.flat[t], t))
+        tiles.append(np.asarray(ids, dtype=np.uint32))
+    return strips, tiles
+
+
+class StripGather:
+    """Gathers the strips each rank drew into the frame on rank `dst`.
+
+    Every rank renders into a full (H, W, 4) frame buffer of its own (atmo_render_tiles addresses the rect like atmo_render; only its
+    tiles are written), packs its strips into a send buffer (one indexed copy), and the root scatters what it receives into the frame
+    (one indexed copy per gather): strips are whole pixel rows, so both are contiguous row blocks.  Ranks hold different numbers of
+    strips (LPT balances cost, not count): the send buffers are padded to the largest count."""
+
+    def __init__(self, height: int, width: int, strips_of_rank, strip_rows: int, device, dst: int = 0, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank, self.world, self.dst = dist.get_rank(group), dist.get_world_size(group), dst
+        if len(strips_of_rank) != self.world:
+            raise ValueError("need one strip list per rank")
+        self.h, self.w, self.strip_rows = height, width, strip_rows
+        self.n_strips = (height + strip_rows - 1) // strip_rows
+        flat = sorted(k for s in strips_of_rank for k in s)
+        if flat != list(range(self.n_strips)):
+            raise ValueError("the strip lists must partition the frame's strips")
+        self.padded_h = self.n_strips * strip_rows
+        self.max_strips = max(1, max(len(s) for s in strips_of_rank))
+        self.mine = torch.as_tensor(list(strips_of_rank[self.rank]), dtype=torch.int64, device=device)
+        self.frame = torch.zeros((self.padded_h, width, 4), dtype=torch.float32, device=device)  # this rank renders into frame[:height]
+        self.send = torch.zeros((self.max_strips, strip_rows, width, 4), dtype=torch.float32, device=device)
+        self.recv = None
+        if self.rank == dst:
+            self.recv = torch.empty((self.world, self.max_strips, strip_rows, width, 4), dtype=torch.float32, device=device)
+            self.src_index = torch.as_tensor([r * self.max_strips + i for r, s in enumerate(strips_of_rank) for i in range(len(s))],
+                                             dtype=torch.int64, device=device)
+            self.dst_index = torch.as_tensor([k for s in strips_of_rank for k in s], dtype=torch.int64, device=device)
+
+    def render_target(self):
+        """(H, W, 4): where this rank's tile-list draw writes (rows beyond H exist only as padding of the last strip)."""
+        return self.frame[: self.h]
+
+    def gather(self):
+        """Collective: on the root returns the assembled (H, W, 4) frame, elsewhere None."""
+        torch = self.torch
+        strips = self.frame.view(self.n_strips, self.strip_rows, self.w, 4)
+        if self.mine.numel():
+            self.send[: self.mine.numel()] = strips.index_select(0, self.mine)
+        gather_list = [self.recv[k] for k in range(self.world)] if self.rank == self.dst else None
+        self.dist.gather(self.send, gather_list, dst=self.dst, group=self.group)
+        if self.rank != self.dst:
+            return None
+        flat = self.recv.view(self.world * self.max_strips, self.strip_rows, self.w, 4)
+        strips.index_copy_(0, self.dst_index, flat.index_select(0, self.src_index))
+        return self.frame[: self.h]

@@ -194,6 +194,18 @@ int atmo_render(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev
 int atmo_render_composite(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *scene_rgba_dev, void *stream);
 
 /*
+ * Sharding aid (no reference counterpart; BASELINE north_star: "independent framebuffer tiles shard across the GPUs of one node"): draws
+ * only the listed pixel tiles of the rect, in list order.  tiles_dev: n_tiles indices (device memory, stream-ordered) into the launch grid
+ * atmo_measure_tile_costs reports for this rect, row-major (tile t covers pixel columns x0 + (t % tiles_x) * tile_w .. and rows
+ * y0 + (t / tiles_x) * tile_h ..., clipped by the rect; with the declared cubemap sampler the grid starts on the even pixel at or before
+ * (x0, y0)).  rgba_dev is addressed exactly as in atmo_render -- (y1-y0) rows of (x1-x0) pixels -- and only the listed tiles' pixels are
+ * written: N GPUs given a partition of the tile list into N lists produce, between them, the frame atmo_render draws, bit for bit.
+ * Tile-order feedback does not apply (the list is the order: put the heaviest tiles first).
+ */
+int atmo_render_tiles(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, const uint32_t *tiles_dev, int n_tiles,
+                      void *stream);
+
+/*
  * Sharding aid (no reference counterpart: the reference is single-GPU): draws the rect like atmo_render and
  * returns what every pixel tile of that draw cost -- the longest of its wavefronts, in shader cycles, row-major over the
  * launch grid (tiles_x x tiles_y tiles of tile_w x tile_h pixels, the last column / row clipped by the rect).  A host that

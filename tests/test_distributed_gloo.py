@@ -333,3 +333,73 @@ def test_cloud_weighted_row_cost_balances_cloud_variants():
         assert bands[0][0] == 0 and bands[-1][1] == 108
         sums = [cost[a:b].sum() for a, b in bands]
         assert max(sums) / (sum(sums) / 4) < 1.25
+
+
+# ---- tile strips dealt longest-processing-time-first (round 4: --shard tiles) ----------------------------------------------------------------
+
+def test_lpt_strips_partition_and_balance():
+    """lpt_strips: every strip and every tile belongs to exactly one rank, a rank's tile list is sorted heaviest first, the deal is
+    deterministic, and on a cost map with one heavy neighbourhood (a cloud bank) the ranks' loads come out within a few per cent of each other
+    where contiguous row bands of equal ROWS would be 4x apart."""
+    from godot_atmosphere_shader_amd.sharding import STRIP_TILE_ROWS, lpt_strips, row_bands
+
+    rng = np.random.default_rng(5)
+    ty, tx = 135, 120   # 1920 x 1080 in 16 x 8 tiles
+    cost = rng.integers(200, 400, (ty, tx)).astype(np.uint32)
+    cost[40:70, 30:90] += rng.integers(3000, 30000, (30, 60)).astype(np.uint32)   # the heavy part of the picture
+    cost[:12] = 0
+    for world in (1, 2, 4, 8):
+        strips, tiles = lpt_strips(cost, world)
+        assert sorted(k for s in strips for k in s) == list(range((ty + STRIP_TILE_ROWS - 1) // STRIP_TILE_ROWS))
+        assert sorted(int(t) for ts in tiles for t in ts) == list(range(ty * tx))
+        for r in range(world):
+            c = cost.reshape(-1)[tiles[r]].astype(np.int64)
+            assert np.all(np.diff(c) <= 0)                                             # heaviest first
+            rows = sorted({int(t) // tx // STRIP_TILE_ROWS for t in tiles[r]})
+            assert rows == strips[r]                                                  # the tiles of exactly its strips
+        again = lpt_strips(cost, world)
+        assert again[0] == strips and all(np.array_equal(a, b) for a, b in zip(again[1], tiles))
+        load = np.array([cost.reshape(-1)[t].sum(dtype=np.int64) for t in tiles], dtype=np.float64)
+        if world > 1:
+            bands = [cost[y0 // 8:(y1 + 7) // 8].sum(dtype=np.int64) for y0, y1 in row_bands(ty * 8, world)]
+            assert load.max() / load.mean() < 1.06 < max(bands) / np.mean(bands)
+    assert lpt_strips(np.zeros((5, 3)), 2)[0] == [[0, 2], [1]]   # nothing measured: still a partition, dealt in turn
+
+
+def _strips_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from godot_atmosphere_shader_amd.sharding import StripGather, lpt_strips
+
+        h, w, tile_h, strip_tile_rows = 27, 11, 4, 2          # 7 tile rows -> 4 strips of 8 pixel rows, the last one 3 rows tall
+        tiles_y, tiles_x = (h + tile_h - 1) // tile_h, 3
+        cost = (np.arange(tiles_y * tiles_x).reshape(tiles_y, tiles_x) % 5 + 1).astype(np.uint32)
+        strips, tiles = lpt_strips(cost, world, strip_tile_rows)
+        g = StripGather(h, w, strips, strip_tile_rows * tile_h, torch.device("cpu"), dst=0)
+        want = torch.arange(h * w * 4, dtype=torch.float32).reshape(h, w, 4)
+        for it in range(2):   # the buffers are re-used frame after frame
+            target = g.render_target()
+            target.fill_(-1.0)
+            for k in strips[rank]:   # what a tile-list draw writes: the pixels of this rank's strips, nothing else
+                y0, y1 = k * strip_tile_rows * tile_h, min((k + 1) * strip_tile_rows * tile_h, h)
+                target[y0:y1] = want[y0:y1] + float(it)
+            res = g.gather()
+            if rank == 0:
+                assert res.shape == (h, w, 4) and torch.equal(res, want + float(it))
+            else:
+                assert res is None
+        with open(os.path.join(tmpdir, f"ok_strips_{rank}"), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_strip_gather_assembles_the_frame(tmp_path, world):
+    port = _free_port()
+    mp.spawn(_strips_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert (tmp_path / f"ok_strips_{r}").exists()

@@ -491,6 +491,48 @@ def test_texture_update_waits_for_draws_on_every_other_stream():
     node.close()
 
 
+
+def test_tile_list_draws_partition_the_frame():
+    """atmo_render_tiles (BASELINE north_star: "independent framebuffer tiles shard across the GPUs"): the tiles of the frame dealt to N ranks
+    (sharding.lpt_strips on measured costs), every rank's list drawn by itself into a poisoned full-frame buffer, and the strips put
+    together equal atmo_render's frame bit for bit -- no-cloud, clouds under both samplers (the declared sampler's quad partners across a
+    strip border are helper lanes... of the SAME draw only when the partner tile is in the list: strips are 16 rows, tiles 8, quads 2:
+    a quad never straddles a strip), raymarched light, a rect with an odd origin."""
+    import torch
+    from godot_atmosphere_shader_amd.sharding import STRIP_TILE_ROWS, lpt_strips
+
+    tex, params = demo_textures(cube_n=64, shape_n=32), demo_params()
+    for config_name, kw, pose, (w, h), rect in (("no_clouds_32x8_direct", {}, "P_space", (320, 180), None),
+                                                ("clouds_high", dict(cubemap_lod=None), "P_clouds", (304, 171), None),
+                                                ("clouds_high_rm", dict(cubemap_lod=None), "P_space", (320, 180), None),
+                                                ("clouds_high_rm", {}, "P_limb", (320, 180), (16, 32, 303, 163))):
+        cam = S.Camera.from_pose(w, h, pose)
+        depth_np = S.depth_ground_sphere(cam)
+        depth = torch.from_numpy(depth_np).cuda()
+        node = make_node(config_name, tex, params, **kw)
+        want = _gpu_render(node, cam, depth_np, rect=rect)
+        cost, tw, th = node.measure_tile_costs(cam, depth, rect=rect)
+        assert (tw, th) == (16, 8) and cost.shape == ((want.shape[0] + th - 1) // th, (want.shape[1] + tw - 1) // tw)
+        frame = node.prepare_frame(cam, rect=rect)
+        stream = torch.cuda.current_stream().cuda_stream
+        for world in (1, 3):
+            strips, tiles = lpt_strips(cost, world)
+            got = np.full_like(want, np.nan)
+            for r in range(world):
+                out = torch.full(want.shape, 77.5, dtype=torch.float32, device="cuda")
+                t = torch.from_numpy(tiles[r].astype(np.int32)).cuda()
+                node.render_tiles_prepared(frame, depth.data_ptr(), out.data_ptr(), t.data_ptr(), t.numel(), stream)
+                torch.cuda.synchronize()
+                o = out.cpu().numpy()
+                mine = np.zeros(want.shape[0], dtype=bool)
+                for k in strips[r]:
+                    mine[k * STRIP_TILE_ROWS * th:(k + 1) * STRIP_TILE_ROWS * th] = True
+                assert np.all(o[~mine] == 77.5), (config_name, world, r)          # nothing outside its strips is touched
+                got[mine] = o[mine]
+            assert np.array_equal(got, want), (config_name, world)
+        node.close()
+
+
 def test_user_supplied_lut_of_other_size(oracle32):
     """atmo_set_texture with a LUT that is not 256x256 (apron layout with run-time stride)."""
     w, h = 128, 72
