@@ -303,10 +303,12 @@ def parse_args():
                          "what bounds a strong-scaled cloud frame -- for 13-29 %% more work; LOD-0 sampler only)")
     ap.add_argument("--also", default="lut32,shipped8,clouds_high,clouds_high_rm,direct32x8@3840x2160,clouds_high_rm@3840x2160,"
                                       "clouds_high@lod0,clouds_high_rm@lod0,clouds_high_rm@lod0@3840x2160,direct32x8@moving,clouds_high_rm@moving,"
-                                      "direct32x8+2vp,direct32x8@reforder,shipped8@cleared,lut32@cleared,noise_cubemap",
+                                      "direct32x8@reforder,shipped8@cleared,lut32@cleared,noise_cubemap,direct32x8+2vp",
                     help="comma-separated extra workloads (name[@lod0][@reforder][@cleared][@WxH], name@moving, name+2vp) timed at N=1 after the headline and reported under "
                          "'extra', each with its own roofline blocks: the reference-exact LUT mode and the shipped 8-step shader "
-                         "(SURVEY.md 8d), BASELINE configs[2] (clouds_high 1080p) and configs[3] (clouds_high_rm 3840x2160); '' to skip")
+                         "(SURVEY.md 8d), BASELINE configs[2] (clouds_high 1080p) and configs[3] (clouds_high_rm 3840x2160); '' to skip.  "
+                         "name+2vp goes LAST: after two contexts have drawn concurrently on two extra streams, later single-stream draws of the "
+                         "same process measure 10-20 %% slower (profiles/round4/bench_order_effect.txt)")
     return ap.parse_args()
 
 

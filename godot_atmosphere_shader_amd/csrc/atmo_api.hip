@@ -635,6 +635,7 @@ int atmo_create(int device, int variant, int view_steps, int cloud_steps, int li
     if (const char *ev = std::getenv("ATMO_LANE_SPLIT")) ctx->env_split = ev[0] == '1' ? 1 : (ev[0] == '2' ? 2 : 0);
     if (const char *ev = std::getenv("ATMO_TILE_FEEDBACK")) ctx->env_feedback = ev[0] == '1' ? 1 : 0;
     if (const char *ev = std::getenv("ATMO_F4")) ctx->f4_footprints = std::atoi(ev) & 3;
+    if (const char *ev = std::getenv("ATMO_TARGET_CLEARED")) ctx->target_cleared = ev[0] == '1' ? 1 : 0;  // tools/ab_env.sh: atmo_set_target_cleared
     if (const char *ev = std::getenv("ATMO_FB_INSTREAM")) ctx->instream = ev[0] == '1' ? 1 : 0;
     if (const char *ev = std::getenv("ATMO_FB_REACH_SCALE")) ctx->env_reach_scale = (float)std::atof(ev);
     if (const char *ev = std::getenv("ATMO_FB_MOVING_PERIOD")) { const int v = std::atoi(ev); ctx->moving_period = (unsigned)(v < 1 ? 1 : v); }

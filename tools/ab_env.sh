@@ -7,8 +7,8 @@ for spec in "$@"; do
   for r in $(seq 1 ${ROUNDS:-3}); do
     for v in on off; do
       if [ $v = off ]; then export $VAR=${OFF:-0}; else unset $VAR; fi
-      name=${WL%@lod}; samp=lod0; [ "$name" != "$WL" ] && samp=lod
-      ms=$(python bench.py --workload $name --sampler $samp --pose $POSE --width $W --height $H --steps ${STEPS:-60} --warmup 10 --no-cpu-baseline --also "" 2>/dev/null | python -c "import json,sys; print('%.4f' % json.loads(sys.stdin.readline())['roofline']['kernel_avg_ms'])")
+      name=${WL%@lod0}; samp=declared; [ "$name" != "$WL" ] && samp=lod0
+      ms=$(ATMO_BENCH_DETAIL= python bench.py --workload $name --sampler $samp --pose $POSE --width $W --height $H --steps ${STEPS:-60} --warmup 10 --no-cpu-baseline --also "" 2>/dev/null | python -c "import json,sys; print('%.4f' % json.loads(sys.stdin.readline())['roofline']['kernel_avg_ms'])")
       if [ $v = off ]; then B="$B $ms"; else A="$A $ms"; fi
     done
   done
