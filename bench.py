@@ -170,7 +170,8 @@ def write_detail(result):
     try:
         with open(path, "w") as f:
             json.dump(result, f)
-        return path
+        rel = os.path.relpath(path)
+        return path if rel.startswith("..") else rel
     except OSError:
         return None
 

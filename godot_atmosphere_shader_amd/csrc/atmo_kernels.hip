@@ -2176,7 +2176,20 @@ __global__ __launch_bounds__(256) void atmo_selftest_kernel(uint32_t first_bits,
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
         const float x = __int_as_float((int)(first_bits + k));
         const int want = __float_as_int(ieee_sqrt(x));  // both short forms: the prologue's and the cloud chain's
-        if (__float_as_int(exact_sqrt(x)) != want || __float_as_int(exact_sqrt_pos(x)) != want) ++bad_sqrt;
+        if (x >= 0.0f && x < 1.9721523e-31f) {
+            // 0, denormals and the binades below 2^-102: exact_sqrt_pos is not the IEEE root there (x = 0 gives NaN) and does not have to be --
+            // what the cloud chain needs from such an |p|^2 (a sample at the planet's centre) is the OUTCOME: the height curve of a layer
+            // whose bottom shell has a positive radius is 0, i.e. the density evaluation leaves through its first early-out.  A NaN root gets
+            // there through fmaxf(NaN, 0) = 0 (IEEE maxNum, which v_max_f32 implements): pinned here instead of assumed.
+            const float bottom = c, thick = c;  // any positive shell radius and thickness
+            auto height_curve = [&](float r) {
+                const float hr = exact_div_uniform(r - bottom, thick, rc);
+                const float t = 2.0f * hr - 1.0f;
+                return fmaxf(1.0f - t * t, 0.0f);
+            };
+            const float hc_fast = height_curve(exact_sqrt_pos(x)), hc_ieee = height_curve(ieee_sqrt(x));
+            if ((hc_fast > 0.0f) || (hc_ieee > 0.0f) || __float_as_int(exact_sqrt(x)) != want) ++bad_sqrt;
+        } else if (__float_as_int(exact_sqrt(x)) != want || __float_as_int(exact_sqrt_pos(x)) != want) ++bad_sqrt;
         if (__float_as_int(exact_div_uniform(x, c, rc)) != __float_as_int(ieee_div(x, c))) ++bad_div;
     }
     if (bad_sqrt) atomicAdd(&mismatch[0], bad_sqrt);

@@ -264,7 +264,12 @@ int atmo_set_target_cleared(AtmoContext *ctx, int cleared);
  * miss the planet, clear sky) into that drain: direct light 32x8 +9.7 %, clouds_high +5 %, clouds_high_rm +49 %
  * (its heaviest tiles are ~10x the mean), baked-LUT atmosphere +4..5 %; within +-1.5 % on frames whose tiles all weigh
  * the same (profiles/round2/ab_tile_feedback.txt).  The picture does not depend on the order.
- * -1 (default) = on; 0 = off; 1 = on.  Launches inside a HIP graph capture never use it.  A context keeps one feedback
+ * -1 (default) = on; 0 = off; 1 = on.  Launches inside a HIP graph capture never use it.
+ * Host-side waits this machinery can cause (hipDeviceSynchronize: ALL of the process's GPU work, not only this context's): changing the
+ * mode while draws are in flight; a FIFTH distinct (rect grid, stream) pair while four are cached (the least recently used state is
+ * recycled, at most 8 times in a row, then such draws simply run in row-major order without waiting); and, outside the feedback, a
+ * texture update arriving on a stream other than one the context drew on.  A host that cycles through many rects should turn the
+ * feedback off (0) for that context.  A context keeps one feedback
  * state per (launch grid, draw stream) it sees, up to four (split screen, stereo eyes, uneven row bands), each allocated by
  * the first launch of its key; a fifth key recycles the least recently used state (which waits for that state's work),
  * and a context that keeps producing new keys runs out of recycling budget (8, one regained every 256 draws) and draws

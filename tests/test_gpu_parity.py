@@ -315,6 +315,13 @@ def test_exact_math_selftest():
         bs, bd = C.c_uint32(0), C.c_uint32(0)
         assert lib.atmo_selftest_exact_math(ctx, (110 + 2 * k) << 23, 1 << 23, dv, C.byref(bs), C.byref(bd)) == N.ATMO_OK
         assert bd.value == 0, (dv, bd.value)
+    # |p|^2 = 0, every denormal and the smallest binades (a sample at the planet's centre): the rsq-based root is not the IEEE one there (NaN
+    # for 0) -- the selftest checks instead that the height curve of a layer with a positive bottom radius comes out 0 either way (the
+    # density evaluation's first early-out), and that the prologue's root still equals IEEE
+    for first, count in ((0, 1 << 23), (1 << 23, 24 << 23)):
+        bs, bd = C.c_uint32(0), C.c_uint32(0)
+        assert lib.atmo_selftest_exact_math(ctx, first, count, 3.2, C.byref(bs), C.byref(bd)) == N.ATMO_OK
+        assert bs.value == 0, (first, bs.value)
     # negative dividends (heights below the cloud bottom)
     bs, bd = C.c_uint32(0), C.c_uint32(0)
     assert lib.atmo_selftest_exact_math(ctx, (1 << 31) | (127 << 23), 1 << 23, divisors[0], C.byref(bs), C.byref(bd)) == N.ATMO_OK
