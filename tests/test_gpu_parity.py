@@ -1305,7 +1305,11 @@ def test_device_texture_layouts_equal_the_host_layouts():
     # argument checks
     assert lib.atmo_set_texture(ctx, b"u_cloud_coverage_cubemap", N.TEX_CUBE_R8, 8, 8, 6, 9, cube.ctypes.data_as(C.c_void_p), N.MEM_HOST, None) == N.ATMO_E_ARG
     assert lib.atmo_set_texture(ctx, b"u_cloud_shape_texture", N.TEX_3D_R8, 8, 8, 8, 2, cube.ctypes.data_as(C.c_void_p), N.MEM_HOST, None) == N.ATMO_E_ARG
-    assert lib.atmo_set_sampler_lod(ctx, 2) == N.ATMO_E_ARG
+    assert lib.atmo_set_sampler_lod(ctx, 2) == N.ATMO_E_ARG and lib.atmo_set_sampler_lod(ctx, -2) == N.ATMO_E_ARG
+    assert lib.atmo_set_sampler_lod(ctx, -1) == N.ATMO_OK and lib.atmo_set_target_cleared(ctx, 1) == N.ATMO_OK
+    assert lib.atmo_render_tiles(ctx, None, None, None, None, -1, None) == N.ATMO_E_ARG          # negative count
+    assert lib.atmo_render_tiles(ctx, None, None, None, None, 3, None) == N.ATMO_E_ARG           # a count without a list
+    assert lib.atmo_render_tiles(ctx, None, None, None, None, 0, None) == N.ATMO_OK              # an empty share of the frame: nothing to do
     lib.atmo_destroy(ctx)
 
 

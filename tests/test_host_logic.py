@@ -72,6 +72,10 @@ def test_argument_validation_needs_no_gpu():
     assert lib.atmo_create(0, 0, 0, 0, 0, 0, None) == N.ATMO_E_ARG
     assert lib.atmo_destroy(None) == N.ATMO_OK
     assert lib.atmo_set_param_f32(None, b"u_density", (C.c_float * 1)(1.0), 1) == N.ATMO_E_ARG
+    # round 4 entry points: a null context is an argument error, not a crash
+    assert lib.atmo_set_target_cleared(None, 1) == N.ATMO_E_ARG
+    assert lib.atmo_set_sampler_lod(None, -1) == N.ATMO_E_ARG
+    assert lib.atmo_render_tiles(None, None, None, None, None, 0, None) == N.ATMO_E_ARG
 
 
 def test_row_bands_cover_and_partition():
