@@ -168,7 +168,8 @@ struct AtmoContext {
     uint32_t *measure_cost = nullptr;                  // atmo_measure_tile_costs: the next draw records here
     // the streams draws of this context have been enqueued on since the last texture update waited for them: an update arriving on
     // stream s is stream-ordered behind the draws on s and has to wait, on the host, for those on every OTHER stream of this set
-    std::vector<hipStream_t> draw_streams;
+    std::vector<hipStream_t> draw_streams;             // (at most 8 remembered; beyond that `draw_streams_many` stands for "some other stream")
+    bool draw_streams_many = false;
     DeviceBuffer measure_buf;                          // atmo_measure_tile_costs: the tile costs on their way to the host (grow-only)
 #ifdef ATMO_WAVE_TRACE
     DeviceBuffer wave_trace;                           // diagnostic build only
@@ -769,11 +770,12 @@ static int tex_updated(AtmoContext *ctx, hipStream_t s) {
 //     reading).  Updates are rare and normally arrive on the one draw stream, where stream order is enough and nothing waits.
 static int tex_begin_update(AtmoContext *ctx, hipStream_t s) {
     if (ctx->tex_pending && ctx->tex_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->tex_event, 0));
-    bool elsewhere = false;
+    bool elsewhere = ctx->draw_streams_many;
     for (hipStream_t d : ctx->draw_streams) elsewhere = elsewhere || d != s;
     if (elsewhere) {
         HIP_TRY(ctx, hipDeviceSynchronize());
         ctx->draw_streams.clear();   // nothing of this context is in flight any more
+        ctx->draw_streams_many = false;
     }
     return ATMO_OK;
 }
@@ -1336,7 +1338,10 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     {
         bool known = false;
         for (hipStream_t d : ctx->draw_streams) known = known || d == s;
-        if (!known) ctx->draw_streams.push_back(s);
+        if (!known) {
+            if (ctx->draw_streams.size() < 8) ctx->draw_streams.push_back(s);
+            else ctx->draw_streams_many = true;  // a host that draws on a new stream every frame: bounded memory, the next update waits
+        }
     }
     ctx->last_split = split;
     ctx->launch_counter += 1;  // counted only once the launch was accepted

@@ -200,6 +200,7 @@ int atmo_render_composite(AtmoContext *ctx, const AtmoFrame *frame, const float 
  * y0 + (t / tiles_x) * tile_h ..., clipped by the rect; with the declared cubemap sampler the grid starts on the even pixel at or before
  * (x0, y0)).  rgba_dev is addressed exactly as in atmo_render -- (y1-y0) rows of (x1-x0) pixels -- and only the listed tiles' pixels are
  * written: N GPUs given a partition of the tile list into N lists produce, between them, the frame atmo_render draws, bit for bit.
+ * An index beyond the grid shades nothing (its pixels lie outside the rect).
  * Tile-order feedback does not apply (the list is the order: put the heaviest tiles first).
  */
 int atmo_render_tiles(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, const uint32_t *tiles_dev, int n_tiles,
