@@ -2,7 +2,7 @@
 """How full the light batches of the lit-sample queue run (march_clouds_rm_queue), from a diagnostic build:
 
     tools/ab_build.sh rmqstats -DATMO_WAVE_TRACE=1 -DATMO_RMQ_STATS=1
-    gpurun -- 'ATMO_HIP_LIB=$PWD/godot_atmosphere_shader_amd/libatmo_hip_rmqstats.so python tools/rmq_stats.py [workload W H pose]'
+    gpurun -- 'ATMO_HIP_LIB=$PWD/godot_atmosphere_shader_amd/libatmo_hip_rmqstats.so python tools/rmq_stats.py [workload[@lod0] W H pose]'
 """
 import ctypes as C
 import os
@@ -24,8 +24,8 @@ def main():
     pose = sys.argv[4] if len(sys.argv) > 4 else "P_space"
     config_name, _ = bench.WORKLOADS[wl.split("@")[0]]
     kw = dict(bench.node_kwargs(wl.split("@")[0]))
-    if wl.endswith("@lod"):
-        kw["cubemap_lod"] = True
+    if wl.endswith("@lod0"):   # default: the declared cubemap sampler; name@lod0: level 0 only
+        kw["cubemap_lod"] = False
     node = make_node(config_name, demo_textures(), demo_params(), **kw)
     cam = S.Camera.from_pose(w, h, pose)
     depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
