@@ -485,6 +485,7 @@ __device__ __forceinline__ void quad_exchange_positions(float px, float py, floa
     asm volatile(
         "s_mov_b64 %[saved], exec\n\t"
         "s_wqm_b64 exec, exec\n\t"
+        "s_nop 1\n\t"  // a VALU write of px / py / pz right in front of the block needs 2 wait states before a DPP read (the compiler cannot see in here)
         "v_mov_b32_dpp %[fidx], %[px] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "v_mov_b32_dpp %[scx], %[py] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "v_mov_b32_dpp %[tcx], %[pz] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
