@@ -1533,6 +1533,7 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
     constexpr bool DIET = !DIRECT && !((FLAGS & KF_CLOUDS) && (FLAGS & KF_CLOUD_LIGHT_RM));
     constexpr bool FASTMISS = (ATMO_FAST_MISS_MASK >> ((DIRECT ? 1 : 0) + (CLOUDS ? 2 : 0) + (LITE ? 4 : 0))) & 1;
     static_assert(!LOD || (CLOUDS && PRECISE && SPLIT == 1), "implicit cubemap LOD: precise cloud kernels, one lane per ray");
+    static_assert(!LOD || (WAVE_W == 16 && WAVE_H == 4), "the quad-major lane order of the LOD kernels is written for 16 x 4 pixel waves");
 
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
     const f32x4 *lvl_table = nullptr;
