@@ -567,8 +567,8 @@ __device__ __forceinline__ float cube_sample_lod(const RenderConsts &rc, V3 d, b
 
 // ---- the same sampler on the fast path (rounds 3-4): power-of-two faces up to 1024 texels ----------------------------------------
 // What the general form above spends and this one does not: five IEEE divisions per sample (here: one v_rcp + two Markstein
-// steps shared by s and t -- the IEEE quotients, as in cube_sample<true> -- and ONE plain v_rcp for the derivatives of both quad
-// partners, whose relative error of 1e-7 moves lambda by 1e-7), face selection by compares (here: v_cubeid/sc/tc/ma), flat loads
+// steps shared by s and t -- the IEEE quotients, as in cube_sample<true> -- and a plain v_rcp per partner for the derivatives, whose
+// relative error of 1e-7 moves lambda by 1e-7), face selection by compares (here: v_cubeid/sc/tc/ma), flat loads
 // with integer address chains and a global load of the level offset (here: one buffer gather per level at a byte offset formed in
 // fp32 from four per-level constants read from a 16-entry LDS table).  Bit-for-bit the same s, t, texels and filters as the general
 // form; lambda agrees to a few ulp.
@@ -628,10 +628,9 @@ __device__ __forceinline__ CubeFaceFrame cube_face_frame(bool isz, bool isy, boo
     f.b2 = f.my * f.sgn;          // +Y: z, -Y: -z
     return f;
 }
-// One quad partner's finite difference (cube_lod_partner_coords below) on the selected face, as numerator and denominator of (2 rho / n)^2:
-//   s' - s = 0.5 (dsc ma - sc dma) / (ma ma') = 0.5 (dsc - (sc / ma) dma) / ma',   ma' = ma + dma      (cancellation-free, qs = sc / ma)
-//   num = (dsc - qs dma)^2 + (dtc - qt dma)^2,   den = ma'^2;   a partner that does not reach the call, or lies beyond the face's half
-//   space (ma' <= 0), contributes num = 0.
+// One quad partner's finite difference on the selected face (cube_lod_partner_coords below):
+//   s' - s = 0.5 (dsc ma - sc dma) / (ma ma'),   ma' = ma + dma      (the cancellation-free form of the Vulkan derivative transformation);
+//   rho^2 = ((s' - s)^2 + (t' - t)^2) n^2; a partner that does not reach the call, or lies beyond the face's half space (ma' <= 0), contributes 0.
 // The difference q - d is rounded like the reference's; the face frame applied to it is exact (one non-zero term per sum, whether the
 // compiler fuses it or not); everything behind it only moves lambda by ulps.
 // The direction a set of cube coordinates came from (inverse of the Vulkan face table; sc, tc are signed copies of two components and
@@ -642,12 +641,12 @@ __device__ __forceinline__ V3 cube_dir_from_coords(float fid, float sc, float tc
     if (fid < 4.0f) return V3{sc, m, fid < 3.0f ? tc : -tc};    // +Y: sc = +x, tc = +z;  -Y: sc = +x, tc = -z
     return V3{fid < 5.0f ? sc : -sc, -tc, m};                   // +Z: sc = +x, tc = -y;  -Z: sc = -x, tc = -y
 }
-// cube_lod_partner for a partner given by its cube coordinates.  On the lane's own face -- all but the quads that straddle a cube edge --
+// max(rho2, this partner's rho^2), the partner given by its cube coordinates.  On the lane's own face -- all but the quads that straddle a cube edge --
 // the differences of the coordinates ARE the face frame applied to the rounded difference of the directions, bit for bit: sc and tc are
 // signed copies of one component each (so scp - sc = +-(q.c - d.c), the same rounding), and 0.5 |v_cubema| is the major component with
 // the face's sign on both.
-__device__ __forceinline__ void cube_lod_partner_coords(const CubeFaceFrame &f, float fid, float sc, float tc, float qs, float qt, float ma, V3 d,
-                                                        bool valid, float fidp, float scp, float tcp, float masp, float &num, float &den) {
+__device__ __forceinline__ float cube_lod_partner_coords(const CubeFaceFrame &f, float fid, float sc, float tc, float ma, V3 d, bool valid, float fidp,
+                                                         float scp, float tcp, float masp, float n2, float rho2) {
     float dsc = scp - sc, dtc = tcp - tc, dma = 0.5f * fabsf(masp) - ma;
     if (valid && fidp != fid) {
         const V3 q = cube_dir_from_coords(fidp, scp, tcp, masp);
@@ -656,31 +655,24 @@ __device__ __forceinline__ void cube_lod_partner_coords(const CubeFaceFrame &f, 
         dtc = f.b1 * dv.y + f.b2 * dv.z;
         dma = f.sgn * (f.mx * dv.x + f.my * dv.y + f.mz * dv.z);
     }
-    float n_, ma2;
-    {
-#pragma clang fp contract(fast)
-        ma2 = ma + dma;
-        const float ns = dsc - qs * dma, nt = dtc - qt * dma;
-        n_ = ns * ns + nt * nt;
-    }
-    const bool ok = valid && ma2 > 0.0f;
-    num = ok ? n_ : 0.0f;
-    den = ok ? ma2 * ma2 : 1.0f;
+    // rho^2 of this partner exactly as rounds 2-3 evaluated it (the arithmetic the executed-reference vectors were pinned with): fused numerators,
+    // one approximate reciprocal per partner.  A cheaper form (both partners' numerators compared by cross-multiplication, ONE reciprocal; round 4,
+    // first attempt) is the same real function and differs by an ulp or two of lambda -- which is enough to move a hypersensitive pixel (a
+    // `clouds` march of 8 long steps at a high density scale: 1 ulp of lambda x 135 (density ramp) x ~250 (optical thickness per unit density)) by
+    // 5e-4: extended fuzz, seed 128, profiles/round4/fuzz_sensitive_pixels.txt.  Bit-identity with the pinned kernels was worth its 3 %.
+    // (written with explicit FMAs: under `fp contract(fast)` hipcc chooses which product of a difference to fuse, and that choice is part of the bits)
+    const float ma2 = ma + dma;
+    const float inv = 0.5f * hw_rcp(ma * ma2);
+    const float ds = __builtin_fmaf(ma, dsc, -(sc * dma)) * inv, dt = __builtin_fmaf(ma, dtc, -(tc * dma)) * inv;
+    const float r2 = __builtin_fmaf(dt, dt, ds * ds) * n2;
+    return (valid && ma2 > 0.0f) ? fmaxf(rho2, r2) : rho2;
 }
 
-// lambda from the two partners' (numerator, denominator), then the two nearest levels (cube_sample_lod_fast / _quad)
-__device__ __forceinline__ float cube_lod_finish(const RenderConsts &rc, float fid, float qs, float qt, float nx, float ex, float ny, float ey, const f32x4 *lvl) {
-    const float nf = (float)rc.cube_n;
-    float lambda;
-    {
-#pragma clang fp contract(fast)
-        // rho^2 = max(nx / ex, ny / ey) n^2 / 4: the larger quotient chosen by cross-multiplication, one reciprocal for both partners
-        const bool x_wins = nx * ey >= ny * ex;
-        const float num = x_wins ? nx : ny, den = x_wins ? ex : ey;
-        const float rho2 = num * hw_rcp(den) * (0.25f * nf * nf);
-        // clamp(0.5 log2(rho2), 0, levels - 1); rho2 <= 1 (or 0, or NaN) => lambda = 0: the lower clamp as a max in front of the logarithm
-        lambda = fminf(0.5f * __builtin_amdgcn_logf(fmaxf(rho2, 1.0f)), (float)(rc.cube_levels - 1));  // v_log_f32 = log2
-    }
+// lambda from rho^2 = max over the partners, then the two nearest levels (cube_sample_lod_fast / _quad)
+__device__ __forceinline__ float cube_lod_finish(const RenderConsts &rc, float fid, float qs, float qt, float rho2, const f32x4 *lvl) {
+    // clamp(0.5 log2(rho2), 0, levels - 1); rho2 <= 1 (or 0, or NaN) => lambda = 0: the lower clamp as a max in front of the logarithm (the same bits
+    // as `rho2 > 0 ? 0.5 log2(rho2) : 0` clamped: log2(1) = 0, and v_max returns the other operand for a NaN)
+    const float lambda = fminf(0.5f * __builtin_amdgcn_logf(fmaxf(rho2, 1.0f)), (float)(rc.cube_levels - 1));  // v_log_f32 = log2
     const float lf = floorf(lambda), fr = lambda - lf;
     const int lo = (int)lf;
     const float q1s = qs + 1.0f, q1t = qt + 1.0f;
@@ -714,12 +706,13 @@ __device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3
     cube_exact_quotients(sc, tc, ma, qs, qt);
     const bool isz = fid >= 4.0f, isy = !isz && fid >= 2.0f, pos = ma2x >= 0.0f;
     const CubeFaceFrame ff = cube_face_frame(isz, isy, pos);  // only the quads that straddle a cube edge use it
-    float nx, ex, ny, ey;
-    cube_lod_partner_coords(ff, fid, sc, tc, qs, qt, ma, d, vx, __builtin_amdgcn_cubeid(dx.x, dx.y, dx.z), __builtin_amdgcn_cubesc(dx.x, dx.y, dx.z),
-                            __builtin_amdgcn_cubetc(dx.x, dx.y, dx.z), __builtin_amdgcn_cubema(dx.x, dx.y, dx.z), nx, ex);
-    cube_lod_partner_coords(ff, fid, sc, tc, qs, qt, ma, d, vy, __builtin_amdgcn_cubeid(dy.x, dy.y, dy.z), __builtin_amdgcn_cubesc(dy.x, dy.y, dy.z),
-                            __builtin_amdgcn_cubetc(dy.x, dy.y, dy.z), __builtin_amdgcn_cubema(dy.x, dy.y, dy.z), ny, ey);
-    return cube_lod_finish(rc, fid, qs, qt, nx, ex, ny, ey, lvl);
+    const float nf = (float)rc.cube_n, n2 = nf * nf;
+    float rho2 = 0.0f;
+    rho2 = cube_lod_partner_coords(ff, fid, sc, tc, ma, d, vx, __builtin_amdgcn_cubeid(dx.x, dx.y, dx.z), __builtin_amdgcn_cubesc(dx.x, dx.y, dx.z),
+                                   __builtin_amdgcn_cubetc(dx.x, dx.y, dx.z), __builtin_amdgcn_cubema(dx.x, dx.y, dx.z), n2, rho2);
+    rho2 = cube_lod_partner_coords(ff, fid, sc, tc, ma, d, vy, __builtin_amdgcn_cubeid(dy.x, dy.y, dy.z), __builtin_amdgcn_cubesc(dy.x, dy.y, dy.z),
+                                   __builtin_amdgcn_cubetc(dy.x, dy.y, dy.z), __builtin_amdgcn_cubema(dy.x, dy.y, dy.z), n2, rho2);
+    return cube_lod_finish(rc, fid, qs, qt, rho2, lvl);
 }
 // lock-step form: own and partners' cube coordinates come out of the whole-quad exchange
 __device__ __forceinline__ float cube_sample_lod_quad(const RenderConsts &rc, float px, float py, float pz, const QuadNb *nb) {
@@ -734,10 +727,11 @@ __device__ __forceinline__ float cube_sample_lod_quad(const RenderConsts &rc, fl
     cube_exact_quotients(sc, tc, ma, qs, qt);
     const bool isz = fid >= 4.0f, isy = !isz && fid >= 2.0f, pos = ma2x >= 0.0f;
     const CubeFaceFrame ff = cube_face_frame(isz, isy, pos);  // only the quads that straddle a cube edge use it
-    float nx, ex, ny, ey;
-    cube_lod_partner_coords(ff, fid, sc, tc, qs, qt, ma, d, nb->vx, q.fidx, q.scx, q.tcx, q.masx, nx, ex);
-    cube_lod_partner_coords(ff, fid, sc, tc, qs, qt, ma, d, nb->vy, q.fidy, q.scy, q.tcy, q.masy, ny, ey);
-    return cube_lod_finish(rc, fid, qs, qt, nx, ex, ny, ey, nb->lvl);
+    const float nf = (float)rc.cube_n, n2 = nf * nf;
+    float rho2 = 0.0f;
+    rho2 = cube_lod_partner_coords(ff, fid, sc, tc, ma, d, nb->vx, q.fidx, q.scx, q.tcx, q.masx, n2, rho2);
+    rho2 = cube_lod_partner_coords(ff, fid, sc, tc, ma, d, nb->vy, q.fidy, q.scy, q.tcy, q.masy, n2, rho2);
+    return cube_lod_finish(rc, fid, qs, qt, rho2, nb->lvl);
 }
 
 // The direct light march of one view sample (ATMO_LIGHT_DIRECT; SURVEY.md 8d "N view x M light steps"): the quantity the LUT
