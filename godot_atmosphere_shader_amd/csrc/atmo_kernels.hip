@@ -645,10 +645,14 @@ __device__ __forceinline__ V3 cube_dir_from_coords(float fid, float sc, float tc
 // the differences of the coordinates ARE the face frame applied to the rounded difference of the directions, bit for bit: sc and tc are
 // signed copies of one component each (so scp - sc = +-(q.c - d.c), the same rounding), and 0.5 |v_cubema| is the major component with
 // the face's sign on both.
-__device__ __forceinline__ float cube_lod_partner_coords(const CubeFaceFrame &f, float fid, float sc, float tc, float ma, V3 d, bool valid, float fidp,
+__device__ __forceinline__ float cube_lod_partner_coords(float fid, float sc, float tc, float ma2x, float ma, V3 d, bool valid, float fidp,
                                                          float scp, float tcp, float masp, float n2, float rho2) {
     float dsc = scp - sc, dtc = tcp - tc, dma = 0.5f * fabsf(masp) - ma;
     if (valid && fidp != fid) {
+        // (the face frame is built HERE, inside the branch only the quads across a cube edge take: computed in front of it, its dozen compares
+        //  and selects ran for every sample)
+        const bool isz = fid >= 4.0f, isy = !isz && fid >= 2.0f, pos = ma2x >= 0.0f;
+        const CubeFaceFrame f = cube_face_frame(isz, isy, pos);
         const V3 q = cube_dir_from_coords(fidp, scp, tcp, masp);
         const V3 dv = {q.x - d.x, q.y - d.y, q.z - d.z};
         dsc = f.a1 * dv.x + f.a2 * dv.z;
@@ -704,13 +708,11 @@ __device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3
     const float ma = 0.5f * fabsf(ma2x);
     float qs, qt;
     cube_exact_quotients(sc, tc, ma, qs, qt);
-    const bool isz = fid >= 4.0f, isy = !isz && fid >= 2.0f, pos = ma2x >= 0.0f;
-    const CubeFaceFrame ff = cube_face_frame(isz, isy, pos);  // only the quads that straddle a cube edge use it
     const float nf = (float)rc.cube_n, n2 = nf * nf;
     float rho2 = 0.0f;
-    rho2 = cube_lod_partner_coords(ff, fid, sc, tc, ma, d, vx, __builtin_amdgcn_cubeid(dx.x, dx.y, dx.z), __builtin_amdgcn_cubesc(dx.x, dx.y, dx.z),
+    rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, vx, __builtin_amdgcn_cubeid(dx.x, dx.y, dx.z), __builtin_amdgcn_cubesc(dx.x, dx.y, dx.z),
                                    __builtin_amdgcn_cubetc(dx.x, dx.y, dx.z), __builtin_amdgcn_cubema(dx.x, dx.y, dx.z), n2, rho2);
-    rho2 = cube_lod_partner_coords(ff, fid, sc, tc, ma, d, vy, __builtin_amdgcn_cubeid(dy.x, dy.y, dy.z), __builtin_amdgcn_cubesc(dy.x, dy.y, dy.z),
+    rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, vy, __builtin_amdgcn_cubeid(dy.x, dy.y, dy.z), __builtin_amdgcn_cubesc(dy.x, dy.y, dy.z),
                                    __builtin_amdgcn_cubetc(dy.x, dy.y, dy.z), __builtin_amdgcn_cubema(dy.x, dy.y, dy.z), n2, rho2);
     return cube_lod_finish(rc, fid, qs, qt, rho2, lvl);
 }
@@ -725,12 +727,10 @@ __device__ __forceinline__ float cube_sample_lod_quad(const RenderConsts &rc, fl
     const float ma = 0.5f * fabsf(ma2x);
     float qs, qt;
     cube_exact_quotients(sc, tc, ma, qs, qt);
-    const bool isz = fid >= 4.0f, isy = !isz && fid >= 2.0f, pos = ma2x >= 0.0f;
-    const CubeFaceFrame ff = cube_face_frame(isz, isy, pos);  // only the quads that straddle a cube edge use it
     const float nf = (float)rc.cube_n, n2 = nf * nf;
     float rho2 = 0.0f;
-    rho2 = cube_lod_partner_coords(ff, fid, sc, tc, ma, d, nb->vx, q.fidx, q.scx, q.tcx, q.masx, n2, rho2);
-    rho2 = cube_lod_partner_coords(ff, fid, sc, tc, ma, d, nb->vy, q.fidy, q.scy, q.tcy, q.masy, n2, rho2);
+    rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, nb->vx, q.fidx, q.scx, q.tcx, q.masx, n2, rho2);
+    rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, nb->vy, q.fidy, q.scy, q.tcy, q.masy, n2, rho2);
     return cube_lod_finish(rc, fid, qs, qt, rho2, nb->lvl);
 }
 
