@@ -502,9 +502,8 @@ def test_texture_update_waits_for_draws_on_every_other_stream():
 def test_tile_list_draws_partition_the_frame():
     """atmo_render_tiles (BASELINE north_star: "independent framebuffer tiles shard across the GPUs"): the tiles of the frame dealt to N ranks
     (sharding.lpt_strips on measured costs), every rank's list drawn by itself into a poisoned full-frame buffer, and the strips put
-    together equal atmo_render's frame bit for bit -- no-cloud, clouds under both samplers (the declared sampler's quad partners across a
-    strip border are helper lanes... of the SAME draw only when the partner tile is in the list: strips are 16 rows, tiles 8, quads 2:
-    a quad never straddles a strip), raymarched light, a rect with an odd origin."""
+    together equal atmo_render's frame bit for bit -- no-cloud, clouds under both samplers (the declared sampler's 2 x 2 quads never straddle
+    a tile, so a tile-list draw needs nothing from tiles that are not in its list), raymarched light, rects with even and odd origins."""
     import torch
     from godot_atmosphere_shader_amd.sharding import STRIP_TILE_ROWS, lpt_strips
 
@@ -512,14 +511,20 @@ def test_tile_list_draws_partition_the_frame():
     for config_name, kw, pose, (w, h), rect in (("no_clouds_32x8_direct", {}, "P_space", (320, 180), None),
                                                 ("clouds_high", dict(cubemap_lod=None), "P_clouds", (304, 171), None),
                                                 ("clouds_high_rm", dict(cubemap_lod=None), "P_space", (320, 180), None),
-                                                ("clouds_high_rm", {}, "P_limb", (320, 180), (16, 32, 303, 163))):
+                                                ("clouds_high_rm", {}, "P_limb", (320, 180), (16, 32, 303, 163)),
+                                                # declared sampler + a rect with an ODD origin: the launch grid starts on the even pixel in front
+                                                # of it (helper lanes), so tile rows sit one pixel row higher in the output
+                                                ("clouds_high", dict(cubemap_lod=None), "P_limb", (320, 180), (5, 3, 301, 170))):
         cam = S.Camera.from_pose(w, h, pose)
         depth_np = S.depth_ground_sphere(cam)
         depth = torch.from_numpy(depth_np).cuda()
         node = make_node(config_name, tex, params, **kw)
         want = _gpu_render(node, cam, depth_np, rect=rect)
         cost, tw, th = node.measure_tile_costs(cam, depth, rect=rect)
-        assert (tw, th) == (16, 8) and cost.shape == ((want.shape[0] + th - 1) // th, (want.shape[1] + tw - 1) // tw)
+        declared = kw.get("cubemap_lod", False) is None
+        x0, y0 = (rect[0], rect[1]) if rect else (0, 0)
+        gx0, gy0 = (x0 & ~1, y0 & ~1) if declared else (x0, y0)   # the grid's first pixel
+        assert (tw, th) == (16, 8) and cost.shape == ((y0 + want.shape[0] - gy0 + th - 1) // th, (x0 + want.shape[1] - gx0 + tw - 1) // tw)
         frame = node.prepare_frame(cam, rect=rect)
         stream = torch.cuda.current_stream().cuda_stream
         for world in (1, 3):
@@ -532,8 +537,8 @@ def test_tile_list_draws_partition_the_frame():
                 torch.cuda.synchronize()
                 o = out.cpu().numpy()
                 mine = np.zeros(want.shape[0], dtype=bool)
-                for k in strips[r]:
-                    mine[k * STRIP_TILE_ROWS * th:(k + 1) * STRIP_TILE_ROWS * th] = True
+                for k in strips[r]:   # output rows of strip k: frame rows gy0 + 16 k .., minus the rect's first row
+                    mine[max(0, gy0 - y0 + k * STRIP_TILE_ROWS * th):max(0, gy0 - y0 + (k + 1) * STRIP_TILE_ROWS * th)] = True
                 assert np.all(o[~mine] == 77.5), (config_name, world, r)          # nothing outside its strips is touched
                 got[mine] = o[mine]
             assert np.array_equal(got, want), (config_name, world)
