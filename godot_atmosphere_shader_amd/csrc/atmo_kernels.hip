@@ -578,7 +578,8 @@ __device__ __forceinline__ float cube_sample_lod(const RenderConsts &rc, V3 d, b
 //   words before level l = 6 sum_{k<l} (n_k + 1)^2 = 8 n^2 - 8 nl^2 + 24 n - 24 nl + 6 l.
 // Entry l = {hn = nl / 2, s4 = 4 nl + 4 (bytes per footprint row), F = s4 (nl + 1) (bytes per face), G = 4 words_before(l) + s4 + 4
 // (byte offset of the footprint of texel (0, 0) on face 0)}; every entry and every partial sum below is a multiple of 4 below 2^26
-// (33.6 MB for the whole chain at n = 1024), i.e. exact in fp32.  Each wave fills the table itself before it reads it (identical
+// (33.6 MB for the whole chain at n = 1024), i.e. exact in fp32.  For the float copy of the chain (rc.cube_f4: 16-byte footprints)
+// s4, F and G are stored times four -- multiples of 16 below 2^28, as exact.  Each wave fills the table itself before it reads it (identical
 // values from both waves of a workgroup: no barrier).
 constexpr int CUBE_LEVEL_TABLE = 16;
 __device__ __forceinline__ void cube_level_table_fill(const RenderConsts &rc, f32x4 *lvl, int lane) {
@@ -588,7 +589,8 @@ __device__ __forceinline__ void cube_level_table_fill(const RenderConsts &rc, f3
         const float s4 = 4.0f * nl + 4.0f;
         const float c0 = __builtin_fmaf(32.0f * nf, nf, 96.0f * nf);
         const float base = __builtin_fmaf(-32.0f * nl, nl, __builtin_fmaf(-96.0f, nl, __builtin_fmaf(24.0f, l, c0)));
-        lvl[lane] = f32x4{0.5f * nl, s4, s4 * (nl + 1.0f), base + s4 + 4.0f};
+        const float u = rc.cube_f4 != nullptr ? 4.0f : 1.0f;  // the float copy of the chain: 16-byte footprints at four times the offsets
+        lvl[lane] = f32x4{0.5f * nl, u * s4, u * (s4 * (nl + 1.0f)), u * (base + s4 + 4.0f)};
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 }
@@ -599,10 +601,10 @@ __device__ __forceinline__ float cube_level_sample_fast(__amdgpu_buffer_rsrc_t r
     const float fx = x - xf, fy = y - yf;
     const float nm1 = __builtin_fmaf(hn, 2.0f, -1.0f);
     const float ic = __builtin_amdgcn_fmed3f(xf, -1.0f, nm1), jc = __builtin_amdgcn_fmed3f(yf, -1.0f, nm1);
-    const float off = __builtin_fmaf(fid, k.z, __builtin_fmaf(jc, s4, __builtin_fmaf(ic, 4.0f, k.w)));
+    const float off = __builtin_fmaf(fid, k.z, __builtin_fmaf(jc, s4, __builtin_fmaf(ic, f4 ? 16.0f : 4.0f, k.w)));
     f32x4 t;
-    if (f4) {  // `rs` is the chain's float copy: 16-byte footprints at four times the offset (a multiple of 16 below 2^28: exact in fp32)
-        t = buf_f32x4(rs, (uint32_t)(off * 4.0f));
+    if (f4) {  // `rs` is the chain's float copy: the table holds its strides (multiples of 16 below 2^28: exact in fp32)
+        t = buf_f32x4(rs, (uint32_t)off);
     } else {
         const uint32_t w = buf_u32(rs, (uint32_t)off);
         t = f32x4{unorm8_exact(ub0(w)), unorm8_exact(ub1(w)), unorm8_exact(ub2(w)), unorm8_exact(ub3(w))};
