@@ -164,6 +164,7 @@ struct AtmoContext {
     float env_reach_scale = 1.0f;                      // ATMO_FB_REACH_SCALE: multiplies the predicted reach (A/B)
     unsigned moving_period = 2;                        // ATMO_FB_MOVING_PERIOD: recording period while the camera moves
     int f4_footprints = 3;                             // ATMO_F4=0..3 (A/B): bit 0 = float copy of the cubemap footprints, bit 1 = of the shape volume's
+    int env_lod0_cert = 1;                             // ATMO_LOD0_CERT=0 (A/B): the declared sampler's level-0 certificate off
     int instream = 1;                                  // ATMO_FB_INSTREAM=0: never sort on the draw stream (A/B)
     uint32_t *measure_cost = nullptr;                  // atmo_measure_tile_costs: the next draw records here
     // the streams draws of this context have been enqueued on since the last texture update waited for them: an update arriving on
@@ -363,6 +364,23 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
     rc.cube_f4 = (ctx->f4_footprints & 1) ? (const float *)ctx->cube_f4.ptr : nullptr;
     rc.shape_f4 = (ctx->f4_footprints & 2) ? (const float *)ctx->shape_f4.ptr : nullptr;
     rc.cube_lod_fast = (ctx->cube_n >= 1 && ctx->cube_n <= 1024 && (ctx->cube_n & (ctx->cube_n - 1)) == 0) ? 1 : 0;
+    {   // the level-0 certificate of the declared sampler (atmo_kernels.hip: cube_lod_level0_certain):  w E <= lod0_c ma^2  =>  lambda = 0.
+        //   lod0_c = 0.9 * 4 (1 - 2/n)^2 / (n^2 sigma^2),  sigma = 1.002 >= the coverage rotation's largest singular value: the certificate is
+        // only offered when u_cloud_coverage_rotation is a rotation to 1e-3 (the node builds it from one angle; any other mat2 renders through
+        // the full derivative path).  The 0.9 -- 5 % of the distance threshold, >= 5.6e-5 ma at n = 1024 -- pays for what the kernel's E
+        // leaves out: the rounding of the tap offsets and of the rotation, <= 8 ulp(|p|) = 1.6e-6 ma (the march's drift is in E itself).
+        rc.lod0_c = -1.0f;
+        rc.lod0_last = (float)(rc.cloud_steps - 1);
+        rc.lod0_drift = (float)((rc.cloud_steps + 1) * 2.07e-7);
+        const double n = (double)ctx->cube_n;
+        const double a = rc.cov_rot[0], b = rc.cov_rot[2], c = rc.cov_rot[1], d = rc.cov_rot[3];  // column-major: rows (a b), (c d)
+        const double fro = a * a + b * b + c * c + d * d, det = a * d - b * c;
+        if (rc.cube_lod_fast && ctx->cube_n >= 4 && std::fabs(fro - 2.0) <= 2e-3 && std::fabs(std::fabs(det) - 1.0) <= 1e-3) {
+            const double sigma = 1.002;
+            rc.lod0_c = (float)(0.9 * 4.0 * (1.0 - 2.0 / n) * (1.0 - 2.0 / n) / (n * n * sigma * sigma));
+        }
+        if (ctx->env_lod0_cert == 0) rc.lod0_c = -1.0f;  // ATMO_LOD0_CERT=0 (A/B): every sample takes the derivative path
+    }
     {   // sure-miss test (shade_pixel): usable when the view-ray direction does not depend on the depth sample (x, y, z rows of
         // inv_projection have no depth column: every perspective and orthographic-free Godot camera) and the camera is well
         // outside the shell, so that the 0.2 % margin dwarfs fp32 rounding of h = R^2 - |c|^2 + (c.d)^2 (a few 1e-7 |c|^2)
@@ -636,6 +654,7 @@ int atmo_create(int device, int variant, int view_steps, int cloud_steps, int li
     if (const char *ev = std::getenv("ATMO_LANE_SPLIT")) ctx->env_split = ev[0] == '1' ? 1 : (ev[0] == '2' ? 2 : 0);
     if (const char *ev = std::getenv("ATMO_TILE_FEEDBACK")) ctx->env_feedback = ev[0] == '1' ? 1 : 0;
     if (const char *ev = std::getenv("ATMO_F4")) ctx->f4_footprints = std::atoi(ev) & 3;
+    if (const char *ev = std::getenv("ATMO_LOD0_CERT")) ctx->env_lod0_cert = ev[0] == '0' ? 0 : 1;
     if (const char *ev = std::getenv("ATMO_TARGET_CLEARED")) ctx->target_cleared = ev[0] == '1' ? 1 : 0;  // tools/ab_env.sh: atmo_set_target_cleared
     if (const char *ev = std::getenv("ATMO_FB_INSTREAM")) ctx->instream = ev[0] == '1' ? 1 : 0;
     if (const char *ev = std::getenv("ATMO_FB_REACH_SCALE")) ctx->env_reach_scale = (float)std::atof(ev);

@@ -501,7 +501,9 @@ __device__ __forceinline__ void quad_exchange_positions(float px, float py, floa
 // What a texture() call of the declared sampler needs to know about the pixel's two 2x2-quad partners; valid = the partner reaches the call.
 struct QuadNb {
     bool vx, vy;
-    V3 px, py;         // position form (light taps of a queued sample): the horizontal / vertical partner's sample position (model space)
+    V3 px, py;         // position form (light taps of a queued sample): the horizontal / vertical partner's sample position (model space) ...
+    V3 k;              // ... and the tap's offset from it (the partners evaluate the same tap from their own sample)
+    float e2;          // >= |partner's position - this lane's|^2 for both partners that reach the call (cube_lod_level0_certain)
     const f32x4 *lvl;  // LDS: per mip level {0.5 n_l, 4 n_l + 4, 4 (n_l + 1)^2, byte offset of footprint (0, 0) of face 0} (cube_level_table)
     QuadRegs *regs;    // lock-step form (the march): the whole-quad exchange registers
 };
@@ -679,6 +681,16 @@ __device__ __forceinline__ float cube_lod_finish(const RenderConsts &rc, float f
     // clamp(0.5 log2(rho2), 0, levels - 1); rho2 <= 1 (or 0, or NaN) => lambda = 0: the lower clamp as a max in front of the logarithm (the same bits
     // as `rho2 > 0 ? 0.5 log2(rho2) : 0` clamped: log2(1) = 0, and v_max returns the other operand for a NaN)
     const float lambda = fminf(0.5f * __builtin_amdgcn_logf(fmaxf(rho2, 1.0f)), (float)(rc.cube_levels - 1));  // v_log_f32 = log2
+#if defined(ATMO_WAVE_TRACE) && ATMO_RMQ_STATS  // diagnostic build: how many samples select level 0 alone (words 40..42 of the statistics block)
+    if (rc.wave_trace != nullptr) {
+        unsigned long long *st_ = rc.wave_trace + 16ull * gridDim.x * gridDim.y - 64 + 40;
+        const unsigned long long m_ = __builtin_amdgcn_ballot_w64(true), z_ = __builtin_amdgcn_ballot_w64(!(rho2 > 1.0f));
+        if ((int)(threadIdx.x & 63) == __builtin_ffsll((long long)m_) - 1) {
+            atomicAdd(st_, (unsigned long long)__builtin_popcountll(m_)); atomicAdd(st_ + 1, (unsigned long long)__builtin_popcountll(z_));
+            atomicAdd(st_ + 2, 1ull); atomicAdd(st_ + 3, z_ == m_ ? 1ull : 0ull);
+        }
+    }
+#endif
     const float lf = floorf(lambda), fr = lambda - lf;
     const int lo = (int)lf;
     const float q1s = qs + 1.0f, q1t = qt + 1.0f;
@@ -699,10 +711,62 @@ __device__ __forceinline__ void cube_exact_quotients(float sc, float tc, float m
     qt = __builtin_fmaf(__builtin_fmaf(-qt, ma, tc), r, qt);
 }
 
-// position form: the partners' (rotated) sample positions are given (the light taps of a queued sample).  Their cube coordinates come from
-// the hardware cube instructions as well (4 instructions instead of the face frame applied to a difference: 13), and
+// ---- the level-0 certificate (round 4) ---------------------------------------------------------------------------------------------
+// In the scenes this path renders the coverage cubemap is MAGNIFIED almost everywhere (256^2 faces wrapped around a planet that fills a
+// 1080p frame: 0.4 texels per pixel at the disc's centre; lambda = 0 for 97.2 % of the coverage samples of clouds_high(_rm) at 1920x1080,
+// 99.8 % at 3840x2160, 100 % from the ground: profiles/round4/lod0_certificate.txt) -- and there the derivative machinery (two partners'
+// coordinates, two rho^2, a logarithm) computes a zero.  A sample whose partners are provably within a texel takes level 0 without it.
+//   With d = (dsc, dtc, dma) the partner's coordinate differences on the lane's face (cube_lod_partner_coords: a signed permutation of the
+//   rounded difference of the two directions, on the lane's own face and across a cube edge alike), s = sc / ma, t = tc / ma, ma' = ma + dma:
+//     s' - s = (dsc - s dma) / (2 ma'),   so   rho^2 = n^2 ((dsc - s dma)^2 + (dtc - t dma)^2) / (4 ma'^2)
+//            <= n^2 (1 + s^2 + t^2) |d|^2 / (4 ma'^2)                 (triangle inequality, then Cauchy-Schwarz on |(dsc, dtc)| + |(s, t)| |dma|)
+//   and ma' >= ma - |d|.  If  w E <= C ma^2  with w = 1 + s^2 + t^2, E >= |d|^2 and C = 0.9 * 4 (1 - 2/n)^2 / (n sigma)^2 (host: lod0_c), then
+//   |d| <= 2 ma / n, ma' >= (1 - 2/n) ma and rho^2 <= 0.9 for either partner: max(rho^2, 1) = 1, lambda = 0, frac = 0 -- the sample IS level 0's
+//   bilinear tap, bit for bit what the full path returns.  E is taken between the UNROTATED positions (sigma bounds the rotation); the few ulp
+//   the rotation's and the tap offsets' roundings add to |d|, and the 1e-6 relative error of the kernel's own rho^2, are inside the 0.9.
+// A partner that does not reach the call, or lies beyond the face's half space, contributes nothing to rho^2: leaving it out of E, or in, is
+// safe.  NaN or infinite operands fail the comparison and take the full path; ma > 1e-15 keeps C ma^2 a normal number.
+__device__ __forceinline__ bool cube_lod_level0_certain(const RenderConsts &rc, float qs, float qt, float ma, float e2) {
+    const float w = __builtin_fmaf(qs, qs, __builtin_fmaf(qt, qt, 1.0f));
+    const bool certain = w * e2 <= rc.lod0_c * (ma * ma) && ma > 1e-15f;
+#if defined(ATMO_WAVE_TRACE) && ATMO_RMQ_STATS  // diagnostic build: how many samples carry the certificate (words 44..47 of the statistics block)
+    if (rc.wave_trace != nullptr) {
+        unsigned long long *st_ = rc.wave_trace + 16ull * gridDim.x * gridDim.y - 64 + 44;
+        const unsigned long long m_ = __builtin_amdgcn_ballot_w64(true), z_ = __builtin_amdgcn_ballot_w64(certain);
+        if ((int)(threadIdx.x & 63) == __builtin_ffsll((long long)m_) - 1) {
+            atomicAdd(st_, (unsigned long long)__builtin_popcountll(m_)); atomicAdd(st_ + 1, (unsigned long long)__builtin_popcountll(z_));
+            atomicAdd(st_ + 2, 1ull); atomicAdd(st_ + 3, z_ == m_ ? 1ull : 0ull);
+        }
+    }
+#endif
+    return certain;
+}
+template <int CTRL>
+__device__ __forceinline__ float quad_read(float x) {  // v_mov_b32_dpp quad_perm: 0xB1 = [1,0,3,2] (lane ^ 1), 0x4E = [2,3,0,1] (lane ^ 2)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+// E for a whole cloud march (lock-step form), once per ray where every marching lane is active: the two lanes' sample positions at step k
+// are affine in k up to the drift of the rounded position chain (one rounded addition per step and component: <= k ulp(|p|) / 2 per lane), and
+// the norm of an affine function is convex -- its maximum over the march is at the first or the last sample.
+__device__ __forceinline__ float quad_march_spread2(const RenderConsts &rc, float px, float py, float pz, float ddx, float ddy, float ddz, bool vx, bool vy) {
+    const float last = rc.lod0_last;
+    const float lx = __builtin_fmaf(last, ddx, px), ly = __builtin_fmaf(last, ddy, py), lz = __builtin_fmaf(last, ddz, pz);
+    auto norm2 = [](float a, float b, float c) { return __builtin_fmaf(a, a, __builtin_fmaf(b, b, c * c)); };
+    const float ex = fmaxf(norm2(quad_read<0xB1>(px) - px, quad_read<0xB1>(py) - py, quad_read<0xB1>(pz) - pz),
+                           norm2(quad_read<0xB1>(lx) - lx, quad_read<0xB1>(ly) - ly, quad_read<0xB1>(lz) - lz));
+    const float ey = fmaxf(norm2(quad_read<0x4E>(px) - px, quad_read<0x4E>(py) - py, quad_read<0x4E>(pz) - pz),
+                           norm2(quad_read<0x4E>(lx) - lx, quad_read<0x4E>(ly) - ly, quad_read<0x4E>(lz) - lz));
+    const float e = hw_sqrt(fmaxf(vx ? ex : 0.0f, vy ? ey : 0.0f));                          // (v_sqrt_f32: 1 ulp, inside the 1.001 below)
+    const float pmax = hw_sqrt(fmaxf(norm2(px, py, pz), norm2(lx, ly, lz))) + e;              // either lane, any step
+    // drift: sqrt(3) components x (k/2 + k/2) ulp, ulp(|p|) <= 2^-23 |p|, k <= steps (one more for the rounding of `l`); 1.001: this function's own rounding
+    const float r = (e + rc.lod0_drift * pmax) * 1.001f;
+    return r * r;
+}
+
+// position form (the light taps of a queued sample): the partners' sample positions and the tap offset are given.  Their cube coordinates come
+// from the hardware cube instructions as well (4 instructions instead of the face frame applied to a difference: 13), and
 // cube_lod_partner_coords takes it from there -- the same bits as the frame form on the lane's own face, the frame form itself elsewhere.
-__device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3 d, bool vx, V3 dx, bool vy, V3 dy, const f32x4 *lvl) {
+__device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3 d, const QuadNb *nb) {
     const float fid = __builtin_amdgcn_cubeid(d.x, d.y, d.z);
     const float sc = __builtin_amdgcn_cubesc(d.x, d.y, d.z);
     const float tc = __builtin_amdgcn_cubetc(d.x, d.y, d.z);
@@ -710,29 +774,43 @@ __device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3
     const float ma = 0.5f * fabsf(ma2x);
     float qs, qt;
     cube_exact_quotients(sc, tc, ma, qs, qt);
-    const float nf = (float)rc.cube_n, n2 = nf * nf;
     float rho2 = 0.0f;
-    rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, vx, __builtin_amdgcn_cubeid(dx.x, dx.y, dx.z), __builtin_amdgcn_cubesc(dx.x, dx.y, dx.z),
-                                   __builtin_amdgcn_cubetc(dx.x, dx.y, dx.z), __builtin_amdgcn_cubema(dx.x, dx.y, dx.z), n2, rho2);
-    rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, vy, __builtin_amdgcn_cubeid(dy.x, dy.y, dy.z), __builtin_amdgcn_cubesc(dy.x, dy.y, dy.z),
-                                   __builtin_amdgcn_cubetc(dy.x, dy.y, dy.z), __builtin_amdgcn_cubema(dy.x, dy.y, dy.z), n2, rho2);
-    return cube_lod_finish(rc, fid, qs, qt, rho2, lvl);
+    if (!cube_lod_level0_certain(rc, qs, qt, ma, nb->e2)) {
+        auto at = [&](V3 p) {  // the partner's tap position, rotated like the lane's own (cloud_funcs.gdshaderinc:43)
+            const float x = p.x + nb->k.x, y = p.y + nb->k.y, z = p.z + nb->k.z;
+            return V3{rc.cov_rot[0] * x + rc.cov_rot[2] * z, y, rc.cov_rot[1] * x + rc.cov_rot[3] * z};
+        };
+        const V3 dx = at(nb->px), dy = at(nb->py);
+        const float nf = (float)rc.cube_n, n2 = nf * nf;
+        rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, nb->vx, __builtin_amdgcn_cubeid(dx.x, dx.y, dx.z), __builtin_amdgcn_cubesc(dx.x, dx.y, dx.z),
+                                       __builtin_amdgcn_cubetc(dx.x, dx.y, dx.z), __builtin_amdgcn_cubema(dx.x, dx.y, dx.z), n2, rho2);
+        rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, nb->vy, __builtin_amdgcn_cubeid(dy.x, dy.y, dy.z), __builtin_amdgcn_cubesc(dy.x, dy.y, dy.z),
+                                       __builtin_amdgcn_cubetc(dy.x, dy.y, dy.z), __builtin_amdgcn_cubema(dy.x, dy.y, dy.z), n2, rho2);
+    }
+    return cube_lod_finish(rc, fid, qs, qt, rho2, nb->lvl);
 }
-// lock-step form: own and partners' cube coordinates come out of the whole-quad exchange
+// lock-step form (the march): the partners' cube coordinates come out of the whole-quad exchange -- which only the lanes without a certificate
+// enter (their quad mates, certain or gone through an early-out, are its helper lanes)
 __device__ __forceinline__ float cube_sample_lod_quad(const RenderConsts &rc, float px, float py, float pz, const QuadNb *nb) {
-    QuadRegs &q = *nb->regs;
-    quad_exchange_coords(px, py, pz, rc.cov_rot[0], rc.cov_rot[1], rc.cov_rot[2], rc.cov_rot[3], q);
-    const float fid = q.fid, sc = q.sc, tc = q.tc, ma2x = q.mas;
-    const V3 d = {q.qx, py, q.qz};
-    if (!rc.cube_lod_fast)  // faces that are not a power of two (or above 1024): the general sampler on the partners' directions
-        return cube_sample_lod(rc, d, nb->vx, cube_dir_from_coords(q.fidx, q.scx, q.tcx, q.masx), nb->vy, cube_dir_from_coords(q.fidy, q.scy, q.tcy, q.masy));
+    const float qx = rc.cov_rot[0] * px + rc.cov_rot[2] * pz, qz = rc.cov_rot[1] * px + rc.cov_rot[3] * pz;
+    const V3 d = {qx, py, qz};
+    const float fid = __builtin_amdgcn_cubeid(qx, py, qz);
+    const float sc = __builtin_amdgcn_cubesc(qx, py, qz);
+    const float tc = __builtin_amdgcn_cubetc(qx, py, qz);
+    const float ma2x = __builtin_amdgcn_cubema(qx, py, qz);
     const float ma = 0.5f * fabsf(ma2x);
     float qs, qt;
     cube_exact_quotients(sc, tc, ma, qs, qt);
-    const float nf = (float)rc.cube_n, n2 = nf * nf;
     float rho2 = 0.0f;
-    rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, nb->vx, q.fidx, q.scx, q.tcx, q.masx, n2, rho2);
-    rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, nb->vy, q.fidy, q.scy, q.tcy, q.masy, n2, rho2);
+    if (!cube_lod_level0_certain(rc, qs, qt, ma, nb->e2)) {   // (never certain when !cube_lod_fast: lod0_c < 0)
+        QuadRegs &q = *nb->regs;
+        quad_exchange_coords(px, py, pz, rc.cov_rot[0], rc.cov_rot[1], rc.cov_rot[2], rc.cov_rot[3], q);  // q.fid, sc, tc, mas, qx, qz: the values above
+        if (!rc.cube_lod_fast)  // faces that are not a power of two (or above 1024): the general sampler on the partners' directions
+            return cube_sample_lod(rc, d, nb->vx, cube_dir_from_coords(q.fidx, q.scx, q.tcx, q.masx), nb->vy, cube_dir_from_coords(q.fidy, q.scy, q.tcy, q.masy));
+        const float nf = (float)rc.cube_n, n2 = nf * nf;
+        rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, nb->vx, q.fidx, q.scx, q.tcx, q.masx, n2, rho2);
+        rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, nb->vy, q.fidy, q.scy, q.tcy, q.masy, n2, rho2);
+    }
     return cube_lod_finish(rc, fid, qs, qt, rho2, nb->lvl);
 }
 
@@ -1120,9 +1198,12 @@ __device__ __forceinline__ float cloud_density_precise(const RenderConsts &rc, f
         const float qx = rc.cov_rot[0] * px + rc.cov_rot[2] * pz;
         const float qz = rc.cov_rot[1] * px + rc.cov_rot[3] * pz;
         if (LOD) {
-            auto rot = [&](V3 q) { return V3{rc.cov_rot[0] * q.x + rc.cov_rot[2] * q.z, q.y, rc.cov_rot[1] * q.x + rc.cov_rot[3] * q.z}; };
-            if (rc.cube_lod_fast) coverage = cube_sample_lod_fast(rc, V3{qx, py, qz}, nb->vx, rot(nb->px), nb->vy, rot(nb->py), nb->lvl);
-            else coverage = cube_sample_lod(rc, V3{qx, py, qz}, nb->vx, rot(nb->px), nb->vy, rot(nb->py));
+            auto at = [&](V3 p) {
+                const float x = p.x + nb->k.x, y = p.y + nb->k.y, z = p.z + nb->k.z;
+                return V3{rc.cov_rot[0] * x + rc.cov_rot[2] * z, y, rc.cov_rot[1] * x + rc.cov_rot[3] * z};
+            };
+            if (rc.cube_lod_fast) coverage = cube_sample_lod_fast(rc, V3{qx, py, qz}, nb);
+            else coverage = cube_sample_lod(rc, V3{qx, py, qz}, nb->vx, at(nb->px), nb->vy, at(nb->py));
         } else {
             coverage = cube_sample<true>(rc.cube, rc.cube_n, qx, py, qz, rc.cube_f4);
         }
@@ -1220,8 +1301,7 @@ __device__ __forceinline__ float light_raymarched(const RenderConsts &rc, float 
         QuadNb tap;
         if (LOD) {  // the quad partners evaluate the same tap from their own sample position
             tap.vx = nb->vx; tap.vy = nb->vy; tap.lvl = nb->lvl; tap.regs = nullptr;
-            tap.px = V3{nb->px.x + kx, nb->px.y + ky, nb->px.z + kz};
-            tap.py = V3{nb->py.x + kx, nb->py.y + ky, nb->py.z + kz};
+            tap.px = nb->px; tap.py = nb->py; tap.k = V3{kx, ky, kz}; tap.e2 = nb->e2;
         }
         const float d = cloud_density<true, PRECISE, LOD>(rc, qx, qy, qz, hr, LOD ? &tap : nullptr DENS_STAT_PASS(1));
         sum = __builtin_fmaf(d, rc.rm_weight[i], sum);  // step_len_i * density_scale  [host]
@@ -1282,6 +1362,7 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
         const int lane = threadIdx.x & 63;
         nb.vx = (marching >> (lane ^ 1)) & 1ull; nb.vy = (marching >> (lane ^ 2)) & 1ull;
         nb.lvl = lvl; nb.regs = qregs;
+        nb.e2 = quad_march_spread2(rc, px, py, pz, ddx, ddy, ddz, nb.vx, nb.vy);
     }
 
     // pow(dot(ray_dir, sun_dir), 16) is constant along the ray; dp <= 0 => 0
@@ -1409,7 +1490,7 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
     const float step_len = self.step_len;
     float px = self.px, py = self.py, pz = self.pz;
     const float ddx = self.ddx, ddy = self.ddy, ddz = self.ddz;
-    const float sx = rc.sun_dir_model[0], sy = rc.sun_dir_model[1], sz = rc.sun_dir_model[2];
+    float sx = rc.sun_dir_model[0], sy = rc.sun_dir_model[1], sz = rc.sun_dir_model[2];
     float total_transmittance = 1.0f, total_light = 0.0f, one_minus_alpha = 1.0f;
     const float scale_step = rc.cloud_density_scale * step_len;
     const float neg_scale_step_log2e = -scale_step * LOG2E;
@@ -1417,6 +1498,8 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
     if (LOD) {  // the partners that march (= reach the texture() calls of this march): the quad mates among the active lanes
         nb.vx = (active >> (lane ^ 1)) & 1ull; nb.vy = (active >> (lane ^ 2)) & 1ull;
         nb.lvl = lvl; nb.regs = qregs;
+        nb.e2 = quad_march_spread2(rc, px, py, pz, ddx, ddy, ddz, nb.vx, nb.vy);
+        asm volatile("" : "+v"(sx), "+v"(sy), "+v"(sz));
     }
 
     auto light_batch = [&](int avail) {  // phase B: lane `rank` lights queue entry qhead + rank
@@ -1432,6 +1515,10 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
                 enb.vx = (sl >> 10) & 1u; enb.vy = (sl >> 11) & 1u; enb.lvl = lvl; enb.regs = nullptr;
                 enb.px = V3{qn[e], qn[RMQ_CAP + e], qn[2 * RMQ_CAP + e]};
                 enb.py = V3{qn[3 * RMQ_CAP + e], qn[4 * RMQ_CAP + e], qn[5 * RMQ_CAP + e]};
+                enb.k = V3{0.0f, 0.0f, 0.0f};
+                // the same three differences at every tap of this sample (the partners add the same offset), up to an ulp of |p| (lod0_c's reserve)
+                auto dist2 = [&](V3 p) { const float a = p.x - ex, b = p.y - ey, c = p.z - ez; return __builtin_fmaf(a, a, __builtin_fmaf(b, b, c * c)); };
+                enb.e2 = fmaxf(enb.vx ? dist2(enb.px) : 0.0f, enb.vy ? dist2(enb.py) : 0.0f) * 1.001f;
                 sl &= 1023u;
             }
             const float light = light_raymarched<PRECISE, LOD>(rc, ex, ey, ez, eh, ed, sx, sy, sz, LOD ? &enb : nullptr);

@@ -1352,6 +1352,60 @@ def test_parity_implicit_cubemap_lod(oracle32, config_name):
     assert changed > 1e-3   # the mode does change the picture at these pixel footprints
 
 
+def test_level0_certificate_never_changes_a_bit(oracle32, monkeypatch):
+    """Round 4: a coverage sample whose quad partners are provably within a texel takes level 0 without the derivative machinery
+    (atmo_kernels.hip: cube_lod_level0_certain).  The certificate is a sufficient condition for lambda = 0, so a frame rendered with it must
+    equal the frame rendered without it (ATMO_LOD0_CERT=0, read at atmo_create) BIT FOR BIT -- at frame sizes where certain and uncertain samples
+    mix inside the waves (the texel footprint crosses one pixel between 1280x720 and 1920x1080 for the demo's 256^2 faces), with a finer cubemap,
+    a rotated coverage map, longer marches, and a coverage matrix that is not a rotation (certificate withheld by the host).  And the mixed
+    frames still agree with the oracle on row bands from limb to limb."""
+    import os
+
+    tex, params = demo_textures(), demo_params()
+    a = 0.7
+    rotated = dict(params, u_cloud_coverage_rotation=(np.cos(a), np.sin(a), -np.sin(a), np.cos(a)))
+    sheared = dict(params, u_cloud_coverage_rotation=(1.0, 0.25, 0.0, 1.0))
+    fine = dict(tex, cubemap=S.make_coverage_cubemap(1024, seed=5))
+    cases = [("clouds_high", tex, params, dict(), "P_space", (1920, 1080)), ("clouds_high_rm", tex, params, dict(), "P_space", (1920, 1080)),
+             ("clouds_high_rm", tex, params, dict(), "P_limb", (1280, 720)), ("clouds_high", tex, params, dict(), "P_clouds", (1280, 720)),
+             ("clouds", tex, rotated, dict(), "P_space", (1600, 900)), ("v1_clouds_high", tex, params, dict(), "P_ground", (960, 540)),
+             ("clouds_high_rm", fine, rotated, dict(), "P_space", (3840, 2160)), ("clouds_high", fine, params, dict(cloud_steps=200), "P_limb", (2560, 1440)),
+             ("clouds_high_rm", tex, sheared, dict(), "P_space", (1280, 720)), ("clouds_high_rm", tex, params, dict(), "P_space", (641, 363))]
+    differs_from_lod0 = 0
+    for config_name, tx, pr, kw, pose, (w, h) in cases:
+        cam = S.Camera.from_pose(w, h, pose)
+        depth = S.depth_ground_sphere(cam)
+        frames = []
+        for cert in ("1", "0"):
+            monkeypatch.setenv("ATMO_LOD0_CERT", cert)
+            node = make_node(config_name, tx, pr, cubemap_lod=True, **kw)
+            monkeypatch.delenv("ATMO_LOD0_CERT")
+            frames.append(_gpu_render(node, cam, depth))
+            node.close()
+        assert np.array_equal(frames[0], frames[1]), (config_name, pose, w, h)
+        base = make_node(config_name, tx, pr, **kw)
+        differs_from_lod0 += int(not np.array_equal(_gpu_render(base, cam, depth), frames[0]))
+        base.close()
+    assert differs_from_lod0 >= 8   # ... while lambda > 0 somewhere in (nearly) every one of these frames
+    # against the oracle where the two kinds of samples mix
+    worst = 0.0
+    for config_name, pose, (w, h) in (("clouds_high_rm", "P_space", (1280, 720)), ("clouds_high", "P_limb", (1600, 900))):
+        cam = S.Camera.from_pose(w, h, pose)
+        depth = S.depth_ground_sphere(cam)
+        node = make_node(config_name, tex, params, cubemap_lod=True)
+        got = _gpu_render(node, cam, depth)
+        lut = node.read_optical_depth()
+        node.close()
+        chain = oracle32.cubemap_mip_chain(tex["cubemap"])
+        for (y0, y1) in _spread_bands(cam, 6, 8):
+            want, _ = oracle32.render(params, dict(tex, cubemap=chain, optical_depth=lut), dict(CONFIGS[config_name][1], cube_lod=1), demo_frame(cam), depth,
+                                      rect=(0, y0, w, y1), nthreads=min(32, os.cpu_count() or 1))
+            assert np.array_equal(np.all(got[y0:y1] == 0.0, axis=-1), np.all(want == 0.0, axis=-1))
+            worst = max(worst, float(np.abs(got[y0:y1] - want).max()))
+    print(f"\nlevel-0 certificate: 10 frame pairs bit-identical; mixed frames vs oracle max |HIP - oracle| = {worst:.3e}")
+    assert worst <= TOL
+
+
 def test_declared_sampler_is_the_default():
     """Round 4: a context samples the coverage cubemap the way the reference declares it (cloud_funcs.gdshaderinc:15,45: linear-mipmap)
     whenever a mip chain is bound -- atmo_set_sampler_lod -1, the default -- bit for bit the frames of mode 1; with the fast cloud mode or a

@@ -445,3 +445,4 @@ def test_whole_quad_exchange_registers_are_private():
     assert p.returncode == 0, p.stdout + p.stderr
     assert len(lines) >= 11 and all(ln.rstrip().endswith("ok") for ln in lines), p.stdout   # every KF_CUBE_LOD instantiation
     assert any("<49, 0, 1>" in ln and " 1 exchange" in ln for ln in lines) and any("<51, 0, 1>" in ln and " 2 exchange" in ln for ln in lines)
+    assert any("0 with a stack frame, 0 scratch instructions" in ln for ln in p.stdout.splitlines()), p.stdout   # and no kernel spills

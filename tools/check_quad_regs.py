@@ -6,6 +6,8 @@ blocks' destination registers.  That is only safe if those registers hold nothin
 the source arranges by making them read-write operands whose live range spans the kernel.  This script verifies it in the ISA hipcc
 emits: in every kernel that contains an exchange block, the VGPRs written inside the blocks are written by NO instruction outside them.
 
+It also verifies that no kernel of the file has a stack frame (ScratchSize 0, no scratch_load / scratch_store).
+
     python tools/check_quad_regs.py [-DFLAG ...]        exit code 0 = every kernel passes; prints one line per kernel
 """
 from __future__ import annotations
@@ -88,6 +90,14 @@ def main(argv):
         ok = ok and not bad and blocks > 0
     if not res:
         print("no kernel contains an exchange block")
+    # and, for every kernel of the file: no stack.  A frame object -- even a dead spill slot of a rematerialised kernel-argument tuple, with no
+    # scratch instruction left in the ISA -- makes the kernel descriptor ask for a private segment (round 4: seven kernels, 36 bytes).
+    text = open(out).read()
+    scratch = re.findall(r"^; ScratchSize: (\d+)", text, re.M)
+    spilled = [m for m in re.finditer(r"^\s*(scratch_(?:load|store)\w*)", text, re.M)]
+    nonzero = [int(x) for x in scratch if int(x)]
+    print(f"{len(scratch)} kernels, {len(nonzero)} with a stack frame" + (f" (bytes: {nonzero})" if nonzero else "") + f", {len(spilled)} scratch instructions")
+    ok = ok and not nonzero and not spilled and len(scratch) > 0
     return 0 if ok else 1
 
 

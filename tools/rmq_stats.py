@@ -48,6 +48,11 @@ def main():
     print(f"  light batches {calls:.0f} ({calls / waves:.1f} per wave); filled {100 * lit / offered:.1f} % of the marching lanes, "
           f"{100 * lit / wave_lanes:.1f} % of the wave's 64 lanes")
     print(f"  time inside phase B (lighting) {100 * ticks_b / ticks_all:.1f} % of the cloud march's wave-time")
+    if st[40]:
+        print(f"  declared sampler: {st[40]:.0f} coverage samples, lambda = 0 (level 0 alone) for {100 * st[41] / st[40]:.1f} % of them; "
+              f"{st[42]:.0f} wave executions, every lane at lambda = 0 in {100 * st[43] / st[42]:.1f} % of them")
+    if st[44]:
+        print(f"  level-0 certificate: held for {100 * st[45] / st[44]:.1f} % of {st[44]:.0f} samples; for every lane in {100 * st[47] / st[46]:.1f} % of {st[46]:.0f} wave executions")
     names = ["entered", "inside the layer (coverage sample)", "past the coverage early-outs (shape sample)"]
     for ph, label in ((0, "march"), (1, "light taps")):
         for stage in range(3):
