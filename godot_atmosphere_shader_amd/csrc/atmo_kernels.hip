@@ -676,12 +676,16 @@ __device__ __forceinline__ float cube_lod_partner_coords(float fid, float sc, fl
     return (valid && ma2 > 0.0f) ? fmaxf(rho2, r2) : rho2;
 }
 
-// lambda from rho^2 = max over the partners, then the two nearest levels (cube_sample_lod_fast / _quad)
-__device__ __forceinline__ float cube_lod_finish(const RenderConsts &rc, float fid, float qs, float qt, float rho2, const f32x4 *lvl) {
+// lambda from rho^2 = max over the partners: the lower level and the weight of the one above it (0: the lower level alone)
+struct CubeLod {
+    int lo;
+    float fr;
+};
+__device__ __forceinline__ CubeLod cube_lod_select(const RenderConsts &rc, float rho2) {
     // clamp(0.5 log2(rho2), 0, levels - 1); rho2 <= 1 (or 0, or NaN) => lambda = 0: the lower clamp as a max in front of the logarithm (the same bits
     // as `rho2 > 0 ? 0.5 log2(rho2) : 0` clamped: log2(1) = 0, and v_max returns the other operand for a NaN)
     const float lambda = fminf(0.5f * __builtin_amdgcn_logf(fmaxf(rho2, 1.0f)), (float)(rc.cube_levels - 1));  // v_log_f32 = log2
-#if defined(ATMO_WAVE_TRACE) && ATMO_RMQ_STATS  // diagnostic build: how many samples select level 0 alone (words 40..42 of the statistics block)
+#if defined(ATMO_WAVE_TRACE) && ATMO_RMQ_STATS  // diagnostic build: how many of these samples select level 0 alone (words 40..43 of the statistics block)
     if (rc.wave_trace != nullptr) {
         unsigned long long *st_ = rc.wave_trace + 16ull * gridDim.x * gridDim.y - 64 + 40;
         const unsigned long long m_ = __builtin_amdgcn_ballot_w64(true), z_ = __builtin_amdgcn_ballot_w64(!(rho2 > 1.0f));
@@ -691,15 +695,21 @@ __device__ __forceinline__ float cube_lod_finish(const RenderConsts &rc, float f
         }
     }
 #endif
-    const float lf = floorf(lambda), fr = lambda - lf;
-    const int lo = (int)lf;
+    const float lf = floorf(lambda);
+    CubeLod l;
+    l.lo = (int)lf;
+    l.fr = lambda - lf;   // 0 on the last level: lambda <= levels - 1 is an integer there
+    return l;
+}
+// the two nearest levels (cube_sample_lod_fast / _quad); a sample with the level-0 certificate arrives with {0, 0}
+__device__ __forceinline__ float cube_lod_finish(const RenderConsts &rc, float fid, float qs, float qt, CubeLod l, const f32x4 *lvl) {
     const float q1s = qs + 1.0f, q1t = qt + 1.0f;
     const bool f4 = rc.cube_f4 != nullptr;  // wave-uniform: the float copy of the chain, or the byte footprints
     const __amdgpu_buffer_rsrc_t rs = f4 ? make_rsrc(rc.cube_f4, rc.cube_bytes * 4u) : make_rsrc(rc.cube, rc.cube_bytes);
-    const float v0 = cube_level_sample_fast(rs, f4, fid, q1s, q1t, lvl[lo]);
-    if (lo + 1 >= rc.cube_levels || fr == 0.0f) return v0;
-    const float v1 = cube_level_sample_fast(rs, f4, fid, q1s, q1t, lvl[lo + 1]);
-    return v0 * (1.0f - fr) + v1 * fr;
+    const float v0 = cube_level_sample_fast(rs, f4, fid, q1s, q1t, lvl[l.lo]);
+    if (l.fr == 0.0f) return v0;
+    const float v1 = cube_level_sample_fast(rs, f4, fid, q1s, q1t, lvl[l.lo + 1]);
+    return v0 * (1.0f - l.fr) + v1 * l.fr;
 }
 // s = sc / ma, t = tc / ma: the IEEE quotients from one v_rcp and two Markstein steps each (as in cube_sample<true>)
 __device__ __forceinline__ void cube_exact_quotients(float sc, float tc, float ma, float &qs, float &qt) {
@@ -774,8 +784,9 @@ __device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3
     const float ma = 0.5f * fabsf(ma2x);
     float qs, qt;
     cube_exact_quotients(sc, tc, ma, qs, qt);
-    float rho2 = 0.0f;
+    CubeLod lod = {0, 0.0f};
     if (!cube_lod_level0_certain(rc, qs, qt, ma, nb->e2)) {
+        float rho2 = 0.0f;
         auto at = [&](V3 p) {  // the partner's tap position, rotated like the lane's own (cloud_funcs.gdshaderinc:43)
             const float x = p.x + nb->k.x, y = p.y + nb->k.y, z = p.z + nb->k.z;
             return V3{rc.cov_rot[0] * x + rc.cov_rot[2] * z, y, rc.cov_rot[1] * x + rc.cov_rot[3] * z};
@@ -786,8 +797,9 @@ __device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3
                                        __builtin_amdgcn_cubetc(dx.x, dx.y, dx.z), __builtin_amdgcn_cubema(dx.x, dx.y, dx.z), n2, rho2);
         rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, nb->vy, __builtin_amdgcn_cubeid(dy.x, dy.y, dy.z), __builtin_amdgcn_cubesc(dy.x, dy.y, dy.z),
                                        __builtin_amdgcn_cubetc(dy.x, dy.y, dy.z), __builtin_amdgcn_cubema(dy.x, dy.y, dy.z), n2, rho2);
+        lod = cube_lod_select(rc, rho2);
     }
-    return cube_lod_finish(rc, fid, qs, qt, rho2, nb->lvl);
+    return cube_lod_finish(rc, fid, qs, qt, lod, nb->lvl);
 }
 // lock-step form (the march): the partners' cube coordinates come out of the whole-quad exchange -- which only the lanes without a certificate
 // enter (their quad mates, certain or gone through an early-out, are its helper lanes)
@@ -801,8 +813,9 @@ __device__ __forceinline__ float cube_sample_lod_quad(const RenderConsts &rc, fl
     const float ma = 0.5f * fabsf(ma2x);
     float qs, qt;
     cube_exact_quotients(sc, tc, ma, qs, qt);
-    float rho2 = 0.0f;
+    CubeLod lod = {0, 0.0f};
     if (!cube_lod_level0_certain(rc, qs, qt, ma, nb->e2)) {   // (never certain when !cube_lod_fast: lod0_c < 0)
+        float rho2 = 0.0f;
         QuadRegs &q = *nb->regs;
         quad_exchange_coords(px, py, pz, rc.cov_rot[0], rc.cov_rot[1], rc.cov_rot[2], rc.cov_rot[3], q);  // q.fid, sc, tc, mas, qx, qz: the values above
         if (!rc.cube_lod_fast)  // faces that are not a power of two (or above 1024): the general sampler on the partners' directions
@@ -810,8 +823,9 @@ __device__ __forceinline__ float cube_sample_lod_quad(const RenderConsts &rc, fl
         const float nf = (float)rc.cube_n, n2 = nf * nf;
         rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, nb->vx, q.fidx, q.scx, q.tcx, q.masx, n2, rho2);
         rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, nb->vy, q.fidy, q.scy, q.tcy, q.masy, n2, rho2);
+        lod = cube_lod_select(rc, rho2);
     }
-    return cube_lod_finish(rc, fid, qs, qt, rho2, nb->lvl);
+    return cube_lod_finish(rc, fid, qs, qt, lod, nb->lvl);
 }
 
 // The direct light march of one view sample (ATMO_LIGHT_DIRECT; SURVEY.md 8d "N view x M light steps"): the quantity the LUT
