@@ -1468,8 +1468,17 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m,
 #endif
 // (Round 3, measured and dropped: summing a half-chunk one half later so that no partial batch is lit at the chunk ends fills the
 // batches to 97 % instead of 93 % -- tools/rmq_stats.py -- and is 0.7-2 % slower: profiles/round3/rmq_stage_stats.txt.)
-constexpr int RMQ_CHUNK = ATMO_RMQ_CHUNK, RMQ_CAP = 128;
-constexpr int rmq_words_per_wave(bool lod) { return (lod ? 12 : 6) * RMQ_CAP + RMQ_CHUNK * 64; }
+// The declared-sampler kernel's entries are twice as long (12 x 128 queue words per wave): with 8 slot rows its workgroup needs 16.9 KB of LDS, 9
+// workgroups = 4.5 waves per SIMD, and since the level-0 certificate (round 4) the kernel is short enough for that to bind (a wave waits 34 % of its
+// cycles, occupancy 51 %: profiles/round4/pmc_clouds_high_rm_3840x2160.json).  5 rows: 15.1 KB, 10 workgroups = the 5 waves its 90 VGPRs allow:
+// -3.5 % at 1920x1080 and 3840x2160, -4.5 % from the ground, +3 % on the tail-bound limb frame; 6 rows (still 9 workgroups) +2 %, 4 rows -3 %, 3 rows
+// -2.5 % (more chunk-end partial batches); the LOD-0 kernel loses 3 % with 4 rows (profiles/round4/lod0_certificate.txt, section 6).
+#ifndef ATMO_RMQ_CHUNK_LOD
+#define ATMO_RMQ_CHUNK_LOD 5
+#endif
+constexpr int RMQ_CAP = 128;
+constexpr int rmq_chunk(bool lod) { return lod ? ATMO_RMQ_CHUNK_LOD : ATMO_RMQ_CHUNK; }
+constexpr int rmq_words_per_wave(bool lod) { return (lod ? 12 : 6) * RMQ_CAP + rmq_chunk(lod) * 64; }
 
 template <bool PRECISE, bool LOD = false>
 __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, V3 dir_m, float t_begin, float t_end, float jitter,
@@ -1542,6 +1551,7 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
         RMQ_STAT_B_END();
     };
 
+    constexpr int RMQ_CHUNK = rmq_chunk(LOD);
     for (int c0 = 0; c0 < steps; c0 += RMQ_CHUNK) {
         const int cn = steps - c0 < RMQ_CHUNK ? steps - c0 : RMQ_CHUNK;
         uint32_t lit_bits = 0;
