@@ -136,6 +136,7 @@ struct AtmoContext {
         AtmoFrame prev_frame;          // the previous draw's camera: screen-space motion estimate
         bool have_prev = false;
         float motion_px = 0.0f;        // pixels per frame the picture's features move (peak-held estimate)
+        float sil_px[2] = {0.0f, 0.0f};  // ... and the planet's silhouette alone, per screen axis (the in-stream sort's dilation window)
         float order_reach_px[2] = {0.0f, 0.0f};  // how far features may have moved for order[k] to stay conservative
         unsigned order_born[2] = {0, 0};         // n of the recording draw order[k] was sorted from
         // in-stream mode (moving camera, long frames): the sort runs on the draw stream right behind every draw, so the
@@ -166,6 +167,7 @@ struct AtmoContext {
     int f4_footprints = 3;                             // ATMO_F4=0..3 (A/B): bit 0 = float copy of the cubemap footprints, bit 1 = of the shape volume's
     int env_lod0_cert = 1;                             // ATMO_LOD0_CERT=0 (A/B): the declared sampler's level-0 certificate off
     int instream = 1;                                  // ATMO_FB_INSTREAM=0: never sort on the draw stream (A/B)
+    int fb_axis_windows = 1;                           // ATMO_FB_AXIS_WINDOWS=0: the in-stream sort dilates by motion_px in both axes, as in round 3 (A/B)
     uint32_t *measure_cost = nullptr;                  // atmo_measure_tile_costs: the next draw records here
     // the streams draws of this context have been enqueued on since the last texture update waited for them: an update arriving on
     // stream s is stream-ordered behind the draws on s and has to wait, on the host, for those on every OTHER stream of this set
@@ -459,7 +461,7 @@ int dev_reserve(AtmoContext *ctx, DeviceBuffer &b, size_t bytes) {
 //               taken with that frame's camera: where the disc sits on the screen and how large it is (all a kernel without
 //               clouds can see of the camera: a march costs the same wherever the sun and the ground features are);
 //   surface:    six points fixed on the planet (world axes): where the cloud pattern is (the cloud kernels' cost map).
-float feedback_motion_px(const AtmoFrame &a, const AtmoFrame &b, float radius, bool surface) {
+float feedback_motion_px(const AtmoFrame &a, const AtmoFrame &b, float radius, bool surface, float *silhouette_xy = nullptr) {
     auto to_world = [](const AtmoFrame &f, const float *v, float *w) {
         const float *M = f.inv_view_matrix;
         for (int r = 0; r < 3; ++r) w[r] = M[r] * v[0] + M[4 + r] * v[1] + M[8 + r] * v[2] + M[12 + r];
@@ -479,12 +481,13 @@ float feedback_motion_px(const AtmoFrame &a, const AtmoFrame &b, float radius, b
                             M[8] * d[0] + M[9] * d[1] + M[10] * d[2]};
         return view_to_pixel(f, v, px);
     };
-    float worst = 0.0f;
-    bool any = false;
+    float worst = 0.0f, sil_x = 0.0f, sil_y = 0.0f;
+    bool any = false, silhouette = true;
     auto take = [&](bool oka, const float *pa, bool okb, const float *pb) {
         if (!oka || !okb) return;
         const float dx = pa[0] - pb[0], dy = pa[1] - pb[1];
         worst = std::fmax(worst, std::sqrt(dx * dx + dy * dy));
+        if (silhouette) { sil_x = std::fmax(sil_x, std::fabs(dx)); sil_y = std::fmax(sil_y, std::fabs(dy)); }
         any = true;
     };
     for (int k = 0; k < 5; ++k) {  // silhouette: view-space centre and centre +- R along view x / y, per frame
@@ -499,6 +502,7 @@ float feedback_motion_px(const AtmoFrame &a, const AtmoFrame &b, float radius, b
         const bool oka = view_to_pixel(a, va, pa), okb = view_to_pixel(b, vb, pb);
         take(oka, pa, okb, pb);
     }
+    silhouette = false;
     if (surface) {
         float c[3];
         to_world(a, a.planet_center_viewspace, c);
@@ -518,7 +522,9 @@ float feedback_motion_px(const AtmoFrame &a, const AtmoFrame &b, float radius, b
         const float cosang = std::fmin(std::fmax(0.5f * (tr - 1.0f), -1.0f), 1.0f);
         const float ty = std::fabs(a.inv_projection_matrix[5]);
         worst = std::acos(cosang) * (ty > 0.0f ? 0.5f * (float)a.viewport_h / ty : (float)a.viewport_h);
+        sil_x = sil_y = worst;
     }
+    if (silhouette_xy) { silhouette_xy[0] = sil_x; silhouette_xy[1] = sil_y; }
     return worst;
 }
 
@@ -656,7 +662,8 @@ int atmo_create(int device, int variant, int view_steps, int cloud_steps, int li
     if (const char *ev = std::getenv("ATMO_F4")) ctx->f4_footprints = std::atoi(ev) & 3;
     if (const char *ev = std::getenv("ATMO_LOD0_CERT")) ctx->env_lod0_cert = ev[0] == '0' ? 0 : 1;
     if (const char *ev = std::getenv("ATMO_TARGET_CLEARED")) ctx->target_cleared = ev[0] == '1' ? 1 : 0;  // tools/ab_env.sh: atmo_set_target_cleared
-    if (const char *ev = std::getenv("ATMO_FB_INSTREAM")) ctx->instream = ev[0] == '1' ? 1 : 0;
+    if (const char *ev = std::getenv("ATMO_FB_INSTREAM")) ctx->instream = ev[0] >= '1' && ev[0] <= '2' ? ev[0] - '0' : 0;  // 2 (A/B): every cloud and direct-light kernel
+    if (const char *ev = std::getenv("ATMO_FB_AXIS_WINDOWS")) ctx->fb_axis_windows = ev[0] == '1' ? 1 : 0;
     if (const char *ev = std::getenv("ATMO_FB_REACH_SCALE")) ctx->env_reach_scale = (float)std::atof(ev);
     if (const char *ev = std::getenv("ATMO_FB_MOVING_PERIOD")) { const int v = std::atoi(ev); ctx->moving_period = (unsigned)(v < 1 ? 1 : v); }
     if (const char *ev = std::getenv("ATMO_TILE_FEEDBACK_PERIOD")) { const int v = std::atoi(ev); ctx->fb_period = (unsigned)(v < 1 ? 1 : v); }
@@ -1238,15 +1245,17 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     // the camera moves; and an order whose reach the motion has outrun is not used (row-major instead).
     // reach beyond which an order says nothing about the frame it would be used on: 160 px for the in-stream sort (a frame of lag),
     // 48 px for the side-stream sort (four to six frames of lag: measured, recording every 2nd frame without a usable order costs 1-2 %)
-    constexpr float FB_STILL_PX = 0.5f, FB_MAX_REACH_PX = 160.0f, FB_MAX_REACH_SIDE_PX = 48.0f, FB_INSTREAM_PX = 3.0f;
+    constexpr float FB_STILL_PX = 0.5f, FB_MAX_REACH_PX = 160.0f, FB_MAX_REACH_SIDE_PX = 48.0f, FB_INSTREAM_PX = 3.0f, FB_INSTREAM_LONG_PX = 8.0f;
     int dil_rx = 0, dil_ry = 0;
     float reach_px = 0.0f;
     if (fb) {
         if (fb->have_prev) {
+            float sil[2] = {0.0f, 0.0f};
             const float m = feedback_motion_px(*frame, fb->prev_frame, ctx->p.u_planet_radius + ctx->p.u_atmosphere_height,
-                                               (ctx->flags & atmo::KF_CLOUDS) != 0);
+                                               (ctx->flags & atmo::KF_CLOUDS) != 0, sil);
             fb->motion_px = std::fmax(m, 0.75f * fb->motion_px);  // peak hold: one still frame does not end a camera move
             if (fb->motion_px < 0.01f) fb->motion_px = 0.0f;
+            for (int k = 0; k < 2; ++k) fb->sil_px[k] = std::fmax(sil[k], 0.75f * fb->sil_px[k]);
         }
         fb->prev_frame = *frame;
         fb->have_prev = true;
@@ -1274,8 +1283,17 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         // price of ~10 us of sort kernels on the critical path per frame.  Measured (profiles/round3/ab_tile_feedback_motion.txt):
         // clouds_high_rm panning 1 degree per frame +20 % in-stream against +7 % with the side-stream sort, but 35 % against 37 %
         // at 0.1 degree per frame; clouds_high (0.18 ms frames, +7 % at best) loses 7 % in-stream: side stream only.
-        const float is_reach = fb->motion_px * 2.0f * ctx->env_reach_scale;  // one frame of lag and one of margin
-        fb_instream = ctx->instream && fb->motion_px >= FB_INSTREAM_PX && (flags & atmo::KF_CLOUD_LIGHT_RM) && !fb->pending && is_reach <= FB_MAX_REACH_PX;
+        // one frame of lag and one of margin -- of the silhouette's motion when the window is taken from it (below)
+        const float is_reach = (ctx->fb_axis_windows ? std::fmax(fb->sil_px[0], fb->sil_px[1]) : fb->motion_px) * 2.0f * ctx->env_reach_scale;
+        // Which kernels: raymarched cloud light from 3 px per frame; since round 4 (per-axis windows) also the other 64-step cloud kernels in
+        // the precise mode (0.2 ms frames: +10..13 % where the side-stream order had nothing left, measured from 8 px per frame; at 1.4 px per
+        // frame the side stream is 2-3 points better).  Shorter frames (`clouds`, the fast cloud mode: 0.12-0.16 ms) are neutral in-stream
+        // (-0.4..+3 %) and stay on the side stream; the cloudless direct-light kernel LOSES 9-12 % in-stream under a pan (ATMO_FB_INSTREAM=2).
+        const bool is_rm = (flags & atmo::KF_CLOUD_LIGHT_RM) != 0;
+        const bool is_long = (flags & atmo::KF_CLOUDS) && (flags & atmo::KF_PRECISE) && ctx->cloud_steps >= 64;
+        const bool is_kernel = ctx->instream == 2 ? (flags & (atmo::KF_CLOUDS | atmo::KF_LIGHT_DIRECT)) != 0 : (is_rm || (is_long && ctx->fb_axis_windows));
+        const float is_px = is_rm ? FB_INSTREAM_PX : FB_INSTREAM_LONG_PX;
+        fb_instream = ctx->instream && fb->motion_px >= is_px && is_kernel && !fb->pending && is_reach <= FB_MAX_REACH_PX;
         const int tile_h = (rc.y1 - rc.y0 + gy - 1) / gy;  // pixel rows per tile of this launch (8, or 4 with two lanes per ray)
         if (fb_instream) {
             if (fb->is_last_n + 1u == fb->n) {  // the sort behind the previous draw of this key wrote is_order
@@ -1286,6 +1304,16 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
             reach_px = is_reach;
             dil_rx = (int)std::ceil(reach_px / 16.0f);
             dil_ry = (int)std::ceil(reach_px / (float)(tile_h > 0 ? tile_h : 8));
+            if (ctx->fb_axis_windows) {
+                // Round 4: the window per screen axis, from the motion of the planet's SILHOUETTE alone (two frames of it, one tile at least).  The
+                // expensive tiles of these kernels sit on the limb, which an orbit leaves where it is while the surface points behind motion_px sweep
+                // across the disc: the isotropic window (7 x 13 tiles at 1 degree of orbit per frame) buried the ranking of exactly those tiles, and
+                // a pan needs nothing vertically (profiles/round4/ab_tile_feedback_motion.txt).
+                dil_rx = (int)std::ceil(2.0f * fb->sil_px[0] * ctx->env_reach_scale / 16.0f);
+                dil_ry = (int)std::ceil(2.0f * fb->sil_px[1] * ctx->env_reach_scale / (float)(tile_h > 0 ? tile_h : 8));
+                dil_rx = dil_rx < 1 ? 1 : (dil_rx > 10 ? 10 : dil_rx);
+                dil_ry = dil_ry < 1 ? 1 : (dil_ry > 10 ? 10 : dil_ry);
+            }
             fb->active = -1;  // whatever the side stream sorted last belongs to an older picture
         } else {
             if (fb->active >= 0) {
