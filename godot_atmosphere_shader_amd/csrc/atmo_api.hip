@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <new>
 #include <string>
 #include <vector>
@@ -366,12 +367,12 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
     rc.cube_f4 = (ctx->f4_footprints & 1) ? (const float *)ctx->cube_f4.ptr : nullptr;
     rc.shape_f4 = (ctx->f4_footprints & 2) ? (const float *)ctx->shape_f4.ptr : nullptr;
     rc.cube_lod_fast = (ctx->cube_n >= 1 && ctx->cube_n <= 1024 && (ctx->cube_n & (ctx->cube_n - 1)) == 0) ? 1 : 0;
-    {   // the level-0 certificate of the declared sampler (atmo_kernels.hip: cube_lod_level0_certain):  w E <= lod0_c ma^2  =>  lambda = 0.
-        //   lod0_c = 0.9 * 4 (1 - 2/n)^2 / (n^2 sigma^2),  sigma = 1.002 >= the coverage rotation's largest singular value: the certificate is
+    {   // the level-0 certificate of the declared sampler (atmo_kernels.hip: cube_lod_level0_certain):  w E <= C ma^2  =>  lambda = 0.
+        //   C = 0.9 * 4 (1 - 2/n)^2 / (n^2 sigma^2),  sigma = 1.002 >= the coverage rotation's largest singular value: the certificate is
         // only offered when u_cloud_coverage_rotation is a rotation to 1e-3 (the node builds it from one angle; any other mat2 renders through
         // the full derivative path).  The 0.9 -- 5 % of the distance threshold, >= 5.6e-5 ma at n = 1024 -- pays for what the kernel's E
         // leaves out: the rounding of the tap offsets and of the rotation, <= 8 ulp(|p|) = 1.6e-6 ma (the march's drift is in E itself).
-        rc.lod0_c = -1.0f;
+        rc.lod0_inv_c = std::numeric_limits<float>::infinity();
         rc.lod0_last = (float)(rc.cloud_steps - 1);
         rc.lod0_drift = (float)((rc.cloud_steps + 1) * 2.07e-7);
         const double n = (double)ctx->cube_n;
@@ -379,9 +380,9 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
         const double fro = a * a + b * b + c * c + d * d, det = a * d - b * c;
         if (rc.cube_lod_fast && ctx->cube_n >= 4 && std::fabs(fro - 2.0) <= 2e-3 && std::fabs(std::fabs(det) - 1.0) <= 1e-3) {
             const double sigma = 1.002;
-            rc.lod0_c = (float)(0.9 * 4.0 * (1.0 - 2.0 / n) * (1.0 - 2.0 / n) / (n * n * sigma * sigma));
+            rc.lod0_inv_c = (float)(1.0 / (0.9 * 4.0 * (1.0 - 2.0 / n) * (1.0 - 2.0 / n) / (n * n * sigma * sigma)));  // the kernels carry E / C
         }
-        if (ctx->env_lod0_cert == 0) rc.lod0_c = -1.0f;  // ATMO_LOD0_CERT=0 (A/B): every sample takes the derivative path
+        if (ctx->env_lod0_cert == 0) rc.lod0_inv_c = std::numeric_limits<float>::infinity();  // ATMO_LOD0_CERT=0 (A/B): every sample takes the derivative path
     }
     {   // sure-miss test (shade_pixel): usable when the view-ray direction does not depend on the depth sample (x, y, z rows of
         // inv_projection have no depth column: every perspective and orthographic-free Godot camera) and the camera is well

@@ -65,7 +65,7 @@ struct RenderConsts {
     const uint32_t *cube_level_off;  // device array of 16 element offsets
     uint32_t cube_bytes;             // bytes of the packed footprint chain (buffer-load bound)
     int32_t cube_lod_fast;           // 1: cube_n is a power of two <= 1024 (closed-form level offsets, fp32 addressing)
-    float lod0_c;                    // [host] the level-0 certificate's constant (cube_lod_level0_certain); negative: never certain
+    float lod0_inv_c;                // [host] 1 / the level-0 certificate's constant C (cube_lod_level0_certain); +inf: never certain
     float lod0_last, lod0_drift;     // [host] cloud_steps - 1 and (cloud_steps + 1) * sqrt(3) 2^-23 (quad_march_spread2)
     // --- per-pixel streams
     const float *depth;      // h rows of w

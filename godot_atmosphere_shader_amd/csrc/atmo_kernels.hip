@@ -503,7 +503,7 @@ struct QuadNb {
     bool vx, vy;
     V3 px, py;         // position form (light taps of a queued sample): the horizontal / vertical partner's sample position (model space) ...
     V3 k;              // ... and the tap's offset from it (the partners evaluate the same tap from their own sample)
-    float e2;          // >= |partner's position - this lane's|^2 for both partners that reach the call (cube_lod_level0_certain)
+    float e2;          // >= |partner's position - this lane's|^2 for both partners that reach the call, scaled: cube_lod_scaled_spread
     const f32x4 *lvl;  // LDS: per mip level {0.5 n_l, 4 n_l + 4, 4 (n_l + 1)^2, byte offset of footprint (0, 0) of face 0} (cube_level_table)
     QuadRegs *regs;    // lock-step form (the march): the whole-quad exchange registers
 };
@@ -701,7 +701,13 @@ __device__ __forceinline__ CubeLod cube_lod_select(const RenderConsts &rc, float
     l.fr = lambda - lf;   // 0 on the last level: lambda <= levels - 1 is an integer there
     return l;
 }
-// the two nearest levels (cube_sample_lod_fast / _quad); a sample with the level-0 certificate arrives with {0, 0}
+// level 0's tap alone: what a sample with the level-0 certificate returns ({0, 0} through cube_lod_finish, without its selects and tests)
+__device__ __forceinline__ float cube_lod_level0(const RenderConsts &rc, float fid, float qs, float qt, const f32x4 *lvl) {
+    const bool f4 = rc.cube_f4 != nullptr;
+    const __amdgpu_buffer_rsrc_t rs = f4 ? make_rsrc(rc.cube_f4, rc.cube_bytes * 4u) : make_rsrc(rc.cube, rc.cube_bytes);
+    return cube_level_sample_fast(rs, f4, fid, qs + 1.0f, qt + 1.0f, lvl[0]);
+}
+// the two nearest levels (cube_sample_lod_fast / _quad)
 __device__ __forceinline__ float cube_lod_finish(const RenderConsts &rc, float fid, float qs, float qt, CubeLod l, const f32x4 *lvl) {
     const float q1s = qs + 1.0f, q1t = qt + 1.0f;
     const bool f4 = rc.cube_f4 != nullptr;  // wave-uniform: the float copy of the chain, or the byte footprints
@@ -730,15 +736,18 @@ __device__ __forceinline__ void cube_exact_quotients(float sc, float tc, float m
 //   rounded difference of the two directions, on the lane's own face and across a cube edge alike), s = sc / ma, t = tc / ma, ma' = ma + dma:
 //     s' - s = (dsc - s dma) / (2 ma'),   so   rho^2 = n^2 ((dsc - s dma)^2 + (dtc - t dma)^2) / (4 ma'^2)
 //            <= n^2 (1 + s^2 + t^2) |d|^2 / (4 ma'^2)                 (triangle inequality, then Cauchy-Schwarz on |(dsc, dtc)| + |(s, t)| |dma|)
-//   and ma' >= ma - |d|.  If  w E <= C ma^2  with w = 1 + s^2 + t^2, E >= |d|^2 and C = 0.9 * 4 (1 - 2/n)^2 / (n sigma)^2 (host: lod0_c), then
+//   and ma' >= ma - |d|.  If  w E <= C ma^2  with w = 1 + s^2 + t^2, E >= |d|^2 and C = 0.9 * 4 (1 - 2/n)^2 / (n sigma)^2 (host: lod0_inv_c = 1 / C), then
 //   |d| <= 2 ma / n, ma' >= (1 - 2/n) ma and rho^2 <= 0.9 for either partner: max(rho^2, 1) = 1, lambda = 0, frac = 0 -- the sample IS level 0's
 //   bilinear tap, bit for bit what the full path returns.  E is taken between the UNROTATED positions (sigma bounds the rotation); the few ulp
 //   the rotation's and the tap offsets' roundings add to |d|, and the 1e-6 relative error of the kernel's own rho^2, are inside the 0.9.
 // A partner that does not reach the call, or lies beyond the face's half space, contributes nothing to rho^2: leaving it out of E, or in, is
-// safe.  NaN or infinite operands fail the comparison and take the full path; ma > 1e-15 keeps C ma^2 a normal number.
-__device__ __forceinline__ bool cube_lod_level0_certain(const RenderConsts &rc, float qs, float qt, float ma, float e2) {
+// safe.  NaN or infinite operands fail the comparison and take the full path (certificate withheld: 1 / C = +inf, 0 * inf = NaN).
+// The lanes carry E / C + 1e-30 (cube_lod_scaled_spread: once per ray / per queued sample), so the test is w (E / C + 1e-30) <= ma^2: no uniform
+// operand (the declared-sampler kernels spill SGPRs to VGPR lanes: every uniform read here was a v_readlane), and the floor fails it for ma^2 < 1e-30.
+__device__ __forceinline__ float cube_lod_scaled_spread(const RenderConsts &rc, float e2) { return e2 * rc.lod0_inv_c + 1e-30f; }
+__device__ __forceinline__ bool cube_lod_level0_certain(const RenderConsts &rc, float qs, float qt, float ma, float e2c) {
     const float w = __builtin_fmaf(qs, qs, __builtin_fmaf(qt, qt, 1.0f));
-    const bool certain = w * e2 <= rc.lod0_c * (ma * ma) && ma > 1e-15f;
+    const bool certain = w * e2c <= ma * ma;
 #if defined(ATMO_WAVE_TRACE) && ATMO_RMQ_STATS  // diagnostic build: how many samples carry the certificate (words 44..47 of the statistics block)
     if (rc.wave_trace != nullptr) {
         unsigned long long *st_ = rc.wave_trace + 16ull * gridDim.x * gridDim.y - 64 + 44;
@@ -770,7 +779,7 @@ __device__ __forceinline__ float quad_march_spread2(const RenderConsts &rc, floa
     const float pmax = hw_sqrt(fmaxf(norm2(px, py, pz), norm2(lx, ly, lz))) + e;              // either lane, any step
     // drift: sqrt(3) components x (k/2 + k/2) ulp, ulp(|p|) <= 2^-23 |p|, k <= steps (one more for the rounding of `l`); 1.001: this function's own rounding
     const float r = (e + rc.lod0_drift * pmax) * 1.001f;
-    return r * r;
+    return cube_lod_scaled_spread(rc, r * r);
 }
 
 // position form (the light taps of a queued sample): the partners' sample positions and the tap offset are given.  Their cube coordinates come
@@ -784,6 +793,8 @@ __device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3
     const float ma = 0.5f * fabsf(ma2x);
     float qs, qt;
     cube_exact_quotients(sc, tc, ma, qs, qt);
+    // (one path to the level taps here, the certain samples arriving with {0, 0}: a direct level-0 return as in the lock-step form below makes the
+    //  rolled tap loop longer -- clouds_high_rm 1080p +1.2 %, P_limb +8 % against -2.5 % / +2.6 % with the direct return in the march alone)
     CubeLod lod = {0, 0.0f};
     if (!cube_lod_level0_certain(rc, qs, qt, ma, nb->e2)) {
         float rho2 = 0.0f;
@@ -813,8 +824,9 @@ __device__ __forceinline__ float cube_sample_lod_quad(const RenderConsts &rc, fl
     const float ma = 0.5f * fabsf(ma2x);
     float qs, qt;
     cube_exact_quotients(sc, tc, ma, qs, qt);
-    CubeLod lod = {0, 0.0f};
-    if (!cube_lod_level0_certain(rc, qs, qt, ma, nb->e2)) {   // (never certain when !cube_lod_fast: lod0_c < 0)
+    if (cube_lod_level0_certain(rc, qs, qt, ma, nb->e2)) return cube_lod_level0(rc, fid, qs, qt, nb->lvl);   // (never when !cube_lod_fast: 1 / C = inf)
+    CubeLod lod;
+    {
         float rho2 = 0.0f;
         QuadRegs &q = *nb->regs;
         quad_exchange_coords(px, py, pz, rc.cov_rot[0], rc.cov_rot[1], rc.cov_rot[2], rc.cov_rot[3], q);  // q.fid, sc, tc, mas, qx, qz: the values above
@@ -1539,9 +1551,9 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
                 enb.px = V3{qn[e], qn[RMQ_CAP + e], qn[2 * RMQ_CAP + e]};
                 enb.py = V3{qn[3 * RMQ_CAP + e], qn[4 * RMQ_CAP + e], qn[5 * RMQ_CAP + e]};
                 enb.k = V3{0.0f, 0.0f, 0.0f};
-                // the same three differences at every tap of this sample (the partners add the same offset), up to an ulp of |p| (lod0_c's reserve)
+                // the same three differences at every tap of this sample (the partners add the same offset), up to an ulp of |p| (the reserve in C)
                 auto dist2 = [&](V3 p) { const float a = p.x - ex, b = p.y - ey, c = p.z - ez; return __builtin_fmaf(a, a, __builtin_fmaf(b, b, c * c)); };
-                enb.e2 = fmaxf(enb.vx ? dist2(enb.px) : 0.0f, enb.vy ? dist2(enb.py) : 0.0f) * 1.001f;
+                enb.e2 = cube_lod_scaled_spread(rc, fmaxf(enb.vx ? dist2(enb.px) : 0.0f, enb.vy ? dist2(enb.py) : 0.0f) * 1.001f);
                 sl &= 1023u;
             }
             const float light = light_raymarched<PRECISE, LOD>(rc, ex, ey, ez, eh, ed, sx, sy, sz, LOD ? &enb : nullptr);
