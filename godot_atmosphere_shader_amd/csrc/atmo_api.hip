@@ -368,19 +368,24 @@ void fill_consts(const AtmoContext *ctx, const AtmoFrame *f, const float *depth,
     rc.shape_f4 = (ctx->f4_footprints & 2) ? (const float *)ctx->shape_f4.ptr : nullptr;
     rc.cube_lod_fast = (ctx->cube_n >= 1 && ctx->cube_n <= 1024 && (ctx->cube_n & (ctx->cube_n - 1)) == 0) ? 1 : 0;
     {   // the level-0 certificate of the declared sampler (atmo_kernels.hip: cube_lod_level0_certain):  w E <= C ma^2  =>  lambda = 0.
-        //   C = 0.9 * 4 (1 - 2/n)^2 / (n^2 sigma^2),  sigma = 1.002 >= the coverage rotation's largest singular value: the certificate is
-        // only offered when u_cloud_coverage_rotation is a rotation to 1e-3 (the node builds it from one angle; any other mat2 renders through
-        // the full derivative path).  The 0.9 -- 5 % of the distance threshold, >= 5.6e-5 ma at n = 1024 -- pays for what the kernel's E
-        // leaves out: the rounding of the tap offsets and of the rotation, <= 8 ulp(|p|) = 1.6e-6 ma (the march's drift is in E itself).
+        //   C = 0.97 * 4 (1 - 2/n)^2 / (n^2 sigma^2),  sigma = the largest singular value of u_cloud_coverage_rotation (1 for the rotation the node
+        // builds from one angle; the bound holds for any linear map, the certificate is offered while both singular values lie in [0.5, 2] -- the
+        // rounding budget below is a rotation's times sigma_max / sigma_min <= 4 then).  The 0.97 (rho^2 <= 0.97 proves lambda = 0) pays for what the kernel's E leaves out: the rounding of the tap
+        // offsets and of the rotation, <= 8 ulp(|p|) = 1.6e-6 ma against a distance threshold >= 1.1e-3 ma (n = 1024, w = 3): 0.3 % of rho^2; the
+        // 1.001 factors on E and the fp32 evaluation of the test and of the kernel's own rho^2: < 0.3 % more (the march's drift is in E itself).
+        // (How much a tighter bound would buy, measured with the factor set beyond 1, i.e. NOT rigorous: 1.5 -> clouds_high -6 %, the limb frame
+        //  -10 %; 0.9 -> 0.97 itself: -1 %.)
         rc.lod0_inv_c = std::numeric_limits<float>::infinity();
         rc.lod0_last = (float)(rc.cloud_steps - 1);
         rc.lod0_drift = (float)((rc.cloud_steps + 1) * 2.07e-7);
         const double n = (double)ctx->cube_n;
         const double a = rc.cov_rot[0], b = rc.cov_rot[2], c = rc.cov_rot[1], d = rc.cov_rot[3];  // column-major: rows (a b), (c d)
         const double fro = a * a + b * b + c * c + d * d, det = a * d - b * c;
-        if (rc.cube_lod_fast && ctx->cube_n >= 4 && std::fabs(fro - 2.0) <= 2e-3 && std::fabs(std::fabs(det) - 1.0) <= 1e-3) {
-            const double sigma = 1.002;
-            rc.lod0_inv_c = (float)(1.0 / (0.9 * 4.0 * (1.0 - 2.0 / n) * (1.0 - 2.0 / n) / (n * n * sigma * sigma)));  // the kernels carry E / C
+        const double disc = fro * fro - 4.0 * det * det;
+        const double sigma = std::sqrt(0.5 * (fro + std::sqrt(disc > 0.0 ? disc : 0.0))) * (1.0 + 1e-6);  // largest singular value of a 2 x 2 matrix
+        const double sigma_min = sigma > 0.0 ? std::fabs(det) / sigma : 0.0;   // ... and the smallest: the products of a nearly singular map cancel
+        if (rc.cube_lod_fast && ctx->cube_n >= 4 && sigma <= 2.0 && sigma_min >= 0.5) {
+            rc.lod0_inv_c = (float)(1.0 / (0.97 * 4.0 * (1.0 - 2.0 / n) * (1.0 - 2.0 / n) / (n * n * sigma * sigma)));  // the kernels carry E / C
         }
         if (ctx->env_lod0_cert == 0) rc.lod0_inv_c = std::numeric_limits<float>::infinity();  // ATMO_LOD0_CERT=0 (A/B): every sample takes the derivative path
     }

@@ -736,10 +736,10 @@ __device__ __forceinline__ void cube_exact_quotients(float sc, float tc, float m
 //   rounded difference of the two directions, on the lane's own face and across a cube edge alike), s = sc / ma, t = tc / ma, ma' = ma + dma:
 //     s' - s = (dsc - s dma) / (2 ma'),   so   rho^2 = n^2 ((dsc - s dma)^2 + (dtc - t dma)^2) / (4 ma'^2)
 //            <= n^2 (1 + s^2 + t^2) |d|^2 / (4 ma'^2)                 (triangle inequality, then Cauchy-Schwarz on |(dsc, dtc)| + |(s, t)| |dma|)
-//   and ma' >= ma - |d|.  If  w E <= C ma^2  with w = 1 + s^2 + t^2, E >= |d|^2 and C = 0.9 * 4 (1 - 2/n)^2 / (n sigma)^2 (host: lod0_inv_c = 1 / C), then
-//   |d| <= 2 ma / n, ma' >= (1 - 2/n) ma and rho^2 <= 0.9 for either partner: max(rho^2, 1) = 1, lambda = 0, frac = 0 -- the sample IS level 0's
+//   and ma' >= ma - |d|.  If  w E <= C ma^2  with w = 1 + s^2 + t^2, E >= |d|^2 and C = 0.97 * 4 (1 - 2/n)^2 / (n sigma)^2 (host: lod0_inv_c = 1 / C), then
+//   |d| <= 2 ma / n, ma' >= (1 - 2/n) ma and rho^2 <= 0.97 for either partner: max(rho^2, 1) = 1, lambda = 0, frac = 0 -- the sample IS level 0's
 //   bilinear tap, bit for bit what the full path returns.  E is taken between the UNROTATED positions (sigma bounds the rotation); the few ulp
-//   the rotation's and the tap offsets' roundings add to |d|, and the 1e-6 relative error of the kernel's own rho^2, are inside the 0.9.
+//   the rotation's and the tap offsets' roundings add to |d|, and the 1e-6 relative error of the kernel's own rho^2, are inside the 0.97 (0.6 % of it).
 // A partner that does not reach the call, or lies beyond the face's half space, contributes nothing to rho^2: leaving it out of E, or in, is
 // safe.  NaN or infinite operands fail the comparison and take the full path (certificate withheld: 1 / C = +inf, 0 * inf = NaN).
 // The lanes carry E / C + 1e-30 (cube_lod_scaled_spread: once per ray / per queued sample), so the test is w (E / C + 1e-30) <= ma^2: no uniform
