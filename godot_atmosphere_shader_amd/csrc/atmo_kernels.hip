@@ -1849,9 +1849,9 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
 #ifndef ATMO_MIN_WAVES  // __launch_bounds__ second argument: minimum waves per SIMD the register allocation must allow (0 = none).
 #define ATMO_MIN_WAVES 6  // 6: only atmo_render_kernel<19 / 23, ..> change (84 -> 80 VGPRs); see ATMO_RMQ_CHUNK
 #endif
-#ifndef ATMO_MIN_WAVES_LOD_RM  // the declared-sampler form of that kernel stays at its natural 111 VGPRs = 4 waves: bound 5 (96 VGPRs,
-#define ATMO_MIN_WAVES_LOD_RM 4  // 13 spilled dwords) measured +3 % slower at both sizes (profiles/round3/ab_occupancy.txt)
-#endif
+#ifndef ATMO_MIN_WAVES_LOD_RM  // the declared-sampler form of that kernel: bound 4 = no constraint in practice.  Round 3: natural 111 VGPRs = 4 waves, and
+#define ATMO_MIN_WAVES_LOD_RM 4  // bound 5 (96 VGPRs, 13 spilled dwords) measured +3 % (profiles/round3/ab_occupancy.txt).  Since round 4 (whole-quad exchange,
+#endif                           // level-0 certificate) it needs 88 VGPRs = 5 waves by itself, and its LDS (ATMO_RMQ_CHUNK_LOD) allows exactly those 5.
 #ifndef ATMO_MIN_WAVES_LOD
 #define ATMO_MIN_WAVES_LOD ATMO_MIN_WAVES
 #endif
