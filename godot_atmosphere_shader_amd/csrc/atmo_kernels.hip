@@ -1363,15 +1363,33 @@ __device__ __forceinline__ MarchRay cloud_march_ray(const RenderConsts &rc, V3 d
     return m;
 }
 
+// The uniforms the density evaluation reads at every sample, in VGPRs (round 4, late).  The declared-sampler kernels run at the SGPR ceiling and
+// spill uniforms to VGPR lanes: every use in the march loop was a v_readlane (18 static in <49, 0, 1>, 0 with this), on top of the slow-class issue
+// of a VALU instruction with an SGPR operand.  `clouds_high` 0.1907 -> 0.1745 ms, `clouds` 0.1141 -> 0.1057, P_limb -9 %, v1 -3.4 %;
+// the level-0 kernels, which spill nothing, are unchanged (+-0.5 %): profiles/round4/ab_vgpr_uniforms.txt.  NOT a general rule: the sun direction
+// of the hand-scheduled atmosphere march in VGPRs costs the headline kernel 10 %.
+// A copy of the constants whose hot fields pass through an empty asm with "+v" operands; everything else of the copy stays what it was.
+#ifndef ATMO_VGPR_UNIFORMS
+#define ATMO_VGPR_UNIFORMS 1
+#endif
+__device__ __forceinline__ void cloud_uniforms_to_vgprs(RenderConsts &v) {
+#if ATMO_VGPR_UNIFORMS
+    asm volatile("" : "+v"(v.cov_rot[0]), "+v"(v.cov_rot[1]), "+v"(v.cov_rot[2]), "+v"(v.cov_rot[3]), "+v"(v.clouds_bottom), "+v"(v.cloud_thickness),
+                 "+v"(v.inv_cloud_thickness), "+v"(v.coverage_bias));
+#endif
+}
+
 // raymarch_cloud (cloud_funcs.gdshaderinc:175-247).  Returns (total_light, alpha).
 // SPLIT = 2: lane `half` of a pair evaluates the samples with step index = half (mod 2) -- position chain, density,
 // light -- while the recurrence over the samples (transmittance floor, light sum, alpha) runs in step order on the
 // pair's values exchanged by DPP.  Every sample is evaluated with the same arithmetic as in the one-lane form (the
 // position is still advanced one rounded addition per step), so the result is bit-identical; only lane 0's is used.
 template <bool RM, bool PRECISE, int SPLIT, bool LOD = false>
-__device__ __forceinline__ float2 march_clouds(const RenderConsts &rc, V3 dir_m, float t_begin, float t_end, float jitter, int half,
+__device__ __forceinline__ float2 march_clouds(const RenderConsts &rc_in, V3 dir_m, float t_begin, float t_end, float jitter, int half,
                                                QuadRegs *qregs = nullptr, const f32x4 *lvl = nullptr) {
     static_assert(!(LOD && RM), "raymarched light under the declared sampler runs through the lit-sample queue");
+    RenderConsts rc = rc_in;
+    if (PRECISE) cloud_uniforms_to_vgprs(rc);
     const int steps = rc.cloud_steps;
     // exact: positions
     const MarchRay self = cloud_march_ray(rc, dir_m, t_begin, t_end, jitter);
@@ -1495,6 +1513,9 @@ constexpr int rmq_words_per_wave(bool lod) { return (lod ? 12 : 6) * RMQ_CAP + r
 template <bool PRECISE, bool LOD = false>
 __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, V3 dir_m, float t_begin, float t_end, float jitter,
                                                         float *__restrict__ lds, QuadRegs *qregs = nullptr, const f32x4 *lvl = nullptr) {
+    // (no cloud_uniforms_to_vgprs here: eight more VGPRs take the declared-sampler kernel from 88 to 103 -- 4 waves per SIMD, +9 % -- and under a
+    //  96-VGPR bound it spills for a gain of 1 %; three of them (the height chain's, 93 VGPRs) bought 0.5-1.5 %; the level-0 kernel, bound to 80
+    //  VGPRs, is 0.5-1.3 % slower with them: profiles/round4/ab_vgpr_uniforms.txt)
     float *qx = lds, *qy = lds + RMQ_CAP, *qz = lds + 2 * RMQ_CAP, *qh = lds + 3 * RMQ_CAP;
     uint32_t *qs = reinterpret_cast<uint32_t *>(lds + 4 * RMQ_CAP);
     float *qd = lds + 5 * RMQ_CAP;  // the sample's own density = light tap 0
