@@ -433,15 +433,15 @@ __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, in
 // its end, so their live range spans every divergent region and nothing can share them; tests/test_host_logic.py checks in the ISA of every
 // LOD kernel that no instruction outside the exchange blocks writes them.
 struct QuadRegs {
-    float fid, sc, tc, mas, qx, qz;                      // own: v_cubeid / sc / tc / ma of the rotated position (qx, p.y, qz)
+    float fid, sc, tc, mas;                              // own: v_cubeid / sc / tc / ma of the rotated position
     float fidx, scx, tcx, masx, fidy, scy, tcy, masy;    // the same of the horizontal (lane ^ 1) and vertical (lane ^ 2) partner
 };
 __device__ __forceinline__ void quad_regs_define(QuadRegs &q) {
-    asm volatile("; QuadRegs defined" : "=v"(q.fid), "=v"(q.sc), "=v"(q.tc), "=v"(q.mas), "=v"(q.qx), "=v"(q.qz), "=v"(q.fidx), "=v"(q.scx),
+    asm volatile("; QuadRegs defined" : "=v"(q.fid), "=v"(q.sc), "=v"(q.tc), "=v"(q.mas), "=v"(q.fidx), "=v"(q.scx),
                  "=v"(q.tcx), "=v"(q.masx), "=v"(q.fidy), "=v"(q.scy), "=v"(q.tcy), "=v"(q.masy));
 }
 __device__ __forceinline__ void quad_regs_keep(const QuadRegs &q) {
-    asm volatile("; QuadRegs kept" ::"v"(q.fid), "v"(q.sc), "v"(q.tc), "v"(q.mas), "v"(q.qx), "v"(q.qz), "v"(q.fidx), "v"(q.scx), "v"(q.tcx),
+    asm volatile("; QuadRegs kept" ::"v"(q.fid), "v"(q.sc), "v"(q.tc), "v"(q.mas), "v"(q.fidx), "v"(q.scx), "v"(q.tcx),
                  "v"(q.masx), "v"(q.fidy), "v"(q.scy), "v"(q.tcy), "v"(q.masy));
 }
 // coverage = texture(cubemap, vec3(rot * p.xz, p.y)): the rotation (cloud_funcs.gdshaderinc:43, every product and sum rounded on its own)
@@ -451,17 +451,17 @@ __device__ __forceinline__ void quad_exchange_coords(float px, float py, float p
     asm volatile(
         "s_mov_b64 %[saved], exec\n\t"
         "s_wqm_b64 exec, exec\n\t"
-        "v_mul_f32_e32 %[qx], %[r0], %[px]\n\t"
+        "v_mul_f32_e32 %[scx], %[r0], %[px]\n\t"   // the rotated x and z in scx / scy until the cube instructions have read them
         "v_mul_f32_e32 %[fidx], %[r2], %[pz]\n\t"
-        "v_mul_f32_e32 %[qz], %[r1], %[px]\n\t"
+        "v_mul_f32_e32 %[scy], %[r1], %[px]\n\t"
         "v_mul_f32_e32 %[fidy], %[r3], %[pz]\n\t"
-        "v_add_f32_e32 %[qx], %[qx], %[fidx]\n\t"
-        "v_add_f32_e32 %[qz], %[qz], %[fidy]\n\t"
+        "v_add_f32_e32 %[scx], %[scx], %[fidx]\n\t"
+        "v_add_f32_e32 %[scy], %[scy], %[fidy]\n\t"
         "s_nop 0\n\t"
-        "v_cubeid_f32 %[fid], %[qx], %[py], %[qz]\n\t"
-        "v_cubesc_f32 %[sc], %[qx], %[py], %[qz]\n\t"
-        "v_cubetc_f32 %[tc], %[qx], %[py], %[qz]\n\t"
-        "v_cubema_f32 %[mas], %[qx], %[py], %[qz]\n\t"
+        "v_cubeid_f32 %[fid], %[scx], %[py], %[scy]\n\t"
+        "v_cubesc_f32 %[sc], %[scx], %[py], %[scy]\n\t"
+        "v_cubetc_f32 %[tc], %[scx], %[py], %[scy]\n\t"
+        "v_cubema_f32 %[mas], %[scx], %[py], %[scy]\n\t"
         "s_nop 1\n\t"
         "v_mov_b32_dpp %[fidx], %[fid] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "v_mov_b32_dpp %[scx], %[sc] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
@@ -472,7 +472,7 @@ __device__ __forceinline__ void quad_exchange_coords(float px, float py, float p
         "v_mov_b32_dpp %[tcy], %[tc] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "v_mov_b32_dpp %[masy], %[mas] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "s_mov_b64 exec, %[saved]"
-        : [saved] "=&s"(saved), [fid] "+v"(q.fid), [sc] "+v"(q.sc), [tc] "+v"(q.tc), [mas] "+v"(q.mas), [qx] "+v"(q.qx), [qz] "+v"(q.qz),
+        : [saved] "=&s"(saved), [fid] "+v"(q.fid), [sc] "+v"(q.sc), [tc] "+v"(q.tc), [mas] "+v"(q.mas),
           [fidx] "+v"(q.fidx), [scx] "+v"(q.scx), [tcx] "+v"(q.tcx), [masx] "+v"(q.masx), [fidy] "+v"(q.fidy), [scy] "+v"(q.scy),
           [tcy] "+v"(q.tcy), [masy] "+v"(q.masy)
         : [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [r0] "s"(r0), [r1] "s"(r1), [r2] "s"(r2), [r3] "s"(r3)
@@ -1514,8 +1514,8 @@ template <bool PRECISE, bool LOD = false>
 __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, V3 dir_m, float t_begin, float t_end, float jitter,
                                                         float *__restrict__ lds, QuadRegs *qregs = nullptr, const f32x4 *lvl = nullptr) {
     // (no cloud_uniforms_to_vgprs here: eight more VGPRs take the declared-sampler kernel from 88 to 103 -- 4 waves per SIMD, +9 % -- and under a
-    //  96-VGPR bound it spills for a gain of 1 %; three of them (the height chain's, 93 VGPRs) bought 0.5-1.5 %; the level-0 kernel, bound to 80
-    //  VGPRs, is 0.5-1.3 % slower with them: profiles/round4/ab_vgpr_uniforms.txt)
+    //  96-VGPR bound it spills for a gain of 1 %; three or four of them (93-95 VGPRs, one short of the step) bought 0.5-1.5 %; the level-0 kernel,
+    //  bound to 80 VGPRs, is 0.5-1.3 % slower with them: profiles/round4/ab_vgpr_uniforms.txt)
     float *qx = lds, *qy = lds + RMQ_CAP, *qz = lds + 2 * RMQ_CAP, *qh = lds + 3 * RMQ_CAP;
     uint32_t *qs = reinterpret_cast<uint32_t *>(lds + 4 * RMQ_CAP);
     float *qd = lds + 5 * RMQ_CAP;  // the sample's own density = light tap 0
