@@ -28,6 +28,7 @@ CORE_SYMBOLS = (
 DEBUG_SYMBOLS = (
     "atmo_set_lane_split", "atmo_debug_motion_px", "atmo_get_feedback_stats", "atmo_set_timing", "atmo_get_timing", "atmo_host_layout_cubemap", "atmo_host_layout_shape",
     "atmo_host_layout_lut", "atmo_host_cubemap_mip", "atmo_read_texture_layout", "atmo_selftest_exact_math", "atmo_debug_marched_optical_depth", "atmo_kernel_name",
+    "atmo_get_host_wait_stats", "atmo_debug_create_host_only", "atmo_debug_frame_constants",
 )
 EXPORTED_SYMBOLS = CORE_SYMBOLS + DEBUG_SYMBOLS
 
@@ -109,6 +110,9 @@ def load() -> C.CDLL:
         "atmo_host_layout_shape": (ip, [vp, ip, vp]),
         "atmo_host_layout_lut": (ip, [vp, ip, ip, vp]),
         "atmo_kernel_name": (cp, [vp]),
+        "atmo_get_host_wait_stats": (ip, [vp, C.POINTER(C.c_uint)]),
+        "atmo_debug_create_host_only": (ip, [ip, ip, ip, ip, ip, C.POINTER(vp)]),
+        "atmo_debug_frame_constants": (ip, [vp, C.POINTER(AtmoFrame), ip, C.POINTER(C.c_float), ip, C.POINTER(ip)]),
         "atmo_last_error_string": (cp, [vp]),
     }
     # ATMO_HIP_LIB names an A/B build (tools/ab_build_commit.sh: possibly an OLDER commit's library): entry points it lacks are skipped
@@ -122,8 +126,16 @@ def load() -> C.CDLL:
             raise RuntimeError(f"libatmo_hip.so does not export {name}; rebuild it")
         fn.restype = res
         fn.argtypes = args
-    if lib.atmo_abi_version() != ABI_VERSION and not ab_build:
-        raise RuntimeError("libatmo_hip.so ABI version mismatch; rebuild it")
+    have = lib.atmo_abi_version()
+    if have != ABI_VERSION:
+        # An A/B library may be older, but only a version whose AtmoFrame layout and shared entry points are KNOWN to be what this binding
+        # declares may be driven with it, and the caller has to name it: ATMO_HIP_LIB_ABI=3 (ABI 3 = round 3: the same AtmoFrame, no
+        # atmo_set_target_cleared / atmo_render_tiles, atmo_set_sampler_lod without the -1 mode).  Anything else could corrupt memory silently.
+        allowed = {3}
+        named = os.environ.get("ATMO_HIP_LIB_ABI", "")
+        if not (ab_build and named.isdigit() and int(named) == have and have in allowed):
+            raise RuntimeError(f"libatmo_hip.so has ABI version {have}, this binding is written for {ABI_VERSION}; rebuild it"
+                               + (f" (an older A/B library needs ATMO_HIP_LIB_ABI={have}; known-compatible: {sorted(allowed)})" if ab_build else ""))
     _lib = lib
     return lib
 

@@ -52,5 +52,28 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def build_sanitized(verbose: bool = False) -> tuple[str, str]:
+    """`make sanitize-host`: the same two sources with the HOST code under AddressSanitizer + UndefinedBehaviorSanitizer (the device code is
+    compiled as always: GPU sanitizers are not available on this pool).  Returns (library, the ASan runtime to LD_PRELOAD into python)."""
+    import glob
+
+    lib = os.path.join(_HERE, "libatmo_hip_san.so")
+    flags = [f for f in HIPCC_FLAGS if f != "-O3"] + ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                                                      "-fno-gpu-sanitize", "-shared-libsan"]
+    cmd = [_hipcc()] + flags + ["-o", lib] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    rt = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not rt:
+        raise RuntimeError("the ASan runtime of ROCm's clang was not found")
+    return lib, rt[-1]
+
+
 if __name__ == "__main__":
-    print(build_native(force=True, verbose=True))
+    import sys
+
+    if "--sanitize" in sys.argv:
+        print(*build_sanitized(verbose=True))
+    else:
+        print(build_native(force=True, verbose=True))

@@ -75,6 +75,7 @@ struct RenderConsts {
     int32_t composite;       // 1 => straight-alpha "mix" blend over the existing contents, discarded pixels untouched
     // --- launch order (atmo_set_tile_feedback)
     int32_t tiles_x;                // tiles per row of the launch grid
+    uint32_t tiles_n;               // tiles of the launch grid: an entry of tile_order beyond it shades nothing (atmo_render_tiles takes the caller's list)
     const uint32_t *tile_order;     // null => tile = linear block index; else the tile each block shades (heaviest first)
     uint32_t *tile_cost;            // null => no feedback; else per-tile max wave duration in shader cycles (atomicMax)
 #ifdef ATMO_WAVE_TRACE  // diagnostic build (tools/wave_timeline.py): 4 x uint64 per wave = start, end (100 MHz), HW_ID, XCC_ID

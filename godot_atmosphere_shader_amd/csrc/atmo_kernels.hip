@@ -1919,7 +1919,10 @@ constexpr bool render_sgpr_cap80(int flags) {
 #define ATMO_RENDER_KERNEL_BODY                                                                                  \
     ATMO_TRACE_ENTRY                                                                                             \
     uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;                                                         \
-    if (rc.tile_order != nullptr) tile = rc.tile_order[tile];                                                    \
+    if (rc.tile_order != nullptr) {                                                                              \
+        tile = rc.tile_order[tile];                                                                              \
+        if (tile >= rc.tiles_n) return; /* include/atmo.h, atmo_render_tiles: an index beyond the grid shades nothing */ \
+    }                                                                                                            \
     const uint32_t tile_y = tile / (uint32_t)rc.tiles_x, tile_x = tile - tile_y * (uint32_t)rc.tiles_x;          \
     uint64_t t0 = 0;                                                                                             \
     if (rc.tile_cost != nullptr) t0 = __builtin_amdgcn_s_memtime();                                              \

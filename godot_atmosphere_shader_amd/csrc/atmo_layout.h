@@ -13,7 +13,7 @@
 
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define ATMO_HD __host__ __device__ inline
 #else
 #define ATMO_HD inline

@@ -527,7 +527,8 @@ class PlanetAtmosphere:
         sun = self._sun_position()
         if sun is not None:
             self.set_shader_parameter("u_sun_position", sun)
-        # Transform3D.inverse() is the orthonormal inverse
+        # planet_atmosphere.gd:335 calls Transform3D.inverse(), which assumes an orthonormal basis (transpose + rotated origin); the general
+        # inverse used here equals it for every rigid transform and stays a true inverse when the node is scaled (what affine_inverse() gives)
         self.set_shader_parameter("u_world_to_model_matrix", np.linalg.inv(np.asarray(self.global_transform, dtype=np.float64)))
         if time is None:
             time = _time.monotonic() - self._start_time

@@ -72,6 +72,30 @@ int atmo_debug_marched_optical_depth(AtmoContext *ctx, int n, const float *pos_x
  * (before the first launch: the one-lane-per-ray form), for matching rocprofv3 kernel traces. */
 const char *atmo_kernel_name(AtmoContext *ctx);
 
+/* How often calls of this context fell back to a device-wide host wait (hipDeviceSynchronize) where a stream-side wait on the device was
+ * not possible: a remembered stream that the caller has destroyed since, or more draw streams than the context tracks (8).  0 in a host
+ * that keeps its streams alive (tests/test_gpu_parity.py::test_texture_update_does_not_wait_for_unrelated_streams). */
+int atmo_get_host_wait_stats(AtmoContext *ctx, unsigned *device_syncs);
+
+/*
+ * The host side WITHOUT a device (round 5; for the CPU test suite and the sanitizer build of libatmo_hip.so, `make sanitize-host`): a
+ * context that owns nothing on a GPU -- the uniform table (atmo_set_param_f32 / atmo_get_param_f32), atmo_set_precision,
+ * atmo_set_sampler_lod, atmo_set_host_double_precision, atmo_set_target_cleared work on it; every entry point that needs the device
+ * fails with ATMO_E_HIP; atmo_destroy frees it.  Arguments as atmo_create (minus the device index).
+ * atmo_debug_frame_constants evaluates the per-frame (pixel-independent) expressions of the shader exactly as a draw would
+ * (fill_consts: main:136,164; v2:47-51; clouds:104-115,186-206,260-261,285-294; the level-0 certificate's constant for faces of
+ * cube_n texels) and returns them as floats, in the order documented at its definition in csrc/atmo_api.hip (81 values).
+ */
+int atmo_debug_create_host_only(int variant, int view_steps, int cloud_steps, int light_mode, int light_steps, AtmoContext **out);
+int atmo_debug_frame_constants(AtmoContext *ctx, const AtmoFrame *frame, int cube_n, float *out, int capacity, int *count);
+
+#ifdef ATMO_WAVE_TRACE
+/* Diagnostic builds only (-DATMO_WAVE_TRACE: tools/wave_timeline.py, tools/rmq_stats.py; the shipped library does not export it): copies the wave
+ * trace of the last draw -- 4 x uint64 per wave: start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID | preamble ticks << 8 -- to the host and
+ * returns the wave count (-1 on a HIP error).  Waits for the device. */
+long long atmo_debug_wave_trace(AtmoContext *ctx, unsigned long long *host, long long max_waves);
+#endif
+
 #ifdef __cplusplus
 }
 #endif

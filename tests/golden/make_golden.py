@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from common import CONFIGS, demo_frame, demo_params, demo_textures  # noqa: E402
+from common import CONFIGS, demo_frame, demo_params, demo_textures, has_clouds, oracle_inputs  # noqa: E402
 from godot_atmosphere_shader_amd import scene as S  # noqa: E402
 from oracle.oracle import Oracle  # noqa: E402
 
@@ -51,6 +51,21 @@ def main():
             out[f"hits_{name}_{pose}"] = np.int64(hits)
     path = os.path.join(HERE, "demo_scene_64x36.npz")
     np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+    # round 5: the same frames of the cloud variants under the cubemap sampler the reference DECLARES (the library's default);
+    # a file of its own so that the round-1 file above stays byte for byte what it was
+    decl = {"crc_cubemap": out["crc_cubemap"], "crc_shape": out["crc_shape"]}
+    for pose in GOLDEN_POSES:
+        cam = S.Camera.from_pose(W, H, pose)
+        for name, (_, cfg, _) in CONFIGS.items():
+            if not has_clouds(name):
+                continue
+            ocfg, otex = oracle_inputs(o, cfg, tex, lut, declared=True)
+            img, hits = o.render(params, otex, ocfg, demo_frame(cam), out[f"depth_{pose}"], nthreads=4)
+            decl[f"rgba_{name}_{pose}"] = img
+            decl[f"hits_{name}_{pose}"] = np.int64(hits)
+    path = os.path.join(HERE, "demo_scene_64x36_declared.npz")
+    np.savez_compressed(path, **decl)
     print("wrote", path, os.path.getsize(path), "bytes")
 
 

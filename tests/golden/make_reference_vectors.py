@@ -317,6 +317,35 @@ def main_round4():
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def main_round5():
+    """tests/golden/reference_exec_r5.npz: the reference text executed with the samplerCube it declares (linear-mipmap, implicit LOD from the
+    2 x 2 pixel quads) on every cloud row of reference_scenes.FULL_SIZE -- whole rows of configs[2] (clouds_high, 1920x1080) and configs[3]
+    (clouds_high_rm, 3840x2160) at poses P_space (limb rows included) and P_clouds, with the bench's 256^2 cubemap and 64^3 shape volume:
+    what round 3's LOD_FULL_SIZE did for 7 rows, for all 25."""
+    t0 = time.time()
+    z = np.load(os.path.join(HERE, "reference_exec.npz"))
+    params, model_matrix = scenes()["demo"]
+    big = demo_textures()
+    big_chain = T.mip_chain(big["cubemap"])
+    out = {"crc_cubemap_full": np.uint32(S.checksum(big["cubemap"])), "crc_shape_full": np.uint32(S.checksum(big["shape"]))}
+    units = dict(u_optical_depth_texture=T.LutTexture(z["lut_demo"]), u_blue_noise_texture=T.ByteTexture2D(S.make_blue_noise()),
+                 u_cloud_shape_texture=T.ShapeTexture(big["shape"]))
+    for shader, w, h, pose, rows in RS.LOD_FULL_SIZE_R5:
+        cam = RS.camera_from_fixture(z, w, h, pose)
+        depth = S.depth_ground_sphere(cam)
+        full, keep = with_partner_rows(rows, h)
+        rgba, disc, _, _ = run_frame(shader, None, params, np.eye(4), model_matrix, cam, depth, units, rows=full, cube_chain=big_chain)
+        key = f"lodfull_{w}x{h}_{pose}_{shader}"
+        out[f"rgba_{key}"], out[f"rows_{key}"], out[f"depth_{key}"] = rgba[keep], np.asarray(rows), depth[list(full)]
+        out[f"depthrows_{key}"] = np.asarray(full)
+        lod0 = z[f"rgba_full_{w}x{h}_{pose}_{shader}"] if f"rgba_full_{w}x{h}_{pose}_{shader}" in z.files else None
+        extra = "" if lod0 is None else f", max |LOD - LOD0| = {np.abs(rgba[keep] - lod0).max():.3e}"
+        print(f"{time.time() - t0:6.1f}s {key}: rows {rows} (+ partners), {int((~disc).sum())} of {disc.size} kept{extra}", flush=True)
+    path = os.path.join(HERE, "reference_exec_r5.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 class UnsetCube:
     """An unbound samplerCube: the engine's default white texture (README.md:46 "cover uniformly")."""
 
@@ -357,7 +386,9 @@ def main_fuzz():
 
 
 if __name__ == "__main__":
-    if "--round4-only" in sys.argv:
+    if "--round5-only" in sys.argv:
+        main_round5()
+    elif "--round4-only" in sys.argv:
         main_round4()
     elif "--fuzz-lod-only" in sys.argv:
         main_fuzz_lod()
@@ -371,3 +402,4 @@ if __name__ == "__main__":
         main_fuzz()
         main_fuzz_lod()
         main_round4()
+        main_round5()

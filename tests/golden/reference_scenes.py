@@ -62,6 +62,9 @@ LOD_FULL_SIZE = [
     ("planet_atmosphere_clouds_high", 1920, 1080, "P_clouds", (300, 801)),
     ("planet_atmosphere_clouds_high_rm", 3840, 2160, "P_space", (801, 1400)),
 ]
+# round 5 (reference_exec_r5.npz): the declared sampler on EVERY cloud row of FULL_SIZE above (25 rows, limb rows of P_space included; the
+# executed rows again include each row's vertical quad partner) -- the kernels bench.py reports for configs[2] / configs[3] since round 4
+LOD_FULL_SIZE_R5 = [c for c in FULL_SIZE if "clouds" in c[0].replace("no_clouds", "")]
 # north_star's 32 view steps and the 64 of atmosphere_funcs_v2.gdshaderinc:42-43, through the reference text with
 # ATMOSPHERE_RAYMARCH_STEPS forced over the file's own #define (planet_atmosphere_no_clouds.gdshader:4)
 VIEW_STEP_COUNTS = [32, 64]

@@ -30,6 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name, want in (("atmo.h", N.CORE_SYMBOLS), ("atmo_debug.h", N.DEBUG_SYMBOLS)):
         header = open(os.path.join(ROOT, "include", name)).read()
         header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+        header = re.sub(r"#ifdef ATMO_WAVE_TRACE.*?#endif", "", header, flags=re.S)   # declared for the diagnostic build only; not exported otherwise
         syms = set(re.findall(r"\b(atmo_[a-z0-9_]+)\s*\(", header))
         assert syms == set(want), name
         declared |= syms
@@ -443,6 +444,167 @@ def test_whole_quad_exchange_registers_are_private():
     p = subprocess.run([_sys.executable, os.path.join(ROOT, "tools", "check_quad_regs.py")], capture_output=True, text=True, timeout=600)
     lines = [ln for ln in p.stdout.splitlines() if "exchange blocks" in ln]
     assert p.returncode == 0, p.stdout + p.stderr
-    assert len(lines) >= 11 and all(ln.rstrip().endswith("ok") for ln in lines), p.stdout   # every KF_CUBE_LOD instantiation
+    assert len(lines) >= 11 and all(": ok;" in ln for ln in lines), p.stdout   # every KF_CUBE_LOD instantiation
+    # round 5: the registers the blocks READ -- the march position the helper lanes read too -- are written inside the march's loop
+    # nest by the position update alone (no copy made under a narrowed EXEC)
+    assert all(ln.rstrip().endswith("only the position update writes them in the march") for ln in lines), p.stdout
     assert any("<49, 0, 1>" in ln and " 1 exchange" in ln for ln in lines) and any("<51, 0, 1>" in ln and " 2 exchange" in ln for ln in lines)
     assert any("0 with a stack frame, 0 scratch instructions" in ln for ln in p.stdout.splitlines()), p.stdout   # and no kernel spills
+
+
+# ---- round 5: the host side of the C ABI without a device (atmo_debug_create_host_only; also what `make sanitize-host` runs) ---------------
+def _host_ctx(variant, view_steps=0, cloud_steps=0, light_mode=0, light_steps=0):
+    from godot_atmosphere_shader_amd import _native as N
+
+    lib = N.load()
+    ctx = C.c_void_p()
+    assert lib.atmo_debug_create_host_only(variant, view_steps, cloud_steps, light_mode, light_steps, C.byref(ctx)) == N.ATMO_OK and ctx.value
+    return lib, ctx
+
+
+def test_uniform_table_on_a_host_only_context():
+    """Every uniform of SURVEY.md 8b by the reference's name: shader defaults (`source_color` ones linear), set / get round trip, the ABI's
+    error codes for unknown names and wrong counts -- on a context that owns no GPU, so the uniform table runs on the CPU box (and under
+    ASan / UBSan: make sanitize-host).  Entry points that need the device fail loudly on such a context."""
+    from godot_atmosphere_shader_amd import _native as N
+
+    lib, ctx = _host_ctx(N.VARIANT_CLOUDS_HIGH_RM)
+    defaults = {"u_planet_radius": [1.0], "u_atmosphere_height": [0.1], "u_density": [0.2], "u_scattering_strength": [20.0],
+                "u_scattering_wavelengths": [700.0, 530.0, 440.0], "u_atmosphere_modulate": [1.0, 1.0, 1.0],
+                "u_atmosphere_ambient_color": [0.0, 0.0, 0.002 / 12.92], "u_sphere_depth_factor": [0.0], "u_cloud_density_scale": [50.0],
+                "u_cloud_bottom": [0.2], "u_cloud_top": [0.5], "u_cloud_blend": [0.5], "u_cloud_shape_invert": [0.0], "u_cloud_coverage_bias": [0.0],
+                "u_cloud_shape_factor": [0.8], "u_cloud_shape_scale": [1.0], "u_cloud_coverage_rotation": [1.0, 0.0, 0.0, 1.0],
+                "u_world_to_model_matrix": list(np.eye(4).reshape(-1)), "u_day_night_transition_scale": [2.0], "u_sun_position": [0.0, 0.0, 0.0],
+                "u_clip_mode": [0.0], "u_day_color0": [0.21404114, 0.60382734, 1.0, 1.0], "u_night_color1": [0.03310477, 0.13286832, 0.60382734, 1.0]}
+    rng = np.random.default_rng(2)
+    for name, want in defaults.items():
+        n = len(want)
+        buf = (C.c_float * n)()
+        assert lib.atmo_get_param_f32(ctx, name.encode(), buf, n) == N.ATMO_OK, name
+        assert list(buf) == pytest.approx(want, rel=1e-6, abs=0), name
+        new = rng.random(n).astype(np.float32)
+        assert lib.atmo_set_param_f32(ctx, name.encode(), (C.c_float * n)(*new), n) == N.ATMO_OK
+        assert lib.atmo_get_param_f32(ctx, name.encode(), buf, n) == N.ATMO_OK and np.array_equal(np.array(buf, dtype=np.float32), new)
+        for wrong in {1, 2, 3, 4, 16} - {n}:
+            assert lib.atmo_set_param_f32(ctx, name.encode(), (C.c_float * 16)(), wrong) == N.ATMO_E_ARG
+            assert lib.atmo_get_param_f32(ctx, name.encode(), (C.c_float * 16)(), wrong) == N.ATMO_E_ARG
+    one = (C.c_float * 1)(1.0)
+    assert lib.atmo_set_param_f32(ctx, b"u_nope", one, 1) == N.ATMO_E_NAME and b"u_nope" in lib.atmo_last_error_string(ctx)
+    assert lib.atmo_get_param_f32(ctx, b"", one, 1) == N.ATMO_E_NAME and lib.atmo_set_param_f32(ctx, None, one, 1) == N.ATMO_E_NAME
+    assert lib.atmo_set_param_f32(ctx, b"u_density", None, 1) == N.ATMO_E_ARG
+    # switches that live on the host
+    assert lib.atmo_set_precision(ctx, 3) == N.ATMO_E_ARG and lib.atmo_set_precision(ctx, 0) == N.ATMO_OK and lib.atmo_set_precision(ctx, 1) == N.ATMO_OK
+    assert lib.atmo_set_sampler_lod(ctx, 2) == N.ATMO_E_ARG and lib.atmo_set_sampler_lod(ctx, 0) == N.ATMO_OK
+    assert lib.atmo_set_tile_feedback(ctx, 5) == N.ATMO_E_ARG and lib.atmo_set_tile_feedback(ctx, 0) == N.ATMO_OK
+    assert lib.atmo_set_target_cleared(ctx, 1) == N.ATMO_OK and lib.atmo_set_host_double_precision(ctx, 1) == N.ATMO_OK
+    w = C.c_int(-1)
+    assert lib.atmo_get_texture_size(ctx, b"u_cloud_shape_texture", C.byref(w), None, None, None) == N.ATMO_OK and w.value == 0
+    assert lib.atmo_get_texture_size(ctx, b"u_bogus", C.byref(w), None, None, None) == N.ATMO_E_NAME
+    n = C.c_uint(7)
+    assert lib.atmo_get_host_wait_stats(ctx, C.byref(n)) == N.ATMO_OK and n.value == 0
+    # anything that needs the device fails loudly (no fallback)
+    f = N.AtmoFrame()
+    f.viewport_w = f.viewport_h = f.x1 = f.y1 = 8
+    if not _has_gpu():
+        assert lib.atmo_bake_optical_depth(ctx, None) in (N.ATMO_E_HIP, N.ATMO_E_NO_DEVICE)
+    assert lib.atmo_render(ctx, C.byref(f), None, None, None) in (N.ATMO_E_ARG, N.ATMO_E_STATE)
+    assert lib.atmo_destroy(ctx) == N.ATMO_OK
+    bad = C.c_void_p()
+    assert lib.atmo_debug_create_host_only(9, 0, 0, 0, 0, C.byref(bad)) == N.ATMO_E_ARG and not bad.value
+    assert lib.atmo_debug_create_host_only(0, 0, 0, N.LIGHT_DIRECT, 0, C.byref(bad)) == N.ATMO_E_ARG
+
+
+def test_per_frame_constants_follow_the_shader_text():
+    """fill_consts (csrc/atmo_api.hip) evaluates the pixel-independent expressions of the shader once per draw, in fp32 and in the reference's
+    operation order: held here, bit for bit, against a numpy float32 restatement written from the shader text -- camera position (main:136),
+    sun direction (main:164), Rayleigh coefficients (v2:47-51), the cloud shell radii (clouds:260-261), view -> model transform (clouds:285-288),
+    the march-distance cap (clouds:186-202), the raymarched light's tap schedule (clouds:108-115,129,138,143) -- and the level-0 certificate's
+    constant against its formula, including ADVICE r4's contracting matrix."""
+    from godot_atmosphere_shader_amd import _native as N
+    from godot_atmosphere_shader_amd.planet_atmosphere import _to_native_frame, make_frame
+
+    F = np.float32
+    rng = np.random.default_rng(11)
+    for trial in range(12):
+        lib, ctx = _host_ctx(N.VARIANT_CLOUDS_HIGH_RM, cloud_steps=[0, 64, 200, 1][trial % 4])
+        R, H = F(rng.choice([1.0, 100.0, 637.1])), None
+        H = F(R * F(rng.uniform(0.03, 0.3)))
+        cb, ct = F(rng.uniform(0.05, 0.3)), F(rng.uniform(0.4, 0.9))
+        lam = rng.uniform(400, 750, 3).astype(F)
+        strength, dscale = F(rng.uniform(0.5, 30)), F(rng.uniform(1, 80))
+        a = rng.uniform(0, 6.28)
+        rot = [np.array([np.cos(a), np.sin(a), -np.sin(a), np.cos(a)]), np.array([0.6, 0.0, 0.0, 0.6]), np.array([1.0, 0.25, 0.0, 1.0]),
+               np.array([0.3, 0.0, 0.0, 3.0])][trial % 4].astype(F)
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        model = np.eye(4)
+        model[:3, :3], model[:3, 3] = q, rng.normal(size=3) * float(R)
+        w2m = np.linalg.inv(model)
+        for name, v in (("u_planet_radius", [R]), ("u_atmosphere_height", [H]), ("u_cloud_bottom", [cb]), ("u_cloud_top", [ct]),
+                        ("u_scattering_wavelengths", lam), ("u_scattering_strength", [strength]), ("u_cloud_density_scale", [dscale]),
+                        ("u_cloud_coverage_rotation", rot), ("u_world_to_model_matrix", S.col_major(w2m))):
+            v = np.asarray(v, dtype=F)
+            assert lib.atmo_set_param_f32(ctx, name.encode(), (C.c_float * len(v))(*v), len(v)) == N.ATMO_OK
+        eye = rng.normal(size=3)
+        eye = eye / np.linalg.norm(eye) * float(R) * rng.uniform(1.02, 3.0)
+        cam = S.Camera(160, 90, eye=eye, target=model[:3, 3] * 0.1, near=0.05, far=50.0 * float(R))
+        sun = tuple((rng.normal(size=3) * 50 * float(R)).tolist())
+        frame = _to_native_frame(make_frame(cam, model, sun))
+        cnt = C.c_int()
+        cube_n = [256, 1024, 17, 4][trial % 4]
+        assert lib.atmo_debug_frame_constants(ctx, C.byref(frame), cube_n, None, 0, C.byref(cnt)) == N.ATMO_OK and cnt.value == 81
+        out = (C.c_float * 81)()
+        assert lib.atmo_debug_frame_constants(ctx, C.byref(frame), cube_n, out, 80, None) == N.ATMO_E_ARG
+        assert lib.atmo_debug_frame_constants(ctx, C.byref(frame), cube_n, out, 81, None) == N.ATMO_OK
+        got = np.array(out, dtype=F)
+        V = np.array(frame.inv_view_matrix, dtype=F)            # column-major
+        pc, sc = np.array(frame.planet_center_viewspace, dtype=F), np.array(frame.sun_center_viewspace, dtype=F)
+        # main:136  inv_view * vec4(0, 0, 0, 1), summed left to right
+        cam_pos = np.array([F(F(F(V[r] * F(0)) + F(V[4 + r] * F(0))) + F(V[8 + r] * F(0))) + F(V[12 + r] * F(1)) for r in range(3)], dtype=F)
+        assert np.array_equal(got[0:3], cam_pos)
+        d = (sc - pc).astype(F)                                   # main:164 normalize = v * (1 / sqrt(dot))
+        inv = F(1) / np.sqrt(F(F(F(d[0] * d[0]) + F(d[1] * d[1])) + F(d[2] * d[2])))
+        sun_dir = (d * inv).astype(F)
+        assert np.array_equal(got[3:6], sun_dir)
+        assert got[6] == F(R + H)
+        pow4 = lambda x: F(F(F(x * x) * x) * x)                   # util.gdshaderinc pow4
+        assert np.array_equal(got[7:10], np.array([F(pow4(F(F(400) / l)) * strength) for l in lam], dtype=F))
+        bottom, top = F(R + F(cb * H)), F(R + F(ct * H))          # clouds:260-261
+        assert (got[10], got[11], got[12], got[13]) == (bottom, top, F(top - bottom), F(F(1) / F(top - bottom)))
+        A = np.asarray(S.col_major(w2m), dtype=F)                 # clouds:285  u_world_to_model_matrix * INV_VIEW_MATRIX
+        M = np.zeros(16, dtype=F)
+        for col in range(4):
+            for row in range(4):
+                M[col * 4 + row] = F(F(F(A[row] * V[col * 4]) + F(A[4 + row] * V[col * 4 + 1])) + F(A[8 + row] * V[col * 4 + 2])) + F(A[12 + row] * V[col * 4 + 3])
+        assert np.array_equal(got[18:34], M)
+        origin = np.array([F(F(F(M[r] * F(0)) + F(M[4 + r] * F(0))) + F(M[8 + r] * F(0))) + F(M[12 + r] * F(1)) for r in range(3)], dtype=F)
+        sun_m = np.array([F(F(F(M[r] * sun_dir[0]) + F(M[4 + r] * sun_dir[1])) + F(M[8 + r] * sun_dir[2])) + F(M[12 + r] * F(0)) for r in range(3)], dtype=F)
+        assert np.array_equal(got[34:37], origin) and np.array_equal(got[37:40], sun_m)
+        # clouds:186-202  the march-distance cap
+        gt = F(R / top)
+        space = F(F(F(0.5) * np.sqrt(F(F(1) - F(gt * gt)))) * bottom)
+        groundd = F(F(3) * space)
+        ln = np.sqrt(F(F(F(origin[0] * origin[0]) + F(origin[1] * origin[1])) + F(origin[2] * origin[2])))
+        t = np.clip(F(F(ln - bottom) / F(F(top * F(1.05)) - bottom)), F(0), F(1))
+        sm = F(F(t * t) * F(F(3) - F(F(2) * t)))
+        assert got[40] == F(F(groundd * F(F(1) - sm)) + F(space * sm))
+        steps = [64, 64, 200, 1][trial % 4]
+        assert got[41] == F(F(1) / F(steps))
+        # clouds:104-151  get_light_raymarched: step_len grows x 1.2 after every tap
+        step_len = F(F(F(top - bottom) * F(0.15)) * F(F(1) / F(6)))
+        for i in range(6):
+            off = F(F(i) * step_len)
+            assert got[42 + i] == off and got[48 + i] == F(step_len * dscale)
+            assert np.array_equal(got[54 + 3 * i:57 + 3 * i], (off * sun_m).astype(F))
+            step_len = F(step_len * F(1.2))
+        # the level-0 certificate: 1 / C, C = 0.97 * 4 (1 - 2/n)^2 / (n max(sigma, 1))^2; withheld (inf) off the fast path, for tiny faces,
+        # and when a singular value of the coverage matrix leaves [0.5, 2]
+        sv = np.linalg.svd(np.array([[rot[0], rot[2]], [rot[1], rot[3]]], dtype=np.float64), compute_uv=False)
+        offered = cube_n in (256, 1024, 4) and sv.max() <= 2.0 and sv.min() >= 0.5
+        if offered:
+            want = 1.0 / (0.97 * 4.0 * (1.0 - 2.0 / cube_n) ** 2 / (cube_n * max(sv.max(), 1.0)) ** 2)
+            assert got[72] == pytest.approx(want, rel=3e-6), (trial, got[72], want)
+        else:
+            assert np.isinf(got[72])
+        assert got[73] == F(steps - 1) and got[74] == pytest.approx((steps + 1) * 2.07e-7, rel=1e-6)
+        assert got[76] == F(F(1) / F(160)) and got[77] == F(F(1) / F(90))
+        assert lib.atmo_destroy(ctx) == N.ATMO_OK

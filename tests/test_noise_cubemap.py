@@ -124,7 +124,7 @@ def test_generated_cubemap_as_coverage(oracle32):
     import ctypes as C
 
     import torch
-    from common import CONFIGS, TOL, demo_frame, demo_params, demo_textures, make_node
+    from common import CONFIGS, TOL, demo_frame, demo_params, demo_textures, kernel_flags, make_node, oracle_inputs
     from godot_atmosphere_shader_amd import NoiseCubemap
     from godot_atmosphere_shader_amd import _native as N
 
@@ -136,12 +136,15 @@ def test_generated_cubemap_as_coverage(oracle32):
     depth_np = S.depth_ground_sphere(cam)
     depth = torch.from_numpy(depth_np).cuda()
     lut = oracle32.bake_optical_depth(100.0, 8.0, 0.5)
-    want, _ = oracle32.render(params, dict(tex_o, optical_depth=lut), CONFIGS["clouds_high"][1], demo_frame(cam), depth_np, nthreads=8)
+    # the node's default sampler is the declared one (the generator builds the mip chain, noise_cubemap.gd:107,135): same rule in the checker
+    ocfg, otex = oracle_inputs(oracle32, CONFIGS["clouds_high"][1], tex_o, lut, declared=True)
+    want, _ = oracle32.render(params, otex, ocfg, demo_frame(cam), depth_np, nthreads=8)
 
     res = NoiseCubemap(noise=SeededValueNoise(21, 0.03, 4, 0.5), resolution=128, scale=case["scale"])
     node = make_node("clouds_high", dict(tex, cubemap=None), params)
     node.set_shader_parameter("u_cloud_coverage_cubemap", res)   # the resource itself, as in the demo scene
     got = node.render(cam, depth).cpu().numpy()
+    assert kernel_flags(node) & 32
     assert np.abs(got - want).max() <= TOL
     # bind on the device through the C ABI
     sc = (C.c_float * 3)(*case["scale"])

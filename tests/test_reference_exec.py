@@ -257,6 +257,31 @@ def test_oracle_equals_reference_with_the_declared_sampler_at_baseline_sizes(ora
     assert worst <= ORACLE_TOL, f"{shader} {w}x{h} {pose}: oracle (implicit LOD) vs executed reference {worst:.3e}"
 
 
+# ---- round 5 vectors (reference_exec_r5.npz): the declared sampler on every cloud row of FULL_SIZE -------------------------------------
+@pytest.fixture(scope="module")
+def r5():
+    return np.load(os.path.join(GOLDEN, "reference_exec_r5.npz"))
+
+
+@pytest.mark.parametrize("case", RS.LOD_FULL_SIZE_R5, ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}-{c[3]}")
+def test_oracle_equals_reference_with_the_declared_sampler_on_all_baseline_rows(oracle32, vectors, r5, case):
+    """the kernels bench.py reports for configs[2] / configs[3] are the declared-sampler ones; the executed-reference rows
+    under that sampler grow from round 3's 7 to the 25 cloud rows of FULL_SIZE (limb rows of P_space included), 78 720 pixels of reference text."""
+    shader, w, h, pose, _ = case
+    tex, cam, rows, depth, want = _lod_full_case(vectors, r5, case)
+    assert rows == list(case[4])
+    tex = dict(tex, cubemap=oracle32.cubemap_mip_chain(tex["cubemap"]))
+    frame = make_frame(cam, np.eye(4), S.DEMO_SUN_POSITION, 0.0)
+    params, _ = _scene("demo")
+    cfg = dict(RS.VARIANTS[shader], cube_lod=1)
+    worst = 0.0
+    for k, r in enumerate(rows):
+        got, _ = oracle32.render(params, dict(tex, optical_depth=vectors["lut_demo"]), cfg, frame, depth, rect=(0, r, w, r + 1), nthreads=4)
+        assert np.array_equal(np.all(got[0] == 0.0, axis=-1), np.all(want[k] == 0.0, axis=-1)), r
+        worst = max(worst, _rel_err(got[0], want[k]))
+    assert worst <= ORACLE_TOL, f"{shader} {w}x{h} {pose}: oracle (implicit LOD) vs executed reference {worst:.3e}"
+
+
 @pytest.mark.parametrize("steps", RS.VIEW_STEP_COUNTS)
 def test_oracle_equals_reference_at_32_and_64_view_steps(oracle32, vectors, r3, textures, steps):
     """north_star's 32 view steps (and the 64 atmosphere_funcs_v2.gdshaderinc:42-43 names for gas giants) through the reference
@@ -553,7 +578,7 @@ def test_hip_bake_equals_reference_bake(vectors, textures, sname):
 def test_hip_equals_reference_fragment(vectors, textures, sname, shader):
     """The product path (PlanetAtmosphere node -> C ABI -> gfx950 kernels) against the executed reference, all poses."""
     params, model = _scene(sname)
-    node = make_node(NODE_CONFIG[shader], textures, params)
+    node = make_node(NODE_CONFIG[shader], textures, params, sampler="lod0")   # reference_exec.npz: the text executed with the level-0 sampler
     node.global_transform = model
     worst = 0.0
     for pose in RS.POSES:
@@ -577,7 +602,7 @@ def test_hip_equals_reference_at_baseline_sizes(vectors, case):
     shader, w, h, pose, _ = case
     tex, cam, rows, depth, want = _full_case(vectors, shader, w, h, pose)
     params, _ = _scene("demo")
-    node = make_node(NODE_CONFIG[shader], tex, params)
+    node = make_node(NODE_CONFIG[shader], tex, params, sampler="lod0")   # FULL_SIZE rows: level-0 sampler; LOD_FULL_SIZE below: the declared one
     got = _gpu_render(node, cam, depth)[rows]
     node.close()
     err = float(np.abs(got - want).max())
@@ -684,7 +709,7 @@ def test_hip_equals_reference_with_the_declared_cubemap_sampler(vectors, r3, tex
     """atmo_set_sampler_lod(ctx, 1) -- the reference's declared linear-mipmap samplerCube -- against the reference text executed
     with such a sampler (quad derivatives from the interpreter's SIMT lanes); the mip chain is generated on the device."""
     params, model = _scene("demo")
-    node = make_node(NODE_CONFIG[shader], textures, params, cubemap_lod=True)
+    node = make_node(NODE_CONFIG[shader], textures, params)   # the library's default sampler
     worst = 0.0
     for pose in RS.LOD_POSES:
         cam = RS.camera_from_fixture(vectors, RS.W, RS.H, pose)
@@ -704,12 +729,32 @@ def test_hip_equals_reference_with_the_declared_sampler_at_baseline_sizes(vector
     shader, w, h, pose, _ = case
     tex, cam, rows, depth, want = _lod_full_case(vectors, r3, case)
     params, _ = _scene("demo")
-    node = make_node(NODE_CONFIG[shader], tex, params, cubemap_lod=True)
+    node = make_node(NODE_CONFIG[shader], tex, params)   # the library's default sampler: kernels <49, 0, 1> / <51, 0, 1>
+    assert int(node.kernel_name.split("<")[1].split(",")[0]) & 32
     got = _gpu_render(node, cam, depth)[rows]
     node.close()
     assert np.array_equal(np.all(got == 0.0, axis=-1), np.all(want == 0.0, axis=-1))
     err = _rel_err(got, want)
     print(f"{shader} {w}x{h} {pose}: max |HIP (implicit LOD) - executed reference| = {err:.3e} over {want.shape[0] * want.shape[1]} pixels")
+    assert err <= TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", RS.LOD_FULL_SIZE_R5, ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}-{c[3]}")
+def test_hip_default_kernels_equal_reference_on_all_baseline_rows(vectors, r5, case):
+    """The library's DEFAULT kernels for BASELINE configs[2] / configs[3] -- <49, 0, 1> / <51, 0, 1>, the declared sampler -- draw the full
+    1920x1080 / 3840x2160 frame; all 25 rows the reference text was executed on under that sampler are compared."""
+    shader, w, h, pose, _ = case
+    tex, cam, rows, depth, want = _lod_full_case(vectors, r5, case)
+    params, _ = _scene("demo")
+    node = make_node(NODE_CONFIG[shader], tex, params)
+    name = node.kernel_name
+    assert name.startswith("atmo_render_kernel<51, 0," if shader.endswith("_rm") else "atmo_render_kernel<49, 0,")
+    got = _gpu_render(node, cam, depth)[rows]
+    node.close()
+    assert np.array_equal(np.all(got == 0.0, axis=-1), np.all(want == 0.0, axis=-1))
+    err = _rel_err(got, want)
+    print(f"\n{shader} {w}x{h} {pose} {name}: max |HIP (default kernel) - executed reference| = {err:.3e} over {want.shape[0] * want.shape[1]} pixels")
     assert err <= TOL
 
 
@@ -764,7 +809,7 @@ def test_hip_reference_order_march_equals_the_executed_reference_to_2e_6(vectors
     # the cloud variants (precise cloud density + the reference-order atmosphere under it), demo scene
     for shader in ("planet_atmosphere_clouds", "planet_atmosphere_clouds_high", "planet_atmosphere_clouds_high_rm"):
         params, model = _scene("demo")
-        node = make_node(NODE_CONFIG[shader], textures, params, precise_atmosphere=True)
+        node = make_node(NODE_CONFIG[shader], textures, params, precise_atmosphere=True, sampler="lod0")
         node.global_transform = model
         for pose in RS.POSES:
             cam = RS.camera_from_fixture(vectors, RS.W, RS.H, pose)
@@ -780,7 +825,7 @@ def test_hip_reference_order_march_equals_the_executed_reference_to_2e_6(vectors
     lod = {}
     for shader in ("planet_atmosphere_clouds_high", "planet_atmosphere_clouds_high_rm"):
         params, model = _scene("demo")
-        node = make_node(NODE_CONFIG[shader], textures, params, cubemap_lod=True, precise_atmosphere=True)
+        node = make_node(NODE_CONFIG[shader], textures, params, precise_atmosphere=True)
         for pose in RS.LOD_POSES:
             cam = RS.camera_from_fixture(vectors, RS.W, RS.H, pose)
             got = _gpu_render(node, cam, vectors[f"depth_demo_{pose}"])

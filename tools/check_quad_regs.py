@@ -4,7 +4,8 @@
 The exchange blocks run a few instructions in whole-quad mode (s_wqm_b64 exec, exec): lanes the compiler believes inactive WRITE the
 blocks' destination registers.  That is only safe if those registers hold nothing else, for any lane, anywhere in the kernel -- which
 the source arranges by making them read-write operands whose live range spans the kernel.  This script verifies it in the ISA hipcc
-emits: in every kernel that contains an exchange block, the VGPRs written inside the blocks are written by NO instruction outside them.
+emits: in every kernel that contains an exchange block, the VGPRs written inside the blocks are written by NO instruction outside them; and the VGPRs the blocks READ (the lane's march position,
+which helper lanes read as well) are written inside the march's loop nest by nothing but the march's own position update (round 5).
 
 It also verifies that no kernel of the file has a stack frame (ScratchSize 0, no scratch_load / scratch_store).
 
@@ -48,6 +49,79 @@ def written(line: str):
     return vgprs(rest.split(",")[0].strip())
 
 
+def read_regs(line: str):
+    """VGPRs an instruction reads: every operand after the first (the first as well for stores and DPP moves' sources are operands 2..)."""
+    parts = line.split(None, 1)
+    if len(parts) < 2:
+        return set()
+    toks = [t.strip().split()[0] for t in parts[1].split(",") if t.strip()]
+    regs = set()
+    for t in toks[1:]:
+        regs |= vgprs(t.strip("|-"))
+    return regs
+
+
+_BB = re.compile(r"^(\.LBB\d+_\d+:|; %bb\.\d+:)")
+
+
+def check_inputs(body: str, private: set):
+    """the helper lanes a whole-quad block re-enables READ the block's input VGPRs (the lane's own march position) -- lanes the
+    compiler believes inactive.  That is only right if those registers hold the position for EVERY lane that marches, i.e. if inside the march
+    loop nest they are written by nothing but the march's own position update (`v_add_f32 R, step, R`, executed by all marching lanes): a copy
+    made inside a divergent region (a split live range: `v_mov_b32 R', R` under a narrowed EXEC, the block then reading R') would leave the helper
+    lanes with a stale R'.  Returns (input registers, offending lines)."""
+    lines = body.split("\n")
+    # basic blocks: (first line, in a loop?)
+    starts = [i for i, ln in enumerate(lines) if _BB.match(ln.strip())]
+    def in_loop(i):  # the label line and the comment lines that continue it
+        txt = lines[i]
+        j = i + 1
+        while j < len(lines) and lines[j].strip().startswith(";") and not _BB.match(lines[j].strip()):
+            txt += lines[j]
+            j += 1
+        return "Loop" in txt
+    blocks_at, inside, inputs = [], False, set()
+    for i, raw in enumerate(lines):
+        ln = raw.strip()
+        if ln.startswith(";;#ASMSTART"):
+            inside, cur, first = True, [], i
+        elif ln.startswith(";;#ASMEND"):
+            inside = False
+            if any("s_wqm_b64" in c for c in cur):
+                blocks_at.append(first)
+                for c in cur:
+                    inputs |= read_regs(c) - private
+        elif inside:
+            cur.append(ln)
+    if not blocks_at:
+        return set(), []
+    # the march's loop nest: the run of basic blocks annotated as inside a loop around the first .. last exchange block
+    bb_of = lambda line: max([k for k in range(len(starts)) if starts[k] <= line], default=0)
+    lo, hi = bb_of(blocks_at[0]), bb_of(blocks_at[-1])
+    while lo > 0 and in_loop(starts[lo - 1]):
+        lo -= 1
+    while hi + 1 < len(starts) and in_loop(starts[hi + 1]):
+        hi += 1
+    first_line = starts[lo]
+    last_line = starts[hi + 1] if hi + 1 < len(starts) else len(lines)
+    bad, inside = [], False
+    for i in range(first_line, last_line):
+        ln = lines[i].strip()
+        if ln.startswith(";;#ASMSTART"):
+            inside = True
+        elif ln.startswith(";;#ASMEND"):
+            inside = False
+        if inside or not ln or ln.startswith((";", ".")) or ln.endswith(":"):
+            continue
+        w = written(ln) & inputs
+        if not w:
+            continue
+        op = ln.split(None, 1)[0]
+        if not (op.startswith("v_add_f32") and w <= read_regs(ln)):   # the position update reads what it writes
+            bad.append(ln)
+    return inputs, bad
+
+
 def check(asm_text: str):
     results = {}
     for m in re.finditer(r"^(_ZN4atmo\w+):[^\n]*\n(.*?)\n\s*s_endpgm", asm_text, re.S | re.M):
@@ -74,7 +148,8 @@ def check(asm_text: str):
                 continue
             (block if inside else outside_lines).append(line)
         bad = [ln for ln in outside_lines if written(ln) & private]
-        results[name] = (blocks, sorted(private), bad)
+        inputs, bad_inputs = check_inputs(body, private)
+        results[name] = (blocks, sorted(private), bad, sorted(inputs), bad_inputs)
     return results
 
 
@@ -84,10 +159,12 @@ def main(argv):
     res = check(open(out).read())
     names = subprocess.run(["c++filt"] + list(res), capture_output=True, text=True).stdout.split("\n") if res else []
     ok = bool(res)
-    for (name, (blocks, private, bad)), nice in zip(res.items(), names):
+    for (name, (blocks, private, bad, inputs, bad_inputs)), nice in zip(res.items(), names):
         nice = nice.replace("void atmo::", "").replace("(atmo::RenderConsts)", "")
-        print(f"{nice:44s} {blocks} exchange blocks, {len(private)} private VGPRs: " + ("ok" if not bad else f"{len(bad)} OUTSIDE WRITES, e.g. {bad[0]}"))
-        ok = ok and not bad and blocks > 0
+        print(f"{nice:44s} {blocks} exchange blocks, {len(private)} private VGPRs: " + ("ok" if not bad else f"{len(bad)} OUTSIDE WRITES, e.g. {bad[0]}")
+              + f"; {len(inputs)} input VGPRs {['v%d' % r for r in inputs]}: "
+              + ("only the position update writes them in the march" if not bad_inputs else f"{len(bad_inputs)} OTHER WRITES IN THE MARCH, e.g. {bad_inputs[0]}"))
+        ok = ok and not bad and blocks > 0 and not bad_inputs and 3 <= len(inputs) <= 7   # the position, and the coverage rotation where it lives in VGPRs
     if not res:
         print("no kernel contains an exchange block")
     # and, for every kernel of the file: no stack.  A frame object -- even a dead spill slot of a rematerialised kernel-argument tuple, with no
