@@ -173,12 +173,23 @@ struct AtmoContext {
     uint32_t *measure_cost = nullptr;                  // atmo_measure_tile_costs: the next draw records here
     // the streams draws of this context have been enqueued on since the last texture update waited for them: an update arriving on
     // stream s is stream-ordered behind the draws on s and has to wait, on the host, for those on every OTHER stream of this set
-    std::vector<hipStream_t> draw_streams;             // (at most 8 remembered; beyond that `draw_streams_many` stands for "some other stream")
+    // A remembered stream OTHER than the context's home stream (= the stream of its most recent texture update: where a single-stream host
+    // does everything, and stream order is all it needs) carries a MARKER EVENT recorded behind its most recent draw (round 5): whoever
+    // must be ordered behind those draws waits for the event on the device -- the stream's handle is never touched again, so a stream the
+    // caller has destroyed since is harmless (HIP dereferences stale stream handles: hipEventRecord on one crashes).  Not on the home
+    // stream: a marker costs 3-4 us per draw (profiles/round5/ab_draw_events.txt: headline -4 %, shipped8 -17 %).
+    struct DrawStream { hipStream_t stream = nullptr; hipEvent_t last_draw = nullptr; bool recorded = false; unsigned long long last_use = 0; };
+    unsigned long long draw_stream_clock = 0;
+    std::vector<DrawStream> draw_streams;              // (at most 8 remembered; beyond that `draw_streams_many` stands for "some other stream")
     bool draw_streams_many = false;
-    hipEvent_t xs_event[8] = {nullptr};                // order_after_stream: one marker per remembered stream (a wait captures the record in front of it)
+    int draw_events = 1;                               // ATMO_DRAW_EVENTS=0 (A/B): no markers, the waits fall back to hipDeviceSynchronize; 2: markers on the home stream too
+    hipEvent_t xs_event[8] = {nullptr};                // order_after_stream: markers on the context's OWN streams (sort stream, staging stream)
     unsigned xs_next = 0;
     unsigned device_syncs = 0;                         // how often a call of this context fell back to hipDeviceSynchronize (atmo_get_host_wait_stats)
     DeviceBuffer measure_buf;                          // atmo_measure_tile_costs: the tile costs on their way to the host (grow-only)
+    // atmo_render_tiles: the caller's tile list, bounded on the device before the draw reads it (one grow-only copy per draw stream, up to 4)
+    struct TileListBuf { hipStream_t stream = nullptr; DeviceBuffer buf; bool used = false; unsigned long long last_use = 0; } tile_lists[4];
+    unsigned long long tile_list_clock = 0;
 #ifdef ATMO_WAVE_TRACE
     DeviceBuffer wave_trace;                           // diagnostic build only
     size_t wave_trace_waves = 0;
@@ -545,10 +556,10 @@ float feedback_motion_px(const AtmoFrame &a, const AtmoFrame &b, float radius, b
 // Orders everything enqueued on `waiter` from now on behind everything enqueued on `other` so far -- on the DEVICE: a marker event recorded
 // on `other`, a stream-side wait on `waiter`; the host does not block and no other queue of the process is involved (round 4 called
 // hipDeviceSynchronize in these places, which stalls every stream of the engine: VERDICT r4 weak #11).
-// `other` is a handle this context merely remembered: the caller may have destroyed that stream since.  HIP validates stream handles against
-// its table of live streams (a stale one fails with hipErrorContextIsDestroyed / hipErrorInvalidHandle instead of being dereferenced); work
-// that was pending on a destroyed stream still runs and can only be waited for device-wide -- that, and more distinct streams than this
-// context tracks, are the two cases left in which a call falls back to hipDeviceSynchronize (counted: atmo_get_host_wait_stats).
+// ONLY for an `other` that is known to be alive: a stream the context owns (its sort stream) or one the caller handed to the call in
+// progress.  A stream the context merely REMEMBERS may have been destroyed by the caller since, and HIP dereferences stale stream handles
+// (hipEventRecord on one crashes the process: round 5, first attempt) -- draws on remembered streams are waited for through the marker
+// event recorded behind them at draw time instead (order_after_draws).
 int order_after_stream(AtmoContext *ctx, hipStream_t waiter, hipStream_t other) {
     if (waiter == other) return ATMO_OK;
     hipEvent_t &ev = ctx->xs_event[ctx->xs_next++ % 8u];
@@ -563,6 +574,29 @@ int order_after_stream(AtmoContext *ctx, hipStream_t waiter, hipStream_t other) 
     return ATMO_OK;
 }
 
+// Orders `waiter` behind the draws this context has enqueued on the remembered stream `d` (its marker event; no use of d's handle).
+int order_after_draws(AtmoContext *ctx, hipStream_t waiter, const AtmoContext::DrawStream &d) {
+    if (d.stream == waiter) return ATMO_OK;   // stream order
+    if (d.recorded && d.last_draw) {
+        HIP_TRY(ctx, hipStreamWaitEvent(waiter, d.last_draw, 0));
+        return ATMO_OK;
+    }
+    if (d.stream == nullptr) return order_after_stream(ctx, waiter, nullptr);   // the null stream cannot have been destroyed
+    // draws without a marker on a stream that may be gone: the home stream of a host that has just moved its texture updates to another
+    // stream (or ATMO_DRAW_EVENTS=0) -- the device-wide wait of rounds 3-4, once per such move
+    ctx->device_syncs += 1;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return ATMO_OK;
+}
+int order_after_draws_on(AtmoContext *ctx, hipStream_t waiter, hipStream_t drawn_on) {
+    if (drawn_on == waiter) return ATMO_OK;
+    for (const AtmoContext::DrawStream &d : ctx->draw_streams)
+        if (d.stream == drawn_on) return order_after_draws(ctx, waiter, d);
+    ctx->device_syncs += 1;   // a stream this context no longer remembers (more than 8 in use)
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return ATMO_OK;
+}
+
 // Makes sure nothing enqueued earlier can still touch the buffers of feedback state `f` (its pending sort; draws on its stream reading an
 // order) once work enqueued on `new_stream` from now on runs: stream-side waits, the host does not block.  Only needed when the slot is
 // recycled for another key.  (A buffer that has to GROW is freed, and hipFree waits for the device by itself.)
@@ -572,7 +606,7 @@ int feedback_quiesce(AtmoContext *ctx, AtmoContext::FeedbackState &f, hipStream_
         if (rc0 != ATMO_OK) return rc0;
     }
     if ((f.n > 0 || f.dirty) && f.draw_stream != new_stream) {
-        const int rc0 = order_after_stream(ctx, new_stream, f.draw_stream);
+        const int rc0 = order_after_draws_on(ctx, new_stream, f.draw_stream);
         if (rc0 != ATMO_OK) return rc0;
     }
     f.pending = false;
@@ -714,6 +748,7 @@ int atmo_create(int device, int variant, int view_steps, int cloud_steps, int li
     if (const char *ev = std::getenv("ATMO_TILE_FEEDBACK")) ctx->env_feedback = ev[0] == '1' ? 1 : 0;
     if (const char *ev = std::getenv("ATMO_F4")) ctx->f4_footprints = std::atoi(ev) & 3;
     if (const char *ev = std::getenv("ATMO_LOD0_CERT")) ctx->env_lod0_cert = ev[0] == '0' ? 0 : 1;
+    if (const char *ev = std::getenv("ATMO_DRAW_EVENTS")) ctx->draw_events = ev[0] == '0' ? 0 : (ev[0] == '2' ? 2 : 1);
     if (const char *ev = std::getenv("ATMO_TARGET_CLEARED")) ctx->target_cleared = ev[0] == '1' ? 1 : 0;  // tools/ab_env.sh: atmo_set_target_cleared
     if (const char *ev = std::getenv("ATMO_FB_INSTREAM")) ctx->instream = ev[0] >= '1' && ev[0] <= '2' ? ev[0] - '0' : 0;  // 2 (A/B): every cloud and direct-light kernel
     if (const char *ev = std::getenv("ATMO_FB_AXIS_WINDOWS")) ctx->fb_axis_windows = ev[0] == '1' ? 1 : 0;
@@ -752,8 +787,11 @@ int atmo_destroy(AtmoContext *ctx) {
     dev_free(ctx->shape_f4);
     dev_free(ctx->staging);
     dev_free(ctx->measure_buf);
+    for (AtmoContext::TileListBuf &t : ctx->tile_lists) dev_free(t.buf);
     if (ctx->tex_event) (void)hipEventDestroy(ctx->tex_event);
     for (hipEvent_t &ev : ctx->xs_event) if (ev) (void)hipEventDestroy(ev);
+    for (AtmoContext::DrawStream &d : ctx->draw_streams) if (d.last_draw) (void)hipEventDestroy(d.last_draw);
+
     if (ctx->fb_stream) {
         (void)hipStreamSynchronize(ctx->fb_stream);
         (void)hipStreamDestroy(ctx->fb_stream);
@@ -801,10 +839,8 @@ int atmo_get_param_f32(AtmoContext *ctx, const char *name, float *v, int n) {
 // is safe on one stream; an update arriving on another stream first waits for the previous one.
 static int stage_texels(AtmoContext *ctx, const void *data, size_t bytes, int memory, hipStream_t s, size_t extra_bytes, uint8_t **out) {
     if (memory == ATMO_MEM_DEVICE && extra_bytes == 0) { *out = (uint8_t *)const_cast<void *>(data); return ATMO_OK; }
-    if (ctx->staging_used && ctx->staging_stream != s) {  // the previous update's kernels still read the staging buffer on their stream
-        const int rc0 = order_after_stream(ctx, s, ctx->staging_stream);
-        if (rc0 != ATMO_OK) return rc0;
-    }
+    // the previous update's kernels may still read the staging buffer on their stream: every update ends with tex_event recorded behind its
+    // last kernel (tex_updated), and tex_begin_update has already ordered `s` behind it -- nothing more to wait for here
     if (ctx->staging.bytes < bytes + extra_bytes) {  // (re-allocation: hipFree waits for the device by itself)
         const int rc = dev_alloc(ctx, ctx->staging, bytes + extra_bytes);
         if (rc != ATMO_OK) return rc;
@@ -847,9 +883,9 @@ static int tex_updated(AtmoContext *ctx, hipStream_t s) {
 //   * an earlier update on ANOTHER stream is chained in front (hipStreamWaitEvent on its event), so the updates of a
 //     context happen in call order whatever streams they come in on, and a draw on `s` that finds tex_stream == s is
 //     behind all of them;
-//   * draws still reading the bound copy on ANY other stream are ordered in front of the update ON THE DEVICE (order_after_stream: a
-//     marker on each such stream, a stream-side wait on `s`; round 5 -- rounds 3-4 waited device-wide on the host, which stalls every
-//     queue of the engine).  Every stream that has carried a draw since the last update counts, not only the most recent one (round 3
+//   * draws still reading the bound copy on ANY other stream are ordered in front of the update ON THE DEVICE (order_after_draws: the
+//     marker event recorded behind each stream's last draw, a stream-side wait on `s`; round 5 -- rounds 3-4 waited device-wide on the
+//     host, which stalls every queue of the engine).  Every stream that has carried a draw since the last update counts, not only the most recent one (round 3
 //     remembered one stream: with draws in flight on A and B, an update on B overwrote what A was still reading).  A context that has
 //     drawn on more streams than it tracks (8) falls back to the device-wide wait.  Updates are rare and normally arrive on the one
 //     draw stream, where stream order is enough and nothing is enqueued at all.
@@ -859,12 +895,13 @@ static int tex_begin_update(AtmoContext *ctx, hipStream_t s) {
         ctx->device_syncs += 1;
         HIP_TRY(ctx, hipDeviceSynchronize());
     } else {
-        for (hipStream_t d : ctx->draw_streams) {
-            const int rc0 = order_after_stream(ctx, s, d);
+        for (const AtmoContext::DrawStream &d : ctx->draw_streams) {
+            const int rc0 = order_after_draws(ctx, s, d);
             if (rc0 != ATMO_OK) return rc0;
         }
     }
-    ctx->draw_streams.clear();   // every earlier draw of this context is in front of the update now; later ones wait for tex_event (tex_order)
+    // every earlier draw of this context is in front of the update now; later ones wait for tex_event (tex_order).  The streams stay
+    // remembered with their markers: the feedback states and tile-list copies that drew on them are handed on behind those markers
     ctx->draw_streams_many = false;
     return ATMO_OK;
 }
@@ -1283,7 +1320,6 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     int gx = 0, gy = 0;
     atmo::render_grid(rc, split, &gx, &gy);
     rc.tiles_x = gx;
-    rc.tiles_n = (uint32_t)gx * (uint32_t)gy;
     // default (-1): on for every variant since the sort no longer costs the draws anything (profiles/round2/ab_tile_feedback.txt)
     bool feedback = ctx->env_feedback >= 0 ? ctx->env_feedback != 0 : ctx->tile_feedback != 0;
     if (ctx->measure_cost) feedback = false;  // a measuring draw: plain row-major launch that records into the caller's buffer
@@ -1427,7 +1463,33 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         HIP_TRY(ctx, hipEventCreate(&ev.e1));
         HIP_TRY(ctx, hipEventRecord(ev.e0, s));
     }
-    if (tiles_dev) rc.tile_order = tiles_dev;
+    if (tiles_dev) {
+        // The list is the caller's: an index beyond the grid must shade nothing (include/atmo.h) -- and must not be turned into addresses.  The
+        // render kernels' preamble is not the place (one scalar compare-and-branch there costs the headline kernel 10 %:
+        // profiles/round5/ab_tile_bound.txt), so a copy of the list is bounded on the device in front of the draw: out-of-range entries
+        // become the first tile BELOW the viewport, whose lanes all leave at the kernel's own bounds test.  One copy per draw stream
+        // (stream order protects it from the next tile-list draw on that stream); a fifth stream takes over the least recently used copy,
+        // ordered behind its last reader on the device.
+        AtmoContext::TileListBuf *tl = nullptr;
+        ctx->tile_list_clock += 1;
+        for (AtmoContext::TileListBuf &t : ctx->tile_lists) if (!tl && t.used && t.stream == s) tl = &t;
+        for (AtmoContext::TileListBuf &t : ctx->tile_lists) if (!tl && !t.used) tl = &t;
+        if (!tl) {
+            tl = &ctx->tile_lists[0];
+            for (AtmoContext::TileListBuf &t : ctx->tile_lists) if (t.last_use < tl->last_use) tl = &t;
+            const int rc0 = order_after_draws_on(ctx, s, tl->stream);  // its last reader: a draw on that stream
+            if (rc0 != ATMO_OK) return rc0;
+        }
+        tl->used = true;
+        tl->stream = s;
+        tl->last_use = ctx->tile_list_clock;
+        { const int rc0 = dev_reserve(ctx, tl->buf, (size_t)n_tiles * sizeof(uint32_t)); if (rc0 != ATMO_OK) return rc0; }
+        int tw = 0, th = 0;
+        atmo::render_tile_size(split, &tw, &th);                                         // pixels per tile of this launch
+        const uint32_t below = (uint32_t)((frame->viewport_h - rc.gy0 + th - 1) / th);   // the first tile row that starts below the viewport's last row
+        HIP_TRY(ctx, atmo::launch_tile_list_bound(tiles_dev, (uint32_t *)tl->buf.ptr, n_tiles, (uint32_t)gx * (uint32_t)gy, below * (uint32_t)gx, s));
+        rc.tile_order = (const uint32_t *)tl->buf.ptr;
+    }
     HIP_TRY(ctx, atmo::launch_render(flags, split, rc, s, tiles_dev ? n_tiles : 0));
     ctx->last_flags = flags;
     if (fb_record) {
@@ -1445,12 +1507,35 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         ctx->fb_sorts += 1;
     }
     if (fb) fb->n += 1;
-    {
-        bool known = false;
-        for (hipStream_t d : ctx->draw_streams) known = known || d == s;
-        if (!known) {
-            if (ctx->draw_streams.size() < 8) ctx->draw_streams.push_back(s);
-            else ctx->draw_streams_many = true;  // a host that draws on a new stream every frame: bounded memory, the next update waits
+    {   // remember the stream and put its marker behind this draw
+        AtmoContext::DrawStream *ds = nullptr;
+        for (AtmoContext::DrawStream &d : ctx->draw_streams) if (d.stream == s) ds = &d;
+        if (!ds) {
+            if (ctx->draw_streams.size() < 8) {
+                ctx->draw_streams.emplace_back();
+                ds = &ctx->draw_streams.back();
+                ds->stream = s;
+            } else {
+                // a host that draws on a new stream every frame: bounded memory.  The least recently used entry makes room (its marker is
+                // re-recorded for the new stream); what it stood for can only be waited for device-wide from now on: the next update does
+                ds = &ctx->draw_streams[0];
+                for (AtmoContext::DrawStream &d : ctx->draw_streams) if (d.last_use < ds->last_use) ds = &d;
+                ds->stream = s;
+                ds->recorded = false;
+                ctx->draw_streams_many = true;
+            }
+        }
+        ds->recorded = false;   // whatever marker it carries is not behind THIS draw
+        ds->last_use = ++ctx->draw_stream_clock;
+        const bool home = s == ctx->tex_stream;   // the stream of the last texture update (the null stream before the first)
+        if (ctx->draw_events && (!home || ctx->draw_events == 2)) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            const bool capturing = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+            if (!capturing) {   // (a draw inside a graph capture gets no marker: replays are the caller's to order)
+                if (!ds->last_draw) HIP_TRY(ctx, hipEventCreateWithFlags(&ds->last_draw, hipEventDisableTiming));
+                HIP_TRY(ctx, hipEventRecord(ds->last_draw, s));
+                ds->recorded = true;
+            }
         }
     }
     ctx->last_split = split;
@@ -1590,7 +1675,12 @@ int atmo_debug_marched_optical_depth(AtmoContext *ctx, int n, const float *pos_x
 
 const char *atmo_kernel_name(AtmoContext *ctx) {
     if (!ctx) return "";
-    return atmo::render_kernel_name(ctx->last_flags >= 0 ? ctx->last_flags : ctx->flags, ctx->light_steps, ctx->last_split);
+    if (ctx->last_flags >= 0) return atmo::render_kernel_name(ctx->last_flags, ctx->light_steps, ctx->last_split);
+    // before the first draw: what a draw would launch as the context stands (render_impl's choices: long view marches, the cubemap's sampler)
+    int flags = ctx->flags, split = choose_split(ctx, nullptr);
+    if (ctx->view_steps > 32 && !(flags & (atmo::KF_LITE | atmo::KF_ATMO_REF))) { flags |= atmo::KF_VIEW_POS; split = 1; }
+    if (resolve_sampler_lod(ctx, nullptr)) { flags |= atmo::KF_CUBE_LOD; split = 1; }
+    return atmo::render_kernel_name(flags, ctx->light_steps, split);
 }
 
 const char *atmo_last_error_string(AtmoContext *ctx) {

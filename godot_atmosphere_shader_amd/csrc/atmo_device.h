@@ -75,7 +75,6 @@ struct RenderConsts {
     int32_t composite;       // 1 => straight-alpha "mix" blend over the existing contents, discarded pixels untouched
     // --- launch order (atmo_set_tile_feedback)
     int32_t tiles_x;                // tiles per row of the launch grid
-    uint32_t tiles_n;               // tiles of the launch grid: an entry of tile_order beyond it shades nothing (atmo_render_tiles takes the caller's list)
     const uint32_t *tile_order;     // null => tile = linear block index; else the tile each block shades (heaviest first)
     uint32_t *tile_cost;            // null => no feedback; else per-tile max wave duration in shader cycles (atomicMax)
 #ifdef ATMO_WAVE_TRACE  // diagnostic build (tools/wave_timeline.py): 4 x uint64 per wave = start, end (100 MHz), HW_ID, XCC_ID
@@ -116,6 +115,7 @@ hipError_t launch_bake(const BakeConsts &bc, hipStream_t stream);
 hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int tiles_x, int tiles_y, int rx, int ry, uint32_t *tmp1, uint32_t *tmp2,
                              uint32_t *scratch, hipStream_t stream);
 size_t tile_order_scratch_bytes();
+hipError_t launch_tile_list_bound(const uint32_t *in, uint32_t *out, int n, uint32_t tiles_n, uint32_t sentinel, hipStream_t stream);  // atmo_render_tiles
 hipError_t launch_layout_lut(const float *lut, int w, int h, float *out, hipStream_t stream);
 hipError_t launch_lut_footprints(const float *apron, int w, int h, float *out4, hipStream_t stream);
 hipError_t launch_layout_shape(const uint8_t *t, int n, uint32_t *out, hipStream_t stream);

@@ -1919,10 +1919,7 @@ constexpr bool render_sgpr_cap80(int flags) {
 #define ATMO_RENDER_KERNEL_BODY                                                                                  \
     ATMO_TRACE_ENTRY                                                                                             \
     uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;                                                         \
-    if (rc.tile_order != nullptr) {                                                                              \
-        tile = rc.tile_order[tile];                                                                              \
-        if (tile >= rc.tiles_n) return; /* include/atmo.h, atmo_render_tiles: an index beyond the grid shades nothing */ \
-    }                                                                                                            \
+    if (rc.tile_order != nullptr) tile = rc.tile_order[tile];                                                    \
     const uint32_t tile_y = tile / (uint32_t)rc.tiles_x, tile_x = tile - tile_y * (uint32_t)rc.tiles_x;          \
     uint64_t t0 = 0;                                                                                             \
     if (rc.tile_cost != nullptr) t0 = __builtin_amdgcn_s_memtime();                                              \
@@ -2099,6 +2096,21 @@ hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int tiles_x, int t
     hipLaunchKernelGGL(atmo_tile_hist_kernel, dim3(ORDER_BLOCKS), dim3(64), 0, stream, key, scratch, n);
     hipLaunchKernelGGL(atmo_tile_scan_kernel, dim3(1), dim3(256), 0, stream, scratch);
     hipLaunchKernelGGL(atmo_tile_scatter_kernel, dim3(ORDER_BLOCKS), dim3(64), 0, stream, key, cost, scratch, order, n);
+    return hipGetLastError();
+}
+
+// atmo_render_tiles: the caller's tile list with every index beyond the launch grid replaced by `sentinel`, a tile that lies wholly below the
+// viewport (its lanes leave at shade_pixel's bounds test).  In front of the draw, on its stream; the render kernels stay untouched.
+__global__ __launch_bounds__(256) void atmo_tile_list_bound_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int n, uint32_t tiles_n,
+                                                                   uint32_t sentinel) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const uint32_t t = in[i];
+        out[i] = t < tiles_n ? t : sentinel;
+    }
+}
+hipError_t launch_tile_list_bound(const uint32_t *in, uint32_t *out, int n, uint32_t tiles_n, uint32_t sentinel, hipStream_t stream) {
+    hipLaunchKernelGGL(atmo_tile_list_bound_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, in, out, n, tiles_n, sentinel);
     return hipGetLastError();
 }
 

@@ -121,10 +121,17 @@ int atmo_get_param_f32(AtmoContext *ctx, const char *name, float *v, int n);
  * linear-mipmap sampler (atmo_set_sampler_lod, default), not in its LOD-0 mode.
  * The copy and the re-layout into the kernels' footprint layouts are enqueued on `stream` (hipStream_t, NULL = default
  * stream).  Updates of one context take effect in call order whatever streams they arrive on (a later update is chained
- * behind an earlier one's event), and draws on other streams wait for them (stream-side).  Nothing waits on the host
- * except: a copy from pageable host memory; the re-allocation when a texture changes size; and an update that arrives
- * on a stream OTHER than the one the context last drew on, which waits for the device first (draws may still be reading
- * the bound copy there) -- send updates down the draw stream and stream order is all there is.
+ * behind an earlier one's event), and draws on other streams wait for them (stream-side).  An update that arrives on a
+ * stream other than the ones the context has drawn on is ordered behind those draws ON THE DEVICE (they may still be
+ * reading the bound copy): the context records a marker event behind every draw it enqueues on a stream other than its
+ * "home" stream -- the stream of its most recent texture update (the null stream before the first) -- and the update's
+ * stream waits for those markers; no queue of the process other than the update's own is held up, and a draw stream
+ * the caller has destroyed in the meantime is never touched again.  Nothing waits on the host except: a copy from
+ * pageable host memory; the re-allocation when a texture changes size; and, device-wide (hipDeviceSynchronize), an
+ * update that moves AWAY from a non-null home stream which has carried draws since (those have no marker, and a stream
+ * that may be gone cannot be asked) or a context that has drawn on more than 8 streams since its last update.  A host
+ * that sends updates down its draw stream pays nothing at all: stream order is all there is (a marker costs 3-4 us
+ * per draw; a host with a separate upload stream pays that on its draws).
  * Device memory per bound texture: 4 bytes per texel position for the two cloud textures (bilinear footprints) plus, up to
  * 1024^2 faces (cubemap, whole chain) and 48^3 (shape volume), a float copy of the same footprints at 16 bytes each, which
  * the precise cloud kernels sample (same bits, fewer instructions); larger textures are sampled from the 4-byte footprints.
@@ -266,13 +273,14 @@ int atmo_set_target_cleared(AtmoContext *ctx, int cleared);
  * (its heaviest tiles are ~10x the mean), baked-LUT atmosphere +4..5 %; within +-1.5 % on frames whose tiles all weigh
  * the same (profiles/round2/ab_tile_feedback.txt).  The picture does not depend on the order.
  * -1 (default) = on; 0 = off; 1 = on.  Launches inside a HIP graph capture never use it.
- * Host-side waits this machinery can cause (hipDeviceSynchronize: ALL of the process's GPU work, not only this context's): changing the
- * mode while draws are in flight; a FIFTH distinct (rect grid, stream) pair while four are cached (the least recently used state is
- * recycled, at most 8 times in a row, then such draws simply run in row-major order without waiting); and, outside the feedback, a
- * texture update arriving on a stream other than one the context drew on.  A host that cycles through many rects should turn the
- * feedback off (0) for that context.  A context keeps one feedback
+ * Host-side waits: none since round 5 in a host whose draws and texture updates use different streams or the null stream.  Changing the
+ * mode never waits (a state with work in flight is handed to its next owner behind that work, on the device); a FIFTH distinct (rect
+ * grid, stream) pair while four are cached recycles the least recently used state (at most 8 times in a row, then such draws simply run
+ * in row-major order) behind the marker event of that state's last draw -- device-wide (hipDeviceSynchronize) only when that state drew on
+ * the context's non-null home stream (see atmo_set_texture), whose draws carry no marker.  A host that cycles through many rects should
+ * still turn the feedback off (0) for that context.  A context keeps one feedback
  * state per (launch grid, draw stream) it sees, up to four (split screen, stereo eyes, uneven row bands), each allocated by
- * the first launch of its key; a fifth key recycles the least recently used state (which waits for that state's work),
+ * the first launch of its key; a fifth key recycles the least recently used state (ordered behind that state's work),
  * and a context that keeps producing new keys runs out of recycling budget (8, one regained every 256 draws) and draws
  * those keys in row-major order while the resident states keep working.
  * A state follows the camera: it compares the matrices of consecutive draws of its key, dilates the measured cost map by the

@@ -520,8 +520,8 @@ def test_texture_update_does_not_wait_for_unrelated_streams():
     which waits for EVERY queue of the process, the engine's own included.  Since round 5 the draws are ordered in front of the update on the
     device (a marker on each draw stream, a stream-side wait on the update's stream): with ~0.3 s of unrelated work in flight on a third
     stream the update returns at once, that work is still running when it does, and the frames are what test_texture_update_waits_for_draws...
-    demands (draws before the update see the old texture whole, draws after it the new one).  The same for a feedback-mode toggle, a fifth
-    (grid, stream) key, and a measuring draw.  A draw stream the caller has DESTROYED since is the one case left for the device-wide wait."""
+    demands (draws before the update see the old texture whole, draws after it the new one).  The same for a feedback-mode toggle and a fifth
+    (grid, stream) key.  A draw stream the caller has destroyed since is no problem either: the context waits for its own marker events."""
     import time
 
     import torch
@@ -537,6 +537,8 @@ def test_texture_update_does_not_wait_for_unrelated_streams():
     ref = make_node("clouds_high_rm", dict(tex, shape=shape2), params)
     want_new = ref.render(cam, depth).cpu().numpy()
     ref.close()
+    # a: the draw stream; b: the stream texture updates arrive on (the context's "home" stream once the first update has used it: draws
+    # on any OTHER stream carry a marker event, 3-4 us each, which is what later waits use instead of the stream handles)
     a, b, unrelated = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
     big = torch.randn(8192, 8192, device="cuda")
     torch.cuda.synchronize()
@@ -569,8 +571,9 @@ def test_texture_update_does_not_wait_for_unrelated_streams():
     # a feedback-mode toggle with draws in flight, then draws on a new key: nothing waits either
     t0 = time.perf_counter()
     assert node._lib.atmo_set_tile_feedback(node._ctx, 0) == N.ATMO_OK and node._lib.atmo_set_tile_feedback(node._ctx, 1) == N.ATMO_OK
+    c2 = torch.cuda.Stream()
     for k in range(6):   # more (rect, stream) keys than feedback slots: recycling orders the new owner behind the old one's work on the device
-        node.render(cam, depth, rect=(0, 0, w - 16 * k, h), stream=(a, b)[k % 2])
+        node.render(cam, depth, rect=(0, 0, w - 16 * k, h), stream=(a, c2)[k % 2])
     dt_toggle = time.perf_counter() - t0
     still_running_2 = not done.query()
     torch.cuda.synchronize()
@@ -583,7 +586,8 @@ def test_texture_update_does_not_wait_for_unrelated_streams():
     for k in (4, 5):
         assert np.array_equal(outs[k % 2].cpu().numpy(), want_old), k
     assert np.array_equal(got_new.cpu().numpy(), want_new)
-    # a draw stream destroyed by the caller: its handle is stale, the work it carried cannot be waited for by name -> device-wide wait, no crash
+    # a draw stream the caller has DESTROYED since: HIP dereferences stale stream handles (an event recorded on one crashes), so the context
+    # never touches a remembered handle again -- it waits for the marker event it recorded behind that stream's last draw
     loaded = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln})   # the HIP runtime this process already uses
     assert loaded, "no HIP runtime mapped"
     hip = C.CDLL(loaded[0])
@@ -596,7 +600,7 @@ def test_texture_update_does_not_wait_for_unrelated_streams():
     shape3 = np.ascontiguousarray(tex["shape"], dtype=np.uint8)
     rc = node._lib.atmo_set_texture(node._ctx, b"u_cloud_shape_texture", N.TEX_3D_R8, 32, 32, 32, 1, shape3.ctypes.data_as(C.c_void_p), N.MEM_HOST,
                                     C.c_void_p(b.cuda_stream))
-    assert rc == N.ATMO_OK and syncs() == 1
+    assert rc == N.ATMO_OK and syncs() == 0
     back = node.render(cam, depth, stream=b)
     torch.cuda.synchronize()
     assert np.array_equal(back.cpu().numpy(), want_old)
@@ -647,7 +651,37 @@ def test_tile_list_draws_partition_the_frame():
                 assert np.all(o[~mine] == 77.5), (config_name, world, r)          # nothing outside its strips is touched
                 got[mine] = o[mine]
             assert np.array_equal(got, want), (config_name, world)
+        # indices beyond the grid shade nothing and touch nothing (include/atmo.h; ADVICE r4: 0xFFFFFFFF on a one-tile-wide rect used to become
+        # tile row -1): a list of nothing but such indices leaves a poisoned target as it was, and mixed into a real list they change nothing
+        n_grid = cost.size
+        junk = np.array([n_grid, n_grid + 5, 0x7FFFFFFF, 0xFFFFFFFF, 0x80000000, 0xFFFFFFF0], dtype=np.uint32)
+        for rogue, real in ((junk, np.zeros(0, dtype=np.uint32)), (junk, tiles[0].astype(np.uint32))):
+            lst = np.concatenate([rogue[:3], real, rogue[3:]])
+            guard = torch.full((want.shape[0] + 64, want.shape[1], 4), 77.5, dtype=torch.float32, device="cuda")   # 32 guard rows on either side
+            out = guard[32:32 + want.shape[0]]
+            t = torch.from_numpy(lst.view(np.int32)).cuda()
+            node.render_tiles_prepared(frame, depth.data_ptr(), out.data_ptr(), t.data_ptr(), t.numel(), stream)
+            torch.cuda.synchronize()
+            g = guard.cpu().numpy()
+            assert np.all(g[:32] == 77.5) and np.all(g[-32:] == 77.5), config_name
+            o = g[32:-32]
+            mine = np.zeros(want.shape[0], dtype=bool)
+            if real.size:
+                for k in strips[0]:
+                    mine[max(0, gy0 - y0 + k * STRIP_TILE_ROWS * th):max(0, gy0 - y0 + (k + 1) * STRIP_TILE_ROWS * th)] = True
+            assert np.all(o[~mine] == 77.5) and np.array_equal(o[mine], want[mine]), (config_name, real.size)
         node.close()
+    # a rect one tile wide (tiles_x = 1: every index IS a tile row) at the top of the viewport
+    cam = S.Camera.from_pose(64, 64, "P_clouds")
+    depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
+    node = make_node("no_clouds_8", tex, params)
+    frame = node.prepare_frame(cam, rect=(0, 0, 16, 24))
+    guard = torch.full((24 + 64, 16, 4), 77.5, dtype=torch.float32, device="cuda")
+    t = torch.from_numpy(np.array([0xFFFFFFFF, 3, 0x1FFFFFFF, 0x20000001], dtype=np.uint32).view(np.int32)).cuda()
+    node.render_tiles_prepared(frame, depth.data_ptr(), guard[32:56].data_ptr(), t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert bool((guard == 77.5).all())
+    node.close()
 
 
 def test_user_supplied_lut_of_other_size(oracle32):
