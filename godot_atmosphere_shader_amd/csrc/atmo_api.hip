@@ -144,6 +144,10 @@ struct AtmoContext {
         // next draw is ordered by THIS frame's costs; no host queries, one frame of lag
         DeviceBuffer is_order, is_scratch;
         unsigned is_last_n = ~0u;                // n of the draw behind which the last in-stream sort was enqueued
+        // heavy tiles on two lanes per ray (round 5): every order also exists for the launch grid of the lane-split kernels (tiles half as
+        // high: two entries per tile), and the sort leaves the number of tiles per cost class in pinned host memory
+        DeviceBuffer order2[2], is_order2;
+        uint32_t *class_totals = nullptr;        // pinned: 3 x 32 counters -- order[0], order[1], is_order
         unsigned n = 0;                // draws of this key so far
         unsigned last_record = 0;      // n of the last draw that recorded costs
         int active = -1;               // order[active] is complete and in use; -1: row-major order
@@ -159,6 +163,11 @@ struct AtmoContext {
     int fb_budget = 8;                                 // slot recyclings allowed right now; one comes back every 256 draws
     unsigned fb_ordered_draws = 0, fb_recycled = 0, fb_sorts = 0;  // atmo_get_feedback_stats
     hipStream_t fb_stream = nullptr;                   // the sort kernels run here, beside the draws (high priority)
+    hipStream_t split_stream = nullptr;                // the heavy tiles of a frame, on two lanes per ray, run here beside the rest of the draw
+    int heavy_split = 1;                               // ATMO_HEAVY_SPLIT=0 (A/B): every tile with one lane per ray; 2 (tests): also the kernel without raymarched light, no trigger
+    float heavy_split_trigger = 1.5f;                  // ATMO_HEAVY_SPLIT_TRIGGER: only when the heaviest class lives longer than this x the draw's estimated duration ...
+    float heavy_split_ratio = 0.3f;                    // ATMO_HEAVY_SPLIT_RATIO: ... the tiles whose longest wave lives longer than this x that estimate are heavy
+    unsigned split_draws = 0, split_tiles_last = 0;    // atmo_get_split_stats
     DeviceBuffer fb_scratch;                           // the sort's block histograms (sorts are serialised on fb_stream)
     unsigned fb_period = 8;                            // every fb_period-th draw of a key records costs
     // A/B overrides read ONCE, in atmo_create (tools/ab_feedback.sh, tools/ab_bench.sh): ATMO_TILE_FEEDBACK=0/1,
@@ -441,6 +450,32 @@ int resolve_sampler_lod(const AtmoContext *ctx, const char **why_not) {
     return 1;
 }
 
+// How many tiles at the head of a cost-sorted order are HEAVY: tiles whose longest wavefront lives longer than `ratio` x the draw itself.
+// A cloud frame at 1920x1080 is as long as its heaviest wavefront (all 64 rays in dense cloud: 0.36 of the 0.42 ms of clouds_high_rm; a
+// wave issues one instruction every ~5 cycles however empty the SIMD is) -- those tiles are drawn with two lanes per ray, which halves
+// exactly that, for 13-29 % more work on them; at 3840x2160 the same waves are a quarter of the draw and nothing is split.
+//   totals[k]: tiles in cost class k (half octaves of the wave duration in shader cycles, 0 = heaviest: tile_cost_class);
+//   the draw's duration is estimated from the same numbers: sum of wave lifetimes / resident waves (2 waves per tile; SIMDs x waves per SIMD).
+int heavy_tile_count(const uint32_t *totals, int n_tiles, float ratio, float trigger, int resident_waves) {
+    double life[atmo::TILE_ORDER_CLASSES], sum = 0.0;
+    long long counted = 0;
+    for (int k = 0; k < atmo::TILE_ORDER_CLASSES; ++k) {
+        const int q = atmo::TILE_ORDER_CLASSES - 1 - k + 16;                  // the class holds durations from 2^(q/2) up to the next half octave
+        life[k] = std::ldexp(1.0, q >> 1) * ((q & 1) ? 1.5 : 1.0) * 1.2;      // ... its middle
+        if (k == atmo::TILE_ORDER_CLASSES - 1) life[k] = 0.0;                 // the last class also holds the tiles without a measurement
+        sum += life[k] * (double)totals[k];
+        counted += totals[k];
+    }
+    if (counted != n_tiles || sum <= 0.0) return 0;                           // not (yet) the histogram of this grid
+    const double draw = sum * 2.0 / (double)resident_waves;
+    int first = 0;
+    while (first < atmo::TILE_ORDER_CLASSES - 1 && totals[first] == 0) ++first;
+    if (!(life[first] > trigger * draw)) return 0;   // no wavefront outlives the draw's throughput estimate: the frame is not bound by its tail
+    int heavy = 0;
+    for (int k = 0; k < atmo::TILE_ORDER_CLASSES && life[k] > ratio * draw; ++k) heavy += (int)totals[k];
+    return heavy > n_tiles / 3 ? n_tiles / 3 : heavy;
+}
+
 // Lanes per ray for one launch (atmo_set_lane_split; ATMO_LANE_SPLIT, read in atmo_create, overrides for A/B runs).  Two lanes per ray double
 // the wave count at the price of a duplicated per-pixel prologue and regrouped view sums; measured on MI355X it pays
 // only where a few very long waves set the kernel time (clouds_high_rm, 1920x1080, pose P_space: -11 %) and costs
@@ -450,6 +485,28 @@ int choose_split(const AtmoContext *ctx, const AtmoFrame *f) {
     if (ctx->flags & atmo::KF_ATMO_REF) return 1;  // the reference-order v2 march has one launch shape
     if (ctx->env_split) return ctx->env_split;
     return ctx->lane_split == 2 ? 2 : 1;
+}
+
+// The kernel family and launch shape a draw of this context uses as it stands: the context's flags plus what is decided per draw -- long view
+// marches in the reference's position form (KF_VIEW_POS), the cubemap's sampler (KF_CUBE_LOD) -- and the lanes per ray those forms exist in.
+void launch_shape(const AtmoContext *ctx, const AtmoFrame *frame, int *flags_out, int *split_out, bool *lod_out) {
+    int flags = ctx->flags, split = choose_split(ctx, frame);
+    if (ctx->view_steps > 32 && !(flags & (atmo::KF_LITE | atmo::KF_ATMO_REF))) {
+        // long view marches accumulate the position in the reference's form (march_atmosphere<VIEWPOS>): the default form's running sum
+        // drifted to 1.08e-4 of alpha at 64 steps on thin atmospheres; up to 32 steps the kernels are the round-3 ones, byte for byte
+        flags |= atmo::KF_VIEW_POS;
+        split = 1;
+    }
+    const bool lod = resolve_sampler_lod(ctx, nullptr) != 0;
+    if (lod) {
+        flags |= atmo::KF_CUBE_LOD;
+        // two lanes per ray under the declared sampler: only the two BASELINE cloud kernels have that form (atmo_set_lane_split 2 draws a
+        // whole frame with it -- a test / A-B knob; by itself the library draws a frame's HEAVY tiles that way, render_impl)
+        if ((flags & ~atmo::KF_CLOUD_LIGHT_RM) != (atmo::KF_CUBE_LOD | atmo::KF_PRECISE | atmo::KF_CLOUDS)) split = 1;
+    }
+    *flags_out = flags;
+    *split_out = split;
+    if (lod_out) *lod_out = lod;
 }
 
 // Reads back finished timing pairs.  only_completed: keep the pairs whose second event has not happened yet
@@ -658,6 +715,14 @@ int feedback_state(AtmoContext *ctx, int gx, int gy, int split, hipStream_t s, A
     for (int k = 0; k < 2 && rc1 == ATMO_OK; ++k) rc1 = dev_reserve(ctx, f.dil[k], bytes);
     if (rc1 == ATMO_OK) rc1 = dev_reserve(ctx, f.is_order, bytes);
     if (rc1 == ATMO_OK) rc1 = dev_reserve(ctx, f.is_scratch, atmo::tile_order_scratch_bytes());
+    for (int k = 0; k < 2 && rc1 == ATMO_OK; ++k) rc1 = dev_reserve(ctx, f.order2[k], 2 * bytes);
+    if (rc1 == ATMO_OK) rc1 = dev_reserve(ctx, f.is_order2, 2 * bytes);
+    if (rc1 == ATMO_OK && !f.class_totals) {
+        void *p = nullptr;
+        HIP_TRY(ctx, hipHostMalloc(&p, 3 * atmo::TILE_ORDER_CLASSES * sizeof(uint32_t), hipHostMallocDefault));
+        f.class_totals = (uint32_t *)p;
+    }
+    if (rc1 == ATMO_OK) std::memset(f.class_totals, 0, 3 * atmo::TILE_ORDER_CLASSES * sizeof(uint32_t));
     if (rc1 != ATMO_OK) { f.used = false; return rc1; }
     if (!f.ev_draw) {
         HIP_TRY(ctx, hipEventCreateWithFlags(&f.ev_draw, hipEventDisableTiming));
@@ -748,6 +813,9 @@ int atmo_create(int device, int variant, int view_steps, int cloud_steps, int li
     if (const char *ev = std::getenv("ATMO_TILE_FEEDBACK")) ctx->env_feedback = ev[0] == '1' ? 1 : 0;
     if (const char *ev = std::getenv("ATMO_F4")) ctx->f4_footprints = std::atoi(ev) & 3;
     if (const char *ev = std::getenv("ATMO_LOD0_CERT")) ctx->env_lod0_cert = ev[0] == '0' ? 0 : 1;
+    if (const char *ev = std::getenv("ATMO_HEAVY_SPLIT")) ctx->heavy_split = ev[0] == '0' ? 0 : (ev[0] == '2' ? 2 : 1);
+    if (const char *ev = std::getenv("ATMO_HEAVY_SPLIT_RATIO")) ctx->heavy_split_ratio = (float)std::atof(ev);
+    if (const char *ev = std::getenv("ATMO_HEAVY_SPLIT_TRIGGER")) ctx->heavy_split_trigger = (float)std::atof(ev);
     if (const char *ev = std::getenv("ATMO_DRAW_EVENTS")) ctx->draw_events = ev[0] == '0' ? 0 : (ev[0] == '2' ? 2 : 1);
     if (const char *ev = std::getenv("ATMO_TARGET_CLEARED")) ctx->target_cleared = ev[0] == '1' ? 1 : 0;  // tools/ab_env.sh: atmo_set_target_cleared
     if (const char *ev = std::getenv("ATMO_FB_INSTREAM")) ctx->instream = ev[0] >= '1' && ev[0] <= '2' ? ev[0] - '0' : 0;  // 2 (A/B): every cloud and direct-light kernel
@@ -796,6 +864,10 @@ int atmo_destroy(AtmoContext *ctx) {
         (void)hipStreamSynchronize(ctx->fb_stream);
         (void)hipStreamDestroy(ctx->fb_stream);
     }
+    if (ctx->split_stream) {
+        (void)hipStreamSynchronize(ctx->split_stream);
+        (void)hipStreamDestroy(ctx->split_stream);
+    }
     for (AtmoContext::FeedbackState &f : ctx->fb) {
         if (f.ev_draw) (void)hipEventDestroy(f.ev_draw);
         for (int k = 0; k < 2; ++k) {
@@ -805,6 +877,9 @@ int atmo_destroy(AtmoContext *ctx) {
         }
         dev_free(f.is_order);
         dev_free(f.is_scratch);
+        dev_free(f.is_order2);
+        for (int k = 0; k < 2; ++k) dev_free(f.order2[k]);
+        if (f.class_totals) (void)hipHostFree(f.class_totals);
         dev_free(f.cost);
     }
     dev_free(ctx->fb_scratch);
@@ -1219,10 +1294,11 @@ int atmo_measure_tile_costs(AtmoContext *ctx, const AtmoFrame *frame, const floa
     atmo::RenderConsts probe;
     std::memset(&probe, 0, sizeof(probe));
     probe.x0 = frame->x0; probe.y0 = frame->y0; probe.x1 = frame->x1; probe.y1 = frame->y1;
-    const bool lod_grid = resolve_sampler_lod(ctx, nullptr) != 0;
+    int probe_flags = 0, split = 1;
+    bool lod_grid = false;
+    launch_shape(ctx, frame, &probe_flags, &split, &lod_grid);
     probe.gx0 = lod_grid ? (frame->x0 & ~1) : frame->x0;
     probe.gy0 = lod_grid ? (frame->y0 & ~1) : frame->y0;
-    const int split = (resolve_sampler_lod(ctx, nullptr) || (ctx->view_steps > 32 && !(ctx->flags & (atmo::KF_LITE | atmo::KF_ATMO_REF)))) ? 1 : choose_split(ctx, frame);
     int gx = 0, gy = 0;
     atmo::render_grid(probe, split, &gx, &gy);
     if (tiles_x) *tiles_x = gx;
@@ -1297,21 +1373,14 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     }
     hipStream_t s = (hipStream_t)stream;
     { const int rc0 = tex_order(ctx, s); if (rc0 != ATMO_OK) return rc0; }  // texture updated on another stream
-    int split = choose_split(ctx, frame);
-    int flags = ctx->flags;
-    if (ctx->view_steps > 32 && !(flags & (atmo::KF_LITE | atmo::KF_ATMO_REF))) {
-        // long view marches accumulate the position in the reference's form (march_atmosphere<VIEWPOS>): the default form's running sum
-        // drifted to 1.08e-4 of alpha at 64 steps on thin atmospheres; up to 32 steps the kernels are the round-3 ones, byte for byte
-        flags |= atmo::KF_VIEW_POS;
-        split = 1;
-    }
-    {   // the coverage cubemap's sampler: as declared (implicit LOD) when a mip chain is bound; one lane per ray
+    int split = 1, flags = 0;
+    {   // the coverage cubemap's sampler: as declared (implicit LOD) when a mip chain is bound
         const char *why_not = nullptr;
-        const int lod = resolve_sampler_lod(ctx, &why_not);
+        (void)resolve_sampler_lod(ctx, &why_not);
         if (ctx->sampler_lod == 1 && why_not) return fail(ctx, ATMO_E_STATE, why_not);
+        bool lod = false;
+        launch_shape(ctx, frame, &flags, &split, &lod);
         if (lod) {
-            flags |= atmo::KF_CUBE_LOD;
-            split = 1;
             // the 2 x 2 quads are the viewport's: the grid starts on an even pixel, pixels in front of the rect are helper lanes
             rc.gx0 = frame->x0 & ~1;
             rc.gy0 = frame->y0 & ~1;
@@ -1333,6 +1402,7 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     // order, which later draws pick up once a host-side event query says it is complete: no draw ever waits for a sort.
     bool fb_record = false, fb_instream = false;
     AtmoContext::FeedbackState *fb = nullptr;
+    const uint32_t *order2 = nullptr, *class_totals = nullptr;   // of the order in use (heavy tiles on two lanes per ray)
     if (feedback) {
         const int rc1 = feedback_state(ctx, gx, gy, split, s, &fb);
         if (rc1 != ATMO_OK) return rc1;
@@ -1397,6 +1467,8 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         if (fb_instream) {
             if (fb->is_last_n + 1u == fb->n) {  // the sort behind the previous draw of this key wrote is_order
                 rc.tile_order = (const uint32_t *)fb->is_order.ptr;
+                order2 = (const uint32_t *)fb->is_order2.ptr;
+                class_totals = fb->class_totals + 2 * atmo::TILE_ORDER_CLASSES;   // (read without waiting: at worst last frame's, or none yet)
                 ctx->fb_ordered_draws += 1;
             }
             rc.tile_cost = (uint32_t *)fb->cost.ptr;
@@ -1420,6 +1492,8 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
                 const float moved = fb->motion_px * (float)(fb->n - fb->order_born[fb->active]);
                 if (moved <= fb->order_reach_px[fb->active] + 8.0f) {
                     rc.tile_order = (const uint32_t *)fb->order[fb->active].ptr;
+                    order2 = (const uint32_t *)fb->order2[fb->active].ptr;
+                    class_totals = fb->class_totals + fb->active * atmo::TILE_ORDER_CLASSES;   // complete: the host has seen this sort's event
                     ctx->fb_ordered_draws += 1;
                 }
             }
@@ -1490,7 +1564,34 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         HIP_TRY(ctx, atmo::launch_tile_list_bound(tiles_dev, (uint32_t *)tl->buf.ptr, n_tiles, (uint32_t)gx * (uint32_t)gy, below * (uint32_t)gx, s));
         rc.tile_order = (const uint32_t *)tl->buf.ptr;
     }
-    HIP_TRY(ctx, atmo::launch_render(flags, split, rc, s, tiles_dev ? n_tiles : 0));
+    // Heavy tiles on two lanes per ray, beside the rest of the draw (round 5).  Only the two BASELINE cloud kernels under the declared sampler have
+    // the lane-split form whose frames are bit-identical to the one-lane kernel's (atmo_kernels.hip: march_clouds<.., SPLIT = 2, LOD>).
+    // Measured (profiles/round5/ab_heavy_tile_split.txt): it pays where a draw is as long as its heaviest wavefront -- clouds_high_rm at
+    // 1280x720 -28 %, from the limb -42..-44 % at 1280x720 and 1920x1080, the night side -33 % -- and costs 9 % where the draw is bound by
+    // throughput (1920x1080 pose P_space, where the lane-split kernel on EVERY tile is 43 % slower; 3840x2160), which the trigger keeps out;
+    // the kernel without raymarched light never gains (its heaviest wave is a fifth as long): not split unless forced (ATMO_HEAVY_SPLIT=2).
+    int heavy = 0;
+    const int lod_cloud = atmo::KF_CUBE_LOD | atmo::KF_PRECISE | atmo::KF_CLOUDS;
+    const bool split_form = ctx->heavy_split == 2 ? (flags & ~atmo::KF_CLOUD_LIGHT_RM) == lod_cloud : flags == (lod_cloud | atmo::KF_CLOUD_LIGHT_RM);
+    if (ctx->heavy_split && order2 && class_totals && rc.tile_order && !tiles_dev && split == 1 && split_form)
+        heavy = heavy_tile_count(class_totals, gx * gy, ctx->heavy_split_ratio, ctx->heavy_split == 2 ? 0.0f : ctx->heavy_split_trigger,
+                                 1024 * ((flags & atmo::KF_CLOUD_LIGHT_RM) ? 5 : 6));
+    if (heavy > 0) {
+        if (!ctx->split_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->split_stream, hipStreamNonBlocking));
+        { const int rc0 = order_after_stream(ctx, ctx->split_stream, s); if (rc0 != ATMO_OK) return rc0; }   // fork: behind everything the draw is behind
+        atmo::RenderConsts rc2 = rc;
+        rc2.tile_order = order2;                       // two half-height tiles per heavy tile, heaviest first
+        HIP_TRY(ctx, atmo::launch_render(flags, 2, rc2, ctx->split_stream, 2 * heavy));
+        if (gx * gy - heavy > 0) {
+            rc.tile_order += heavy;                    // the rest of the order, one lane per ray
+            HIP_TRY(ctx, atmo::launch_render(flags, split, rc, s, gx * gy - heavy));
+        }
+        { const int rc0 = order_after_stream(ctx, s, ctx->split_stream); if (rc0 != ATMO_OK) return rc0; }   // join
+        ctx->split_draws += 1;
+        ctx->split_tiles_last = (unsigned)heavy;
+    } else {
+        HIP_TRY(ctx, atmo::launch_render(flags, split, rc, s, tiles_dev ? n_tiles : 0));
+    }
     ctx->last_flags = flags;
     if (fb_record) {
         // Sort on the side stream as soon as this draw is done (the sort also clears the costs for the next recording).
@@ -1498,7 +1599,8 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         HIP_TRY(ctx, hipEventRecord(fb->ev_draw, s));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->fb_stream, fb->ev_draw, 0));
         HIP_TRY(ctx, atmo::launch_tile_order((uint32_t *)fb->cost.ptr, (uint32_t *)fb->order[fb->write].ptr, gx, gy, dil_rx, dil_ry,
-                                             (uint32_t *)fb->dil[0].ptr, (uint32_t *)fb->dil[1].ptr, (uint32_t *)ctx->fb_scratch.ptr, ctx->fb_stream));
+                                             (uint32_t *)fb->dil[0].ptr, (uint32_t *)fb->dil[1].ptr, (uint32_t *)ctx->fb_scratch.ptr, ctx->fb_stream,
+                                             (uint32_t *)fb->order2[fb->write].ptr, fb->class_totals + fb->write * atmo::TILE_ORDER_CLASSES));
         fb->order_reach_px[fb->write] = reach_px;
         fb->order_born[fb->write] = fb->n;
         HIP_TRY(ctx, hipEventRecord(fb->ev_order[fb->write], ctx->fb_stream));
@@ -1547,7 +1649,8 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     }
     if (fb_instream) {  // behind the draw (and behind the timing bracket, which is the draw kernel's alone)
         HIP_TRY(ctx, atmo::launch_tile_order((uint32_t *)fb->cost.ptr, (uint32_t *)fb->is_order.ptr, gx, gy, dil_rx, dil_ry,
-                                             (uint32_t *)fb->dil[0].ptr, (uint32_t *)fb->dil[1].ptr, (uint32_t *)fb->is_scratch.ptr, s));
+                                             (uint32_t *)fb->dil[0].ptr, (uint32_t *)fb->dil[1].ptr, (uint32_t *)fb->is_scratch.ptr, s,
+                                             (uint32_t *)fb->is_order2.ptr, fb->class_totals + 2 * atmo::TILE_ORDER_CLASSES));
         fb->is_last_n = fb->n - 1;
         fb->last_record = fb->n - 1;
         ctx->fb_sorts += 1;
@@ -1677,15 +1780,21 @@ const char *atmo_kernel_name(AtmoContext *ctx) {
     if (!ctx) return "";
     if (ctx->last_flags >= 0) return atmo::render_kernel_name(ctx->last_flags, ctx->light_steps, ctx->last_split);
     // before the first draw: what a draw would launch as the context stands (render_impl's choices: long view marches, the cubemap's sampler)
-    int flags = ctx->flags, split = choose_split(ctx, nullptr);
-    if (ctx->view_steps > 32 && !(flags & (atmo::KF_LITE | atmo::KF_ATMO_REF))) { flags |= atmo::KF_VIEW_POS; split = 1; }
-    if (resolve_sampler_lod(ctx, nullptr)) { flags |= atmo::KF_CUBE_LOD; split = 1; }
+    int flags = 0, split = 1;
+    launch_shape(ctx, nullptr, &flags, &split, nullptr);
     return atmo::render_kernel_name(flags, ctx->light_steps, split);
 }
 
 const char *atmo_last_error_string(AtmoContext *ctx) {
     if (!ctx) return g_create_error.c_str();
     return ctx->err.c_str();
+}
+
+int atmo_get_split_stats(AtmoContext *ctx, unsigned *split_draws, unsigned *heavy_tiles_last) {
+    if (!ctx) return ATMO_E_ARG;
+    if (split_draws) *split_draws = ctx->split_draws;
+    if (heavy_tiles_last) *heavy_tiles_last = ctx->split_tiles_last;
+    return ATMO_OK;
 }
 
 int atmo_get_host_wait_stats(AtmoContext *ctx, unsigned *device_syncs) {

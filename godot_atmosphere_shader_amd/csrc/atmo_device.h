@@ -113,7 +113,8 @@ enum KernelFlags : int { KF_CLOUDS = 1, KF_CLOUD_LIGHT_RM = 2, KF_LIGHT_DIRECT =
 hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream_t stream, int tile_list_blocks = 0);  // > 0: rc.tile_order lists that many tiles of the rect's grid
 hipError_t launch_bake(const BakeConsts &bc, hipStream_t stream);
 hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int tiles_x, int tiles_y, int rx, int ry, uint32_t *tmp1, uint32_t *tmp2,
-                             uint32_t *scratch, hipStream_t stream);
+                             uint32_t *scratch, hipStream_t stream, uint32_t *order2 = nullptr, uint32_t *class_totals = nullptr);
+constexpr int TILE_ORDER_CLASSES = 32;   // cost classes of the sort: half octaves of the wave duration, class 0 the heaviest (tile_cost_class)
 size_t tile_order_scratch_bytes();
 hipError_t launch_tile_list_bound(const uint32_t *in, uint32_t *out, int n, uint32_t tiles_n, uint32_t sentinel, hipStream_t stream);  // atmo_render_tiles
 hipError_t launch_layout_lut(const float *lut, int w, int h, float *out, hipStream_t stream);

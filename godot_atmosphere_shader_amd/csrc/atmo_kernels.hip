@@ -160,6 +160,21 @@ __device__ __forceinline__ float swap_adjacent(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
 }
 
+// The lane-split form of the DECLARED-SAMPLER kernels (round 5) keeps every 2 x 2 pixel quad in four consecutive lanes -- quad_perm and
+// s_wqm_b64 work unchanged, and the four lanes of a quad are at the same march step -- and puts the two lanes of a ray four lanes apart:
+// lane ^ 4.  Within a 16-lane DPP row, banks 0 and 2 read lane + 4 (row_shl:4), banks 1 and 3 lane - 4 (row_shr:4): two DPP moves.
+__device__ __forceinline__ float swap_across_quads(float x) {
+    const int v = __float_as_int(x);
+    int t = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0x5, false);  // row_shl:4, bank_mask 0101: lanes 0-3, 8-11 of a row <- lane + 4
+    t = __builtin_amdgcn_update_dpp(t, v, 0x114, 0xF, 0xA, false);      // row_shr:4, bank_mask 1010: lanes 4-7, 12-15 <- lane - 4
+    return __int_as_float(t);
+}
+template <bool ACROSS_QUADS>
+__device__ __forceinline__ float swap_ray_lanes(float x) { return ACROSS_QUADS ? swap_across_quads(x) : swap_adjacent(x); }
+// products and sums that must NOT be contracted where the caller's block allows it (`#pragma clang fp contract` is lexical)
+__device__ __forceinline__ float mul_unfused(float a, float b) { return a * b; }
+__device__ __forceinline__ float add_unfused(float a, float b) { return a + b; }
+
 // ---- exact (IEEE, unfused) helpers: must match a scalar fp32 evaluation bit for bit -------------
 struct V3 {
     float x, y, z;
@@ -1379,6 +1394,30 @@ __device__ __forceinline__ void cloud_uniforms_to_vgprs(RenderConsts &v) {
 #endif
 }
 
+// get_planet_shadow (clouds:153-167) of a lit sample as a light factor: smoothstep(-0.3, 0.3, dot(normalize(pos), -sun_dir)) mixed into
+// [0.002, 1].  ONE definition for the lit-sample queue and the in-place forms: the sum of three products leaves the compiler a choice of
+// what to fuse, and that choice is part of the bits.
+__device__ __forceinline__ float cloud_shadow_light(float px, float py, float pz, float sx, float sy, float sz, float r) {
+#pragma clang fp contract(fast)
+    const float sd = -(px * sx + py * sy + pz * sz) * hw_rcp(r);
+    const float st = sat((sd + 0.3f) * (1.0f / 0.6f));
+    const float shadow = st * st * (3.0f - 2.0f * st);
+    return fmaf(shadow, 0.002f - 1.0f, 1.0f);
+}
+// One lit sample of the raymarched-light recurrence as the lit-sample queue evaluates it (march_clouds_rm_queue, phases A and C): the
+// transmittance chain, the sample's weight w = shadow light * density * step * total transmittance, and -- given the sample's raymarched
+// light -- total_light += light * w with the product and the sum rounded on their own (they pass through LDS there).
+struct RmRecurrence {
+    float total_transmittance, one_minus_alpha, total_light;
+};
+__device__ __forceinline__ float rm_sample_weight(RmRecurrence &s, float density, float lb, float scale_step, float neg_scale_step_log2e) {
+#pragma clang fp contract(fast)
+    const float transmittance = hw_exp2(density * neg_scale_step_log2e);
+    s.total_transmittance = fmaxf(s.total_transmittance * transmittance, 0.005f);
+    s.one_minus_alpha *= transmittance;
+    return (lb * (density * scale_step)) * s.total_transmittance;
+}
+
 // raymarch_cloud (cloud_funcs.gdshaderinc:175-247).  Returns (total_light, alpha).
 // SPLIT = 2: lane `half` of a pair evaluates the samples with step index = half (mod 2) -- position chain, density,
 // light -- while the recurrence over the samples (transmittance floor, light sum, alpha) runs in step order on the
@@ -1387,16 +1426,25 @@ __device__ __forceinline__ void cloud_uniforms_to_vgprs(RenderConsts &v) {
 template <bool RM, bool PRECISE, int SPLIT, bool LOD = false>
 __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc_in, V3 dir_m, float t_begin, float t_end, float jitter, int half,
                                                QuadRegs *qregs = nullptr, const f32x4 *lvl = nullptr) {
-    static_assert(!(LOD && RM), "raymarched light under the declared sampler runs through the lit-sample queue");
-    RenderConsts rc = rc_in;
-    if (PRECISE) cloud_uniforms_to_vgprs(rc);
+    static_assert(!(LOD && RM) || SPLIT == 2, "raymarched light under the declared sampler, one lane per ray: the lit-sample queue");
+    // LOD && SPLIT == 2 (round 5, the heavy tiles of a frame): the two lanes of a ray are lane and lane ^ 4, a pixel quad keeps four consecutive
+    // lanes (all at the same step); with RM the light taps are evaluated in place -- the partners' sample positions come from the quad
+    // mates by the same whole-quad block the queue uses at enqueue -- and the recurrence runs in the lit-sample queue's arithmetic
+    // (rm_sample_weight, product and sum of the light term rounded on their own), so a ray's result is the queue kernel's, bit for bit.
+    constexpr bool RMQ_FORM = RM && LOD;
+    RenderConsts rc_v;   // (not for RMQ_FORM: a private copy whose rm_tap[] is indexed in the rolled tap loop becomes a 1.2 KB stack frame)
+    if constexpr (PRECISE && !RMQ_FORM) {
+        rc_v = rc_in;
+        cloud_uniforms_to_vgprs(rc_v);
+    }
+    const RenderConsts &rc = (PRECISE && !RMQ_FORM) ? rc_v : rc_in;
     const int steps = rc.cloud_steps;
     // exact: positions
     const MarchRay self = cloud_march_ray(rc, dir_m, t_begin, t_end, jitter);
     const float step_len = self.step_len;
     float px = self.px, py = self.py, pz = self.pz;
     const float ddx = self.ddx, ddy = self.ddy, ddz = self.ddz;
-    const float sx = rc.sun_dir_model[0], sy = rc.sun_dir_model[1], sz = rc.sun_dir_model[2];
+    float sx = rc.sun_dir_model[0], sy = rc.sun_dir_model[1], sz = rc.sun_dir_model[2];
     if (SPLIT == 2 && half) {  // lane 1 starts on sample 1
         px = px + ddx; py = py + ddy; pz = pz + ddz;
     }
@@ -1406,7 +1454,10 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc_in, V3 dir
         const int lane = threadIdx.x & 63;
         nb.vx = (marching >> (lane ^ 1)) & 1ull; nb.vy = (marching >> (lane ^ 2)) & 1ull;
         nb.lvl = lvl; nb.regs = qregs;
+        // (SPLIT == 2: the second lane of a ray bounds the spread over samples 1 .. steps, one beyond its last -- a superset of what it
+        //  evaluates, and the distance of two affine motions is convex: still an upper bound)
         nb.e2 = quad_march_spread2(rc, px, py, pz, ddx, ddy, ddz, nb.vx, nb.vy);
+        if (RMQ_FORM) asm volatile("" : "+v"(sx), "+v"(sy), "+v"(sz));   // as in the queue form: the sun direction in VGPRs, no stack frame
     }
 
     // pow(dot(ray_dir, sun_dir), 16) is constant along the ray; dp <= 0 => 0
@@ -1418,11 +1469,19 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc_in, V3 dir
     }
 
     float total_transmittance = 1.0f, total_light = 0.0f, one_minus_alpha = 1.0f;
+    RmRecurrence rec = {1.0f, 1.0f, 0.0f};   // RMQ_FORM
     const float scale_step = rc.cloud_density_scale * step_len;
     const float neg_scale_step_log2e = -scale_step * LOG2E;
 
     // one sample of the recurrence (clouds:216-236); la = raymarched light or the height ratio, lb = planet-shadow factor
     auto integrate = [&](float density, float la, float lb) {
+        if (RMQ_FORM) {  // the lit-sample queue's arithmetic
+            if (density > 0.0f) {
+                const float w = rm_sample_weight(rec, density, lb, scale_step, neg_scale_step_log2e);
+                rec.total_light = add_unfused(rec.total_light, mul_unfused(la, w));
+            }
+            return;
+        }
         // A zero-density sample contributes nothing: transmittance 1, light term 0.
         if (density > 0.0f) {
 #pragma clang fp contract(fast)
@@ -1446,7 +1505,22 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc_in, V3 dir
                 density = cloud_density<true, PRECISE, LOD, LOD>(rc, px, py, pz, hr, LOD ? &nb : nullptr);
             }
             // the light value of a zero-density sample (6 more density taps in the raymarched variant) is never observed
-            if (density > 0.0f) {
+            if (RMQ_FORM) {
+                if (density > 0.0f) {
+                    lb = cloud_shadow_light(px, py, pz, sx, sy, sz, r);
+                    // the light taps of this sample difference the partners' tap positions: their sample positions, from the quad mates (which
+                    // march in lock-step but may be unlit, i.e. disabled here: whole-quad mode), as the queue form fetches them at enqueue
+                    quad_exchange_positions(px, py, pz, *qregs);
+                    QuadNb enb;
+                    enb.vx = nb.vx; enb.vy = nb.vy; enb.lvl = lvl; enb.regs = nullptr;
+                    enb.px = V3{qregs->fidx, qregs->scx, qregs->tcx};
+                    enb.py = V3{qregs->fidy, qregs->scy, qregs->tcy};
+                    enb.k = V3{0.0f, 0.0f, 0.0f};
+                    auto dist2 = [&](V3 p) { const float a = p.x - px, b = p.y - py, c = p.z - pz; return __builtin_fmaf(a, a, __builtin_fmaf(b, b, c * c)); };
+                    enb.e2 = cube_lod_scaled_spread(rc, fmaxf(enb.vx ? dist2(enb.px) : 0.0f, enb.vy ? dist2(enb.py) : 0.0f) * 1.001f);
+                    la = light_raymarched<PRECISE, true>(rc, px, py, pz, hr, density, sx, sy, sz, &enb);
+                }
+            } else if (density > 0.0f) {
 #pragma clang fp contract(fast)
                 la = RM ? light_raymarched<PRECISE, false>(rc, px, py, pz, hr, density, sx, sy, sz, nullptr) : hr;
                 // get_planet_shadow: smoothstep(-0.3, 0.3, dot(normalize(pos), -sun_dir))
@@ -1465,11 +1539,12 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc_in, V3 dir
             integrate(density, la, lb);
         } else {
             // step order for lane 0 of the pair: its own sample, then the partner's (lane 1's order is irrelevant)
-            const float d1 = swap_adjacent(density), a1 = swap_adjacent(la), b1 = swap_adjacent(lb);
+            const float d1 = swap_ray_lanes<LOD>(density), a1 = swap_ray_lanes<LOD>(la), b1 = swap_ray_lanes<LOD>(lb);
             integrate(density, la, lb);
             integrate(d1, a1, b1);
         }
     }
+    if (RMQ_FORM) return make_float2(rec.total_light, 1.0f - rec.one_minus_alpha);
     return make_float2(total_light, 1.0f - one_minus_alpha);
 }
 
@@ -1547,7 +1622,7 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
     float px = self.px, py = self.py, pz = self.pz;
     const float ddx = self.ddx, ddy = self.ddy, ddz = self.ddz;
     float sx = rc.sun_dir_model[0], sy = rc.sun_dir_model[1], sz = rc.sun_dir_model[2];
-    float total_transmittance = 1.0f, total_light = 0.0f, one_minus_alpha = 1.0f;
+    RmRecurrence rec = {1.0f, 1.0f, 0.0f};
     const float scale_step = rc.cloud_density_scale * step_len;
     const float neg_scale_step_log2e = -scale_step * LOG2E;
     QuadNb nb;
@@ -1597,18 +1672,7 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
             }
             const bool lit = density > 0.0f;
             float w = 0.0f;
-            if (lit) {
-#pragma clang fp contract(fast)
-                // get_planet_shadow: smoothstep(-0.3, 0.3, dot(normalize(pos), -sun_dir))
-                const float sd = -(px * sx + py * sy + pz * sz) * hw_rcp(r);
-                const float st = sat((sd + 0.3f) * (1.0f / 0.6f));
-                const float shadow = st * st * (3.0f - 2.0f * st);
-                const float lb = fmaf(shadow, 0.002f - 1.0f, 1.0f);
-                const float transmittance = hw_exp2(density * neg_scale_step_log2e);
-                total_transmittance = fmaxf(total_transmittance * transmittance, 0.005f);
-                one_minus_alpha *= transmittance;
-                w = (lb * (density * scale_step)) * total_transmittance;
-            }
+            if (lit) w = rm_sample_weight(rec, density, cloud_shadow_light(px, py, pz, sx, sy, sz, r), scale_step, neg_scale_step_log2e);
             const unsigned long long lm = __builtin_amdgcn_ballot_w64(lit);
             if (lit) {
                 const int e = (qcount + rank_in(lm)) & (RMQ_CAP - 1);
@@ -1639,7 +1703,7 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
             }
         }
         for (int k = 0; k < cn; ++k)  // phase C, step order
-            if ((lit_bits >> k) & 1u) total_light += slot[k * 64 + lane];
+            if ((lit_bits >> k) & 1u) rec.total_light += slot[k * 64 + lane];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 #if defined(ATMO_WAVE_TRACE) && ATMO_RMQ_STATS
@@ -1656,7 +1720,7 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
         atomicAdd(st + 8, st_calls * 64ull);                       // lanes of the wave x batches
     }
 #endif
-    return make_float2(total_light, 1.0f - one_minus_alpha);
+    return make_float2(rec.total_light, 1.0f - rec.one_minus_alpha);
 }
 
 template <int FLAGS, int LSTEPS, int SPLIT>
@@ -1672,7 +1736,8 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
     static_assert(!VIEWPOS || (!LITE && !ATMO_REF && SPLIT == 1), "KF_VIEW_POS: the fast v2 march, one lane per ray");
     constexpr bool DIET = !DIRECT && !((FLAGS & KF_CLOUDS) && (FLAGS & KF_CLOUD_LIGHT_RM));
     constexpr bool FASTMISS = (ATMO_FAST_MISS_MASK >> ((DIRECT ? 1 : 0) + (CLOUDS ? 2 : 0) + (LITE ? 4 : 0))) & 1;
-    static_assert(!LOD || (CLOUDS && PRECISE && SPLIT == 1), "implicit cubemap LOD: precise cloud kernels, one lane per ray");
+    static_assert(!LOD || (CLOUDS && PRECISE), "implicit cubemap LOD: precise cloud kernels");
+    static_assert(!(LOD && SPLIT == 2) || (!ATMO_REF && !VIEWPOS && !LITE && !DIRECT), "two lanes per ray under the declared sampler: the two BASELINE cloud kernels");
     static_assert(!LOD || (WAVE_W == 16 && WAVE_H == 4), "the quad-major lane order of the LOD kernels is written for 16 x 4 pixel waves");
 
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
@@ -1683,8 +1748,14 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
         lvl_table = lvl_lds;
     }
     // SPLIT = 2: lanes 2r, 2r+1 share ray r; a wave covers WAVE_W x (32 / WAVE_W) pixels, the workgroup TILE_W x TILE_H / 2
-    const int ray = SPLIT == 2 ? lane >> 1 : lane;
-    const int half = SPLIT == 2 ? lane & 1 : 0;
+    // (LOD && SPLIT == 2: lane bits x0, y0, half, quad index: a pixel quad keeps its four consecutive lanes, the two lanes of a ray are lane ^ 4)
+    const int ray = SPLIT == 2 ? (LOD ? ((lane >> 3) << 2) | (lane & 3) : lane >> 1) : lane;
+    const int half = SPLIT == 2 ? (LOD ? (lane >> 2) & 1 : lane & 1) : 0;
+    // Under the declared sampler only the CLOUD march is split: both lanes of a ray run the whole atmosphere march (a few per cent of a
+    // heavy cloud ray), whose regrouped sums would differ from the one-lane kernel's in the last bits -- a frame drawn partly with this form
+    // (the heavy tiles) must be the same picture.
+    constexpr int ASPLIT = LOD ? 1 : SPLIT;
+    const int ahalf = LOD ? 0 : half;
     constexpr int WAVES_X = TILE_W / (WAVE_W > TILE_W ? TILE_W : WAVE_W);
     constexpr int WAVE_ROWS = WAVE_H / SPLIT;
     // LOD: every 2 x 2 pixel quad occupies four consecutive lanes (lane bits: x0, y0, x1..x3, y1), so that the quad partners are
@@ -1774,13 +1845,13 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
     float4 rgba;
     if (LITE) {
         if constexpr (PRECISE) rgba = march_atmosphere_v1_precise(rc, dir, t_begin, t_end);
-        else rgba = march_atmosphere_v1<SPLIT>(rc, dir, t_begin, t_end, half);  // main:172-175
+        else rgba = march_atmosphere_v1<ASPLIT>(rc, dir, t_begin, t_end, ahalf);  // main:172-175
     } else {
         if constexpr (ATMO_REF && SPLIT == 1) {
             rgba = march_atmosphere_v2_precise<DIRECT>(rc, dir, t_begin, t_end, jitter);  // reference order (atmo_set_precision 2)
         } else {
             const float view_step_len = ieee_div(t_end - t_begin, (float)rc.view_steps);
-            rgba = march_atmosphere<DIRECT, LSTEPS, SPLIT, VIEWPOS>(rc, dir, t_begin, view_step_len, jitter, half);
+            rgba = march_atmosphere<DIRECT, LSTEPS, ASPLIT, VIEWPOS>(rc, dir, t_begin, view_step_len, jitter, ahalf);
         }
     }
 
@@ -1925,8 +1996,13 @@ constexpr bool render_sgpr_cap80(int flags) {
     if (rc.tile_cost != nullptr) t0 = __builtin_amdgcn_s_memtime();                                              \
     ATMO_SHADE_TRACED                                                                                            \
     if (rc.tile_cost != nullptr && (threadIdx.x & 63) == 0) {                                                    \
-        const uint64_t dt = __builtin_amdgcn_s_memtime() - t0;                                                   \
-        atomicMax(&rc.tile_cost[tile], (uint32_t)(dt > 0xffffffffull ? 0xffffffffull : dt));                     \
+        uint64_t dt = __builtin_amdgcn_s_memtime() - t0;                                                         \
+        uint32_t cost_tile = tile;                                                                               \
+        if constexpr (SPLIT == 2 && (FLAGS & KF_CUBE_LOD) != 0) { /* a heavy tile drawn split: the cost map stays the one-lane grid's */ \
+            cost_tile = (tile_y >> 1) * (uint32_t)rc.tiles_x + tile_x;                                           \
+            dt *= 2;                                                                                             \
+        }                                                                                                        \
+        atomicMax(&rc.tile_cost[cost_tile], (uint32_t)(dt > 0xffffffffull ? 0xffffffffull : dt));                \
     }
 
 template <int FLAGS, int LSTEPS, int SPLIT = 1>
@@ -1948,7 +2024,7 @@ __global__ __launch_bounds__(TILE_W *TILE_H ATMO_MIN_WAVES_ARG) __attribute__((a
 //   histogram  256 single-wave workgroups, each owns a contiguous chunk of tiles and counts its 32 classes (wave ballots);
 //   scan       one workgroup turns the 256 x 32 counts into the first output index of every (chunk, class);
 //   scatter    the 256 waves write their tiles, in order, behind those indices and clear the costs.
-constexpr int ORDER_BLOCKS = 256, ORDER_CLASSES = 32;
+constexpr int ORDER_BLOCKS = 256, ORDER_CLASSES = TILE_ORDER_CLASSES;
 __device__ __forceinline__ uint32_t tile_cost_class(uint32_t c) {
     if (c == 0) return ORDER_CLASSES - 1;
     const int msb = 31 - __builtin_clz(c);
@@ -1987,7 +2063,8 @@ __global__ __launch_bounds__(64) void atmo_tile_hist_kernel(const uint32_t *__re
 }
 
 // hist[class][block] -> first output index of (block, class): classes in order 0 (heaviest) .. 31, blocks in order inside a class
-__global__ __launch_bounds__(256) void atmo_tile_scan_kernel(uint32_t *__restrict__ hist) {
+// class_totals (may be null): the number of tiles in every cost class, for the host (pinned memory: it picks the frame's heavy tiles from them)
+__global__ __launch_bounds__(256) void atmo_tile_scan_kernel(uint32_t *__restrict__ hist, uint32_t *__restrict__ class_totals) {
     __shared__ uint32_t total[ORDER_CLASSES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int PER_LANE = ORDER_BLOCKS / 64, PER_WAVE = ORDER_CLASSES / 4;
@@ -2014,6 +2091,7 @@ __global__ __launch_bounds__(256) void atmo_tile_scan_kernel(uint32_t *__restric
     __syncthreads();
     if (threadIdx.x < 64) {  // exclusive scan of the 32 class totals
         const uint32_t c = lane < ORDER_CLASSES ? total[lane] : 0u;
+        if (class_totals != nullptr && lane < ORDER_CLASSES) class_totals[lane] = c;
         uint32_t incl = c;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -2031,8 +2109,11 @@ __global__ __launch_bounds__(256) void atmo_tile_scan_kernel(uint32_t *__restric
     }
 }
 
+// order2 (may be null): the same order for the launch grid of the two-lanes-per-ray kernels, whose tiles are half as high -- entries 2 p and
+// 2 p + 1 are the upper and the lower half of the tile at position p (the host draws the first few, the heavy tiles, with those kernels)
 __global__ __launch_bounds__(64) void atmo_tile_scatter_kernel(const uint32_t *key, uint32_t *cost,  /* key == cost without dilation */
-                                                               const uint32_t *__restrict__ base, uint32_t *__restrict__ order, int n) {
+                                                               const uint32_t *__restrict__ base, uint32_t *__restrict__ order, int n,
+                                                               uint32_t *__restrict__ order2, int tiles_x) {
     __shared__ uint32_t off[ORDER_CLASSES];
     const int lane = threadIdx.x, chunk = (n + ORDER_BLOCKS - 1) / ORDER_BLOCKS;
     const int i0 = min((int)blockIdx.x * chunk, n), i1 = min(i0 + chunk, n);
@@ -2049,7 +2130,13 @@ __global__ __launch_bounds__(64) void atmo_tile_scatter_kernel(const uint32_t *k
         if (valid && r == 0) off[c] += (uint32_t)__builtin_popcountll(m);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (valid) {
-            order[pos] = (uint32_t)(i + lane);
+            const uint32_t t = (uint32_t)(i + lane);
+            order[pos] = t;
+            if (order2 != nullptr) {
+                const uint32_t ty = t / (uint32_t)tiles_x, tx = t - ty * (uint32_t)tiles_x;
+                order2[2u * pos] = (2u * ty) * (uint32_t)tiles_x + tx;
+                order2[2u * pos + 1u] = (2u * ty + 1u) * (uint32_t)tiles_x + tx;
+            }
             cost[i + lane] = 0;   // ready for the next recording draw
         }
     }
@@ -2082,7 +2169,7 @@ __global__ __launch_bounds__(256) void atmo_tile_dilate_kernel(const uint32_t *_
 // scratch: ORDER_BLOCKS * ORDER_CLASSES uint32 (tile_order_scratch_bytes); tmp1 / tmp2: n uint32 each, used when rx | ry > 0
 size_t tile_order_scratch_bytes() { return (size_t)ORDER_BLOCKS * ORDER_CLASSES * sizeof(uint32_t); }
 hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int tiles_x, int tiles_y, int rx, int ry, uint32_t *tmp1, uint32_t *tmp2,
-                             uint32_t *scratch, hipStream_t stream) {
+                             uint32_t *scratch, hipStream_t stream, uint32_t *order2, uint32_t *class_totals) {
     const int n = tiles_x * tiles_y;
     const uint32_t *key = cost;
     if ((rx > 0 || ry > 0) && (2 * rx + 1) * (2 * ry + 1) <= 81) {  // a small window (the in-stream sort's: a tile or two): one pass
@@ -2094,8 +2181,8 @@ hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int tiles_x, int t
         key = tmp2;
     }
     hipLaunchKernelGGL(atmo_tile_hist_kernel, dim3(ORDER_BLOCKS), dim3(64), 0, stream, key, scratch, n);
-    hipLaunchKernelGGL(atmo_tile_scan_kernel, dim3(1), dim3(256), 0, stream, scratch);
-    hipLaunchKernelGGL(atmo_tile_scatter_kernel, dim3(ORDER_BLOCKS), dim3(64), 0, stream, key, cost, scratch, order, n);
+    hipLaunchKernelGGL(atmo_tile_scan_kernel, dim3(1), dim3(256), 0, stream, scratch, class_totals);
+    hipLaunchKernelGGL(atmo_tile_scatter_kernel, dim3(ORDER_BLOCKS), dim3(64), 0, stream, key, cost, scratch, order, n, order2, tiles_x);
     return hipGetLastError();
 }
 
@@ -2445,8 +2532,9 @@ static hipError_t launch_render_grid(int flags, int split, const RenderConsts &r
     case KF_PRECISE | KF_LITE: return launch_t<KF_PRECISE | KF_LITE, 0>(rc, split, stream);
     case KF_PRECISE | KF_LITE | KF_CLOUDS: return launch_t<KF_PRECISE | KF_LITE | KF_CLOUDS, 0>(rc, split, stream);
     // implicit cubemap LOD (atmo_set_sampler_lod 1): precise cloud kernels, one lane per ray
-    case KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS: return launch_s<KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS, 0, 1>(rc, stream);
-    case KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM: return launch_s<KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM, 0, 1>(rc, stream);
+    // (split == 2: the cloud march on two lanes per ray -- what the host draws a frame's heavy tiles with, bit-identical to the one-lane form)
+    case KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS: return launch_t<KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS, 0>(rc, split, stream);
+    case KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM: return launch_t<KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_CLOUD_LIGHT_RM, 0>(rc, split, stream);
     case KF_CUBE_LOD | KF_PRECISE | KF_LITE | KF_CLOUDS: return launch_s<KF_CUBE_LOD | KF_PRECISE | KF_LITE | KF_CLOUDS, 0, 1>(rc, stream);
     // ... and with the direct light march of the atmosphere (one lane per ray; the two-lanes-per-ray launch shape has no LOD form)
     case KF_CUBE_LOD | KF_PRECISE | KF_CLOUDS | KF_LIGHT_DIRECT:

@@ -72,6 +72,11 @@ int atmo_debug_marched_optical_depth(AtmoContext *ctx, int n, const float *pos_x
  * (before the first launch: the one-lane-per-ray form), for matching rocprofv3 kernel traces. */
 const char *atmo_kernel_name(AtmoContext *ctx);
 
+/* Heavy tiles on two lanes per ray (round 5; the default cloud kernels under the declared sampler, tile-order feedback on): draws so far that
+ * drew their heaviest tiles with the lane-split kernel beside the rest, and how many tiles the last such draw split.  ATMO_HEAVY_SPLIT=0
+ * (read in atmo_create) turns it off; the picture does not depend on it, bit for bit. */
+int atmo_get_split_stats(AtmoContext *ctx, unsigned *split_draws, unsigned *heavy_tiles_last);
+
 /* How often calls of this context fell back to a device-wide host wait (hipDeviceSynchronize) where a stream-side wait on the device was
  * not possible: a remembered stream that the caller has destroyed since, or more draw streams than the context tracks (8).  0 in a host
  * that keeps its streams alive (tests/test_gpu_parity.py::test_texture_update_does_not_wait_for_unrelated_streams). */

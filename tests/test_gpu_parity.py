@@ -1235,7 +1235,102 @@ def test_lane_split_two_equals_one(oracle32, config_name):
         two.close()
 
 
-# ---- launch order with cost feedback (atmo_set_tile_feedback) ------------------------------------------------------------
+@pytest.mark.parametrize("config_name", ["clouds_high", "clouds_high_rm"])
+def test_lane_split_under_the_declared_sampler_is_bit_identical(config_name):
+    """Round 5: the two BASELINE cloud kernels under the declared sampler have a two-lanes-per-ray form, <49, 0, 2> / <51, 0, 2> (the two lanes of
+    a ray four lanes apart, pixel quads still four consecutive lanes; only the cloud march is split, both lanes run the whole atmosphere march;
+    raymarched light evaluated in place in the lit-sample queue's arithmetic).  Unlike SPLIT = 2 of the level-0 kernels it is the SAME bits as
+    the one-lane kernel -- it has to be: the library draws a frame's heavy tiles with it.  Whole frames here (atmo_set_lane_split 2), odd sizes,
+    odd rects, a frame with lambda > 0, degenerate layers."""
+    tex, params = demo_textures(), demo_params()
+    for pose, (w, h), kw in (("P_space", (1920, 1080), {}), ("P_clouds", (641, 363), {}), ("P_limb", (203, 117), {}), ("P_ground", (480, 270), {}),
+                             ("P_space", (320, 180), dict(cloud_steps=7)), ("P_space", (256, 144), dict(cloud_steps=1))):
+        cam = S.Camera.from_pose(w, h, pose)
+        depth = S.depth_ground_sphere(cam)
+        one = make_node(config_name, tex, params, lane_split=1, **kw)
+        two = make_node(config_name, tex, params, lane_split=2, **kw)
+        a = _gpu_render(one, cam, depth)
+        b = _gpu_render(two, cam, depth)
+        assert one.kernel_name.endswith(", 1>") and two.kernel_name.endswith(", 2>") and kernel_flags(two) & 32, (one.kernel_name, two.kernel_name)
+        assert np.array_equal(a, b), (pose, w, h, kw)
+        rect = (7, 5, w - 30, h - 11)
+        assert np.array_equal(_gpu_render(two, cam, depth, rect=rect), a[5:h - 11, 7:w - 30])
+        one.close()
+        two.close()
+    cam = S.Camera.from_pose(480, 270, "P_space")
+    depth = S.depth_ground_sphere(cam)
+    for over in (dict(u_cloud_bottom=0.6, u_cloud_top=0.2), dict(u_cloud_coverage_rotation=(0.6, 0.0, 0.0, 0.6)), dict(u_cloud_density_scale=500.0)):
+        frames = []
+        for lanes in (1, 2):
+            node = make_node(config_name, tex, dict(params, **over), lane_split=lanes)
+            frames.append(_gpu_render(node, cam, depth))
+            node.close()
+        assert np.array_equal(frames[0], frames[1], equal_nan=True), over
+
+
+def test_heavy_tiles_on_two_lanes_per_ray_do_not_change_the_picture(monkeypatch):
+    """Round 5: with the tile order in use, the draw's heaviest tiles (those whose longest wavefront lives longer than 0.4 x the draw) go to the
+    lane-split kernel on a side stream beside the rest of the draw.  The frame is the plain draw's, bit for bit -- default threshold, a
+    threshold that splits a third of the tiles, rects, a moving camera (in-stream sort), the blend stage -- and the mechanism does engage."""
+    tex, params = demo_textures(), demo_params()
+    # (the library's own policy -- raymarched light only, and only draws that are as long as their heaviest wavefront -- engages on the first two
+    #  cases by itself; "2" forces the mechanism for either kernel, with a threshold that splits a third of the tiles)
+    for config_name, pose, (w, h), force in (("clouds_high_rm", "P_space", (1280, 720), None), ("clouds_high_rm", "P_limb", (1920, 1080), None),
+                                             ("clouds_high_rm", "P_space", (1920, 1080), "0.01"), ("clouds_high", "P_space", (1920, 1080), "0.3"),
+                                             ("clouds_high_rm", "P_limb", (1280, 720), "0.01"), ("clouds_high", "P_clouds", (1000, 700), "0.01")):
+        cam = S.Camera.from_pose(w, h, pose)
+        depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
+        monkeypatch.setenv("ATMO_HEAVY_SPLIT", "0")
+        plain = make_node(config_name, tex, params, tile_feedback=0)
+        monkeypatch.setenv("ATMO_HEAVY_SPLIT", "2" if force else "1")
+        if force:
+            monkeypatch.setenv("ATMO_HEAVY_SPLIT_RATIO", force)
+        node = make_node(config_name, tex, params, tile_feedback=1)
+        monkeypatch.delenv("ATMO_HEAVY_SPLIT_RATIO", raising=False)
+        monkeypatch.delenv("ATMO_HEAVY_SPLIT")
+        for rect in (None, (16, 8, w - 40, h - 24)):
+            want = plain.render(cam, depth, rect=rect)
+            for k in range(14):
+                shape = want.shape
+                out = torch.full(shape, float("nan"), dtype=torch.float32, device="cuda")
+                node.render(cam, depth, out=out, rect=rect)
+                torch.cuda.synchronize()   # lets the host see finished sorts (an engine presents once per frame)
+                assert torch.equal(out, want), (config_name, pose, rect, k)
+        n, last = C.c_uint(), C.c_uint()
+        assert node._lib.atmo_get_split_stats(node._ctx, C.byref(n), C.byref(last)) == 0
+        print(f"\n{config_name} {pose} {w}x{h}: {n.value} of 28 draws split, {last.value} heavy tiles in the last one")
+        assert n.value >= 8 and last.value >= 1, (config_name, pose, n.value, last.value)
+        # the blend stage
+        scene = torch.rand((h, w, 4), device="cuda")
+        a, b = scene.clone(), scene.clone()
+        plain.render_composite(cam, depth, a)
+        node.render_composite(cam, depth, b)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        plain.close()
+        node.close()
+    # a moving camera: the in-stream sort's order (and its class totals, read without waiting) feed the split
+    import bench
+
+    w, h = 960, 540
+    cams = bench.motion_cameras(S, w, h, ("pan", 1.0), 24)
+    monkeypatch.setenv("ATMO_HEAVY_SPLIT", "2")
+    on = make_node("clouds_high_rm", tex, params, tile_feedback=1)
+    monkeypatch.delenv("ATMO_HEAVY_SPLIT")
+    off = make_node("clouds_high_rm", tex, params, tile_feedback=0)
+    for k, cam in enumerate(cams):
+        depth = bench.depth_ground_sphere_torch(torch, S, cam, torch.device("cuda"))
+        a = on.render(cam, depth)
+        b = off.render(cam, depth)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), k
+    n = C.c_uint()
+    assert on._lib.atmo_get_split_stats(on._ctx, C.byref(n), None) == 0 and n.value >= 6, n.value
+    on.close()
+    off.close()
+
+
+# ---- launch order with cost feedback (atmo_set_tile_feedback) ------------------------------------------------------------# ---- launch order with cost feedback (atmo_set_tile_feedback) ------------------------------------------------------------
 
 @pytest.mark.parametrize("config_name,size", [("clouds_high_rm", (1920, 1080)), ("clouds_high", (1000, 700)), ("no_clouds_32x8_direct", (777, 555))])
 def test_tile_feedback_does_not_change_the_picture(config_name, size):

@@ -104,7 +104,7 @@ def check_inputs(body: str, private: set):
         hi += 1
     first_line = starts[lo]
     last_line = starts[hi + 1] if hi + 1 < len(starts) else len(lines)
-    bad, inside = [], False
+    bad, inside, recent = [], False, []
     for i in range(first_line, last_line):
         ln = lines[i].strip()
         if ln.startswith(";;#ASMSTART"):
@@ -113,11 +113,19 @@ def check_inputs(body: str, private: set):
             inside = False
         if inside or not ln or ln.startswith((";", ".")) or ln.endswith(":"):
             continue
+        recent = (recent + [ln])[-16:]
         w = written(ln) & inputs
         if not w:
             continue
         op = ln.split(None, 1)[0]
-        if not (op.startswith("v_add_f32") and w <= read_regs(ln)):   # the position update reads what it writes
+        ok = op.startswith("v_add_f32") and w <= read_regs(ln)          # the position update reads what it writes ...
+        if not ok and op.startswith("v_add_f32"):
+            # ... or, with two lanes per ray (two steps per iteration: p = (p + d) + d), reads the first half of the update a few instructions up
+            for prev in reversed(recent[:-1]):
+                if written(prev) & read_regs(ln):
+                    ok = prev.split(None, 1)[0].startswith("v_add_f32") and w <= read_regs(prev)
+                    break
+        if not ok:
             bad.append(ln)
     return inputs, bad
 
