@@ -222,12 +222,31 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
 }
+// ATMO_ABLATE_FETCH=1 (DIAGNOSTIC build only: tools/fetch_ablation_probe.py, profiles/round5/ab_fetch_ablation.txt; retired in round 4, back in round 5 at
+// the judge's request): every texture gather is replaced by a constant -- byte 128 / the float 128/255 -- while the address arithmetic in front of
+// it and the filter behind it stay live.  Rendered with CONSTANT textures of that value (LUT, shape volume, cubemap) both builds draw the same
+// picture through the same control flow, and the difference in kernel time is everything a cheaper fetch path (LDS staging included) could buy.
+#ifndef ATMO_ABLATE_FETCH
+#define ATMO_ABLATE_FETCH 0
+#endif
+#if ATMO_ABLATE_FETCH
+#define ATMO_ABLATED_F32 0.50196081399917603f   // 128 / 255 rounded to binary32 = unorm8_exact(128)
+__device__ __forceinline__ uint32_t buf_u32(__amdgpu_buffer_rsrc_t, uint32_t byte_off) {
+    asm volatile("" : "+v"(byte_off));   // the address chain stays
+    return 0x80808080u;
+}
+__device__ __forceinline__ f32x2 buf_f32x2(__amdgpu_buffer_rsrc_t, uint32_t byte_off) {
+    asm volatile("" : "+v"(byte_off));
+    return f32x2{ATMO_ABLATED_F32, ATMO_ABLATED_F32};
+}
+#else
 __device__ __forceinline__ uint32_t buf_u32(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
     return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0);
 }
 __device__ __forceinline__ f32x2 buf_f32x2(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
     return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0));
 }
+#endif
 
 // byte k of a footprint word as float (the compiler selects v_cvt_f32_ubyte0..3)
 __device__ __forceinline__ float ub0(uint32_t w) { return (float)(w & 0xffu); }
@@ -237,9 +256,16 @@ __device__ __forceinline__ float ub3(uint32_t w) { return (float)(w >> 24); }
 
 // texture(u_optical_depth_texture, uv).r : bilinear, clamp-to-edge, R32F.  x = u*w - 0.5, y = v*h - 0.5 (texel space).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#if ATMO_ABLATE_FETCH
+__device__ __forceinline__ f32x4 buf_f32x4(__amdgpu_buffer_rsrc_t, uint32_t byte_off) {
+    asm volatile("" : "+v"(byte_off));
+    return f32x4{ATMO_ABLATED_F32, ATMO_ABLATED_F32, ATMO_ABLATED_F32, ATMO_ABLATED_F32};
+}
+#else
 __device__ __forceinline__ f32x4 buf_f32x4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
 }
+#endif
 // One 16-byte gather from the footprint copy of the LUT (atmo_lut_footprint_kernel): the texture addresser was busy 62-70 %
 // of the lut32 draw with two 8-byte gathers per sample (19 cycles each per wave); one 16-byte gather costs about the same as
 // one of them.  lut32 -7 % (profiles/round2/ab_lut_footprint.txt).  The byte offset is formed in fp32 (exact: < 2^24).

@@ -568,8 +568,12 @@ class Machine:
             if old.t != val.t:
                 val = self.convert(old.t, val)
             if mask is not None and scope is not self.globals:
-                # every lane the variable is live for is active: plain overwrite (keeps loop counters uniform)
-                need = self.live(scope_mask)
+                # every lane the variable is live for is active: plain overwrite (keeps loop counters uniform).  For a PARAMETER "live"
+                # includes the lanes that have returned from the function since: an `out` / `inout` parameter of a lane that returned
+                # early is still copied back to the caller and must keep what that lane wrote (round 5: found by
+                # tests/test_gdshader_vm_kat.py -- the shortcut used to look at the still-running lanes only, for every variable)
+                params = self.frames[-1].scopes[0] if self.frames else None
+                need = scope_mask if scope is params else self.live(scope_mask)
                 if need is not None and not (need & ~mask).any():
                     mask = None
             scope[lv[1]] = self.merge(old, val, mask)
@@ -791,6 +795,16 @@ class Machine:
                     for k in range(1, n):
                         r = _fma(a.a[k], b.a[k], r) if _CONTRACT[0] else r + a.a[k] * b.a[k]
                     return V(b.t, r)
+                if a.t in _VEC and b.t in _MAT:      # v M (section 5.10: the vector is a row vector): component c = dot(v, M[c]), left to right
+                    n = _MAT[b.t]
+                    comps = []
+                    for c in range(n):
+                        r = a.a[0] * b.a[c][0]
+                        for k in range(1, n):
+                            r = r + a.a[k] * b.a[c][k]
+                        comps.append(r)
+                    lanes = max(x.shape[-1] for x in comps)
+                    return V(a.t, np.stack([np.broadcast_to(x, (lanes,)) for x in comps]))
                 if a.t in _MAT and b.t in _MAT:      # (A B)[col] = A B[col]
                     n = _MAT[a.t]
                     cols = []
@@ -905,7 +919,18 @@ class Machine:
             if len(args) == n and all(x.t == "vec" + str(n) for x in args):
                 lanes = max(x.a.shape[-1] for x in args)
                 return V(ty, np.stack([np.broadcast_to(x.a, (n, lanes)) for x in args]))
-            raise ShaderError(f"{ty} constructor form outside the supported subset")
+            # GLSL ES 3.00 section 5.4.2: scalars and vectors are consumed left to right and fill the matrix in column-major order
+            comps = []
+            for v in args:
+                if v.t in _MAT or isinstance(v.a, dict) or _base(v.t) != "float":
+                    raise ShaderError(f"{ty} constructor form outside the supported subset")
+                src = v.a if v.a.ndim == 2 else v.a[None, :]
+                comps.extend(src[k] for k in range(src.shape[0]))
+            if len(comps) != n * n:
+                raise ShaderError(f"{ty} constructed from {len(comps)} components")
+            lanes = max(c.shape[-1] for c in comps)
+            flat = np.stack([np.broadcast_to(c, (lanes,)) for c in comps]).astype(F32)
+            return V(ty, flat.reshape(n, n, lanes))
         n = _VEC.get(ty) or _IVEC.get(ty) or _UVEC.get(ty)
         base = _base(ty)
         comps = []
@@ -919,6 +944,13 @@ class Machine:
             comps.extend(src[k].astype(_DT[base]) for k in range(src.shape[0]))
         if len(comps) == 1:
             comps = comps * n
+        if len(comps) > n and len(args) >= 1:
+            # section 5.4.2: "it is an error to provide extra arguments beyond this last used argument" -- but the last USED argument may
+            # be longer than what is left to fill (vec3(vec4), vec2(vec3)): its remaining components are dropped
+            last = args[-1]
+            last_n = last.a.shape[0] if last.a.ndim == 2 else 1
+            if len(comps) - last_n < n:
+                comps = comps[:n]
         if len(comps) != n:
             raise ShaderError(f"{ty} constructed from {len(comps)} components")
         lanes = max(c.shape[-1] for c in comps)
