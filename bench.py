@@ -303,9 +303,11 @@ def parse_args():
                     help="--shard tiles: lanes per ray of every rank's draw (atmo_set_lane_split; 2 halves the longest wavefronts of a share -- "
                          "what bounds a strong-scaled cloud frame -- for 13-29 %% more work; LOD-0 sampler only)")
     ap.add_argument("--also", default="lut32,shipped8,clouds_high,clouds_high_rm,direct32x8@3840x2160,clouds_high_rm@3840x2160,"
-                                      "clouds_high@lod0,clouds_high_rm@lod0,clouds_high_rm@lod0@3840x2160,direct32x8@moving,clouds_high_rm@moving,"
+                                      "clouds_high@lod0,clouds_high_rm@lod0,clouds_high_rm@lod0@3840x2160,"
+                                      "clouds_high_rm@1280x720,clouds_high_rm@1280x720@nosplit,clouds_high_rm@P_limb,clouds_high_rm@P_limb@nosplit,"
+                                      "direct32x8@moving,clouds_high_rm@moving,"
                                       "direct32x8@reforder,shipped8@cleared,lut32@cleared,noise_cubemap,direct32x8+2vp",
-                    help="comma-separated extra workloads (name[@lod0][@reforder][@cleared][@WxH], name@moving, name+2vp) timed at N=1 after the headline and reported under "
+                    help="comma-separated extra workloads (name[@lod0][@reforder][@cleared][@nosplit][@P_pose][@WxH], name@moving, name+2vp) timed at N=1 after the headline and reported under "
                          "'extra', each with its own roofline blocks: the reference-exact LUT mode and the shipped 8-step shader "
                          "(SURVEY.md 8d), BASELINE configs[2] (clouds_high 1080p) and configs[3] (clouds_high_rm 3840x2160); '' to skip.  "
                          "name+2vp goes LAST: after two contexts have drawn concurrently on two extra streams, later single-stream draws of the "
@@ -679,7 +681,7 @@ CLOUD_WEIGHT = 8.0
 
 
 def run_workload(torch, S, name, w, h, pose, steps, warmup, textures, params, local_rank, with_frame_stats=True,
-                 motion=None, node_extra=None, sampler=None):
+                 motion=None, node_extra=None, sampler=None, env=None):
     """One single-GPU workload: returns the result dictionary of an `extra` entry (rate, kernel time, both rooflines).
     motion: None or (kind, degrees per frame): a new camera pose every step (time_workload); node_extra: PlanetAtmosphere
     keyword arguments (tile_feedback=0 ...); sampler: None / "declared" (the library's default) or "lod0" -- the coverage cubemap's sampler."""
@@ -692,7 +694,16 @@ def run_workload(torch, S, name, w, h, pose, steps, warmup, textures, params, lo
         kw["cubemap_lod"] = False
     elif os.environ.get("ATMO_BENCH_EXPLICIT_SAMPLER") == "1":
         kw["cubemap_lod"] = CONFIGS_HAS_CLOUDS(config_name)   # tools/ab_bench.sh: the same kernels, selected in the way libraries built before round 4 understand too
-    node = make_node(config_name, textures, params, device=local_rank, **kw)
+    saved = {k: os.environ.get(k) for k in (env or {})}   # A/B switches the library reads once, in atmo_create (ATMO_HEAVY_SPLIT=0 ...)
+    os.environ.update(env or {})
+    try:
+        node = make_node(config_name, textures, params, device=local_rank, **kw)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     cam = S.Camera.from_pose(w, h, pose)
     sequence = None
     if motion is not None:
@@ -709,6 +720,7 @@ def run_workload(torch, S, name, w, h, pose, steps, warmup, textures, params, lo
     res = {"workload": f"{desc}{workload_suffix(config_name, sampler)}; {w}x{h}; demo scene, pose {pose}"
                        + ("; atmosphere march in the reference's operation order (atmo_set_precision 2: validation mode)" if ref_order else "")
                        + ("; discarded fragments store nothing (atmo_set_target_cleared 1)" if (node_extra or {}).get("target_cleared") else "")
+                       + ("; heavy tiles NOT drawn on two lanes per ray (ATMO_HEAVY_SPLIT=0)" if (env or {}).get("ATMO_HEAVY_SPLIT") == "0" else "")
                        + ("" if motion is None else f", camera motion {motion[0]} {motion[1]:g} deg/frame, a new pose every step, "
                                                     f"{len(sequence)} poses replayed ping-pong, host at most {FRAMES_IN_FLIGHT} frames ahead"),
            "Mrays/s": w * h * steps / run.dt / 1e6,
@@ -718,6 +730,7 @@ def run_workload(torch, S, name, w, h, pose, steps, warmup, textures, params, lo
     if with_frame_stats:
         res["hit_fraction"] = float((run.out.abs().sum(dim=-1) > 0).float().mean().item())
     res["feedback_stats"] = node.feedback_stats()
+    res["split_stats"] = node.split_stats()   # draws whose heaviest tiles went to the two-lanes-per-ray kernel, tiles in the last such draw
     node.close()
     del run, depth, sequence
     return res
@@ -999,18 +1012,22 @@ def main():
             if "moving" in opts:
                 extra[item] = bench_motion(torch, S, name, w, h, max(64, ex_steps), ex_warm, textures, params, local_rank)
                 continue
-            ew, eh, sampler, node_extra = w, h, None, None
+            ew, eh, sampler, node_extra, epose, env = w, h, None, None, args.pose, None
             for o in opts:
                 if o == "lod0":
                     sampler = "lod0"
+                elif o == "nosplit":   # ATMO_HEAVY_SPLIT=0: every tile with one lane per ray (the A/B of round 5's heavy-tile split)
+                    env = {"ATMO_HEAVY_SPLIT": "0"}
+                elif o.startswith("P_"):
+                    epose = o
                 elif o == "reforder":  # atmo_set_precision 2: the v2 march in the reference's operation order (validation mode)
                     node_extra = dict(precise_atmosphere=True)
                 elif o == "cleared":  # atmo_set_target_cleared 1: discarded fragments store nothing (the shader's `discard`)
                     node_extra = dict(target_cleared=True)
                 else:
                     ew, eh = (int(v) for v in o.split("x"))
-            extra[item] = run_workload(torch, S, name, ew, eh, args.pose, ex_steps, ex_warm, textures, params, local_rank, sampler=sampler,
-                                       node_extra=node_extra)
+            extra[item] = run_workload(torch, S, name, ew, eh, epose, ex_steps, ex_warm, textures, params, local_rank, sampler=sampler,
+                                       node_extra=node_extra, env=env)
         result["extra"] = extra
     if multi and not strong and args.workload == "direct32x8" and os.environ.get("ATMO_BENCH_NO_CONFIG4") != "1":
         # BASELINE.json configs[4]: independent 3840x2160 clouds_high_rm viewports, one per GPU, gathered to rank 0 over xGMI

@@ -650,6 +650,13 @@ class PlanetAtmosphere:
         rows = np.repeat(cost.astype(np.float64).sum(axis=1) / th.value, th.value)[: y1 - y0]
         return rows
 
+    def split_stats(self) -> dict:
+        """atmo_get_split_stats: draws so far whose heaviest tiles were drawn with two lanes per ray beside the rest, and how many tiles the last
+        such draw split (the raymarched-light kernel under the declared sampler, when a draw is as long as its heaviest wavefront)."""
+        n, last = C.c_uint(0), C.c_uint(0)
+        N.check(self._ctx, self._lib.atmo_get_split_stats(self._ctx, C.byref(n), C.byref(last)))
+        return {"split_draws": int(n.value), "heavy_tiles_last": int(last.value)}
+
     def feedback_stats(self) -> dict:
         """atmo_get_feedback_stats (diagnostics of the tile-order feedback)."""
         st, od, so, rc = C.c_int(0), C.c_uint(0), C.c_uint(0), C.c_uint(0)
