@@ -54,7 +54,7 @@ SPEC_CLOCK_GHZ = 2.4
 #      while another wave's fast ops use the second: a mix costs max(4.1 S, 2.2 (S + F)).
 ISSUE_SPEC = {"valu": 2.0, "trans": 8.0}
 ISSUE_MEASURED = {"fast": 2.2, "slow": 4.1, "trans": 8.1, "poison_cycles_per_trans": 3.4}
-PROFILE_DIR = "profiles/round4"  # no fallback to earlier rounds: "clouds_high" meant the LOD-0 sampler there
+PROFILE_DIR = "profiles/round5"  # no fallback to earlier rounds: "clouds_high" meant the LOD-0 sampler there
 COMPACT_LIMIT = 6144         # bytes of the final stdout line (the driver keeps the last 8 KB of stdout)
 
 
