@@ -1059,7 +1059,7 @@ def main_tile_strips(args, torch, dist, S, textures, params, config_name, desc, 
     of every frame is inside the timed region).  Strong scaling; `value` = the viewport's rays per second of assembled frames."""
     import numpy as np
     from godot_atmosphere_shader_amd.demo import make_node
-    from godot_atmosphere_shader_amd.sharding import STRIP_TILE_ROWS, StripGather, lpt_strips
+    from godot_atmosphere_shader_amd.sharding import STRIP_TILE_ROWS, StripGather, heavy_tiles, lpt_strips
 
     w, h = args.width, args.height
     device = torch.device("cuda", local_rank)
@@ -1081,13 +1081,16 @@ def main_tile_strips(args, torch, dist, S, textures, params, config_name, desc, 
     dist.broadcast(cost_t, src=0)
     strips, tiles = lpt_strips(cost_t.cpu().numpy(), world)
     my_tiles = torch.from_numpy(tiles[rank].astype(np.int32)).to(device)
+    # round 5: a share of one frame is as long as its heaviest wavefront from two GPUs on -- its heavy tiles go on two lanes per ray beside the rest
+    # (atmo_render_tiles_split; the declared-sampler cloud kernels, bit-identical; elsewhere the library ignores the count)
+    my_heavy = heavy_tiles(cost_t.cpu().numpy().reshape(-1)[tiles[rank]]) if not args.lanes else 0
     g = StripGather(h, w, strips, STRIP_TILE_ROWS * th, device, dst=0)
     frame = node.prepare_frame(cam)
     stream = torch.cuda.current_stream().cuda_stream
     target = g.render_target()
 
     def draw():
-        node.render_tiles_prepared(frame, depth.data_ptr(), target.data_ptr(), my_tiles.data_ptr(), my_tiles.numel(), stream)
+        node.render_tiles_prepared(frame, depth.data_ptr(), target.data_ptr(), my_tiles.data_ptr(), my_tiles.numel(), stream, n_heavy=my_heavy)
 
     def loop(n, gather):
         for _ in range(n):

@@ -28,7 +28,7 @@ CORE_SYMBOLS = (
 DEBUG_SYMBOLS = (
     "atmo_set_lane_split", "atmo_debug_motion_px", "atmo_get_feedback_stats", "atmo_set_timing", "atmo_get_timing", "atmo_host_layout_cubemap", "atmo_host_layout_shape",
     "atmo_host_layout_lut", "atmo_host_cubemap_mip", "atmo_read_texture_layout", "atmo_selftest_exact_math", "atmo_debug_marched_optical_depth", "atmo_kernel_name",
-    "atmo_get_host_wait_stats", "atmo_get_split_stats", "atmo_debug_create_host_only", "atmo_debug_frame_constants",
+    "atmo_get_host_wait_stats", "atmo_get_split_stats", "atmo_render_tiles_split", "atmo_debug_create_host_only", "atmo_debug_frame_constants",
 )
 EXPORTED_SYMBOLS = CORE_SYMBOLS + DEBUG_SYMBOLS
 
@@ -112,6 +112,7 @@ def load() -> C.CDLL:
         "atmo_kernel_name": (cp, [vp]),
         "atmo_get_host_wait_stats": (ip, [vp, C.POINTER(C.c_uint)]),
         "atmo_get_split_stats": (ip, [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+        "atmo_render_tiles_split": (ip, [vp, C.POINTER(AtmoFrame), vp, vp, vp, ip, ip, vp]),
         "atmo_debug_create_host_only": (ip, [ip, ip, ip, ip, ip, C.POINTER(vp)]),
         "atmo_debug_frame_constants": (ip, [vp, C.POINTER(AtmoFrame), ip, C.POINTER(C.c_float), ip, C.POINTER(ip)]),
         "atmo_last_error_string": (cp, [vp]),

@@ -166,6 +166,7 @@ struct AtmoContext {
     hipStream_t split_stream = nullptr;                // the heavy tiles of a frame, on two lanes per ray, run here beside the rest of the draw
     int heavy_split = 1;                               // ATMO_HEAVY_SPLIT=0 (A/B): every tile with one lane per ray; 2 (tests): also the kernel without raymarched light, no trigger
     float heavy_split_trigger = 1.5f;                  // ATMO_HEAVY_SPLIT_TRIGGER: only when the heaviest class lives longer than this x the draw's estimated duration ...
+    float heavy_split_trigger_moving = 2.0f;           // ATMO_HEAVY_SPLIT_TRIGGER_MOVING: the trigger while the order comes from the in-stream sort (a moving camera)
     float heavy_split_ratio = 0.3f;                    // ATMO_HEAVY_SPLIT_RATIO: ... the tiles whose longest wave lives longer than this x that estimate are heavy
     unsigned split_draws = 0, split_tiles_last = 0;    // atmo_get_split_stats
     DeviceBuffer fb_scratch;                           // the sort's block histograms (sorts are serialised on fb_stream)
@@ -816,6 +817,7 @@ int atmo_create(int device, int variant, int view_steps, int cloud_steps, int li
     if (const char *ev = std::getenv("ATMO_HEAVY_SPLIT")) ctx->heavy_split = ev[0] == '0' ? 0 : (ev[0] == '2' ? 2 : 1);
     if (const char *ev = std::getenv("ATMO_HEAVY_SPLIT_RATIO")) ctx->heavy_split_ratio = (float)std::atof(ev);
     if (const char *ev = std::getenv("ATMO_HEAVY_SPLIT_TRIGGER")) ctx->heavy_split_trigger = (float)std::atof(ev);
+    if (const char *ev = std::getenv("ATMO_HEAVY_SPLIT_TRIGGER_MOVING")) ctx->heavy_split_trigger_moving = (float)std::atof(ev);
     if (const char *ev = std::getenv("ATMO_DRAW_EVENTS")) ctx->draw_events = ev[0] == '0' ? 0 : (ev[0] == '2' ? 2 : 1);
     if (const char *ev = std::getenv("ATMO_TARGET_CLEARED")) ctx->target_cleared = ev[0] == '1' ? 1 : 0;  // tools/ab_env.sh: atmo_set_target_cleared
     if (const char *ev = std::getenv("ATMO_FB_INSTREAM")) ctx->instream = ev[0] >= '1' && ev[0] <= '2' ? ev[0] - '0' : 0;  // 2 (A/B): every cloud and direct-light kernel
@@ -1266,7 +1268,7 @@ int atmo_read_optical_depth(AtmoContext *ctx, float *lut_host, uint8_t *rgba8_ho
 }
 
 static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, void *stream, bool composite,
-                       const uint32_t *tiles_dev = nullptr, int n_tiles = 0);
+                       const uint32_t *tiles_dev = nullptr, int n_tiles = 0, int n_heavy = 0);
 
 int atmo_render(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, void *stream) {
     return render_impl(ctx, frame, depth_dev, rgba_dev, stream, false);
@@ -1282,6 +1284,14 @@ int atmo_render_tiles(AtmoContext *ctx, const AtmoFrame *frame, const float *dep
     if (n_tiles < 0 || (n_tiles > 0 && !tiles_dev)) return fail(ctx, ATMO_E_ARG, "atmo_render_tiles: bad tile list");
     if (n_tiles == 0) return ATMO_OK;  // an empty share of the frame: nothing to shade
     return render_impl(ctx, frame, depth_dev, rgba_dev, stream, false, tiles_dev, n_tiles);
+}
+
+int atmo_render_tiles_split(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, const uint32_t *tiles_dev, int n_tiles,
+                            int n_heavy, void *stream) {
+    if (!ctx) return ATMO_E_ARG;
+    if (n_tiles < 0 || (n_tiles > 0 && !tiles_dev) || n_heavy < 0 || n_heavy > n_tiles) return fail(ctx, ATMO_E_ARG, "atmo_render_tiles_split: bad tile list");
+    if (n_tiles == 0) return ATMO_OK;
+    return render_impl(ctx, frame, depth_dev, rgba_dev, stream, false, tiles_dev, n_tiles, n_heavy);
 }
 
 int atmo_measure_tile_costs(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, void *stream,
@@ -1337,7 +1347,7 @@ int atmo_measure_tile_costs(AtmoContext *ctx, const AtmoFrame *frame, const floa
 }
 
 static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, void *stream, bool composite,
-                       const uint32_t *tiles_dev, int n_tiles) {
+                       const uint32_t *tiles_dev, int n_tiles, int n_heavy) {
     if (!ctx) return ATMO_E_ARG;
     if (!frame) return fail(ctx, ATMO_E_ARG, "atmo_render: null frame");
     if (frame->viewport_w < 1 || frame->viewport_h < 1 || frame->viewport_w > 65536 || frame->viewport_h > 65536)
@@ -1557,12 +1567,23 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         tl->used = true;
         tl->stream = s;
         tl->last_use = ctx->tile_list_clock;
-        { const int rc0 = dev_reserve(ctx, tl->buf, (size_t)n_tiles * sizeof(uint32_t)); if (rc0 != ATMO_OK) return rc0; }
+        // the leading n_heavy tiles on two lanes per ray (atmo_render_tiles_split): only where that form exists and is the same bits
+        // (as for whole frames: the raymarched-light kernel; the kernel without it gains only from eight GPUs on and loses 21 % at two --
+        //  profiles/round5/band_balance.txt -- so it takes part only when forced, ATMO_HEAVY_SPLIT=2)
+        const int lod_cloud0 = atmo::KF_CUBE_LOD | atmo::KF_PRECISE | atmo::KF_CLOUDS;
+        const bool form = ctx->heavy_split == 2 ? (flags & ~atmo::KF_CLOUD_LIGHT_RM) == lod_cloud0 : flags == (lod_cloud0 | atmo::KF_CLOUD_LIGHT_RM);
+        if (split != 1 || !form || !ctx->heavy_split) n_heavy = 0;
+        { const int rc0 = dev_reserve(ctx, tl->buf, ((size_t)n_tiles + 2 * (size_t)n_heavy) * sizeof(uint32_t)); if (rc0 != ATMO_OK) return rc0; }
         int tw = 0, th = 0;
         atmo::render_tile_size(split, &tw, &th);                                         // pixels per tile of this launch
         const uint32_t below = (uint32_t)((frame->viewport_h - rc.gy0 + th - 1) / th);   // the first tile row that starts below the viewport's last row
-        HIP_TRY(ctx, atmo::launch_tile_list_bound(tiles_dev, (uint32_t *)tl->buf.ptr, n_tiles, (uint32_t)gx * (uint32_t)gy, below * (uint32_t)gx, s));
+        const int th2 = th / 2 > 0 ? th / 2 : 1;
+        const uint32_t below2 = (uint32_t)((frame->viewport_h - rc.gy0 + th2 - 1) / th2);
+        uint32_t *list2 = (uint32_t *)tl->buf.ptr + n_tiles;
+        HIP_TRY(ctx, atmo::launch_tile_list_bound(tiles_dev, (uint32_t *)tl->buf.ptr, n_tiles, (uint32_t)gx * (uint32_t)gy, below * (uint32_t)gx, s,
+                                                  list2, n_heavy, gx, below2 * (uint32_t)gx));
         rc.tile_order = (const uint32_t *)tl->buf.ptr;
+        if (n_heavy > 0) order2 = list2;
     }
     // Heavy tiles on two lanes per ray, beside the rest of the draw (round 5).  Only the two BASELINE cloud kernels under the declared sampler have
     // the lane-split form whose frames are bit-identical to the one-lane kernel's (atmo_kernels.hip: march_clouds<.., SPLIT = 2, LOD>).
@@ -1574,17 +1595,20 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     const int lod_cloud = atmo::KF_CUBE_LOD | atmo::KF_PRECISE | atmo::KF_CLOUDS;
     const bool split_form = ctx->heavy_split == 2 ? (flags & ~atmo::KF_CLOUD_LIGHT_RM) == lod_cloud : flags == (lod_cloud | atmo::KF_CLOUD_LIGHT_RM);
     if (ctx->heavy_split && order2 && class_totals && rc.tile_order && !tiles_dev && split == 1 && split_form)
-        heavy = heavy_tile_count(class_totals, gx * gy, ctx->heavy_split_ratio, ctx->heavy_split == 2 ? 0.0f : ctx->heavy_split_trigger,
+        heavy = heavy_tile_count(class_totals, gx * gy, ctx->heavy_split_ratio,
+                                 ctx->heavy_split == 2 ? 0.0f : (fb_instream ? ctx->heavy_split_trigger_moving : ctx->heavy_split_trigger),
                                  1024 * ((flags & atmo::KF_CLOUD_LIGHT_RM) ? 5 : 6));
+    if (tiles_dev) heavy = n_heavy;   // a tile-list draw: the caller says how many of its leading tiles are heavy (atmo_render_tiles_split)
+    const int total_tiles = tiles_dev ? n_tiles : gx * gy;
     if (heavy > 0) {
         if (!ctx->split_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->split_stream, hipStreamNonBlocking));
         { const int rc0 = order_after_stream(ctx, ctx->split_stream, s); if (rc0 != ATMO_OK) return rc0; }   // fork: behind everything the draw is behind
         atmo::RenderConsts rc2 = rc;
         rc2.tile_order = order2;                       // two half-height tiles per heavy tile, heaviest first
         HIP_TRY(ctx, atmo::launch_render(flags, 2, rc2, ctx->split_stream, 2 * heavy));
-        if (gx * gy - heavy > 0) {
+        if (total_tiles - heavy > 0) {
             rc.tile_order += heavy;                    // the rest of the order, one lane per ray
-            HIP_TRY(ctx, atmo::launch_render(flags, split, rc, s, gx * gy - heavy));
+            HIP_TRY(ctx, atmo::launch_render(flags, split, rc, s, total_tiles - heavy));
         }
         { const int rc0 = order_after_stream(ctx, s, ctx->split_stream); if (rc0 != ATMO_OK) return rc0; }   // join
         ctx->split_draws += 1;

@@ -116,7 +116,8 @@ hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int tiles_x, int t
                              uint32_t *scratch, hipStream_t stream, uint32_t *order2 = nullptr, uint32_t *class_totals = nullptr);
 constexpr int TILE_ORDER_CLASSES = 32;   // cost classes of the sort: half octaves of the wave duration, class 0 the heaviest (tile_cost_class)
 size_t tile_order_scratch_bytes();
-hipError_t launch_tile_list_bound(const uint32_t *in, uint32_t *out, int n, uint32_t tiles_n, uint32_t sentinel, hipStream_t stream);  // atmo_render_tiles
+hipError_t launch_tile_list_bound(const uint32_t *in, uint32_t *out, int n, uint32_t tiles_n, uint32_t sentinel, hipStream_t stream,
+                                  uint32_t *out2 = nullptr, int n_heavy = 0, int tiles_x = 1, uint32_t sentinel2 = 0);  // atmo_render_tiles[_split]
 hipError_t launch_layout_lut(const float *lut, int w, int h, float *out, hipStream_t stream);
 hipError_t launch_lut_footprints(const float *apron, int w, int h, float *out4, hipStream_t stream);
 hipError_t launch_layout_shape(const uint8_t *t, int n, uint32_t *out, hipStream_t stream);

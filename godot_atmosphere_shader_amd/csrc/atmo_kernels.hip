@@ -2192,12 +2192,33 @@ __global__ __launch_bounds__(256) void atmo_tile_dilate_kernel(const uint32_t *_
     out[i] = m;
 }
 
+// The class totals of the UNDILATED costs (one workgroup; a moving camera's sort): the host's estimate of the draw's duration and of its heaviest
+// wavefront (heavy_tile_count) must not see the max-filtered map the order is sorted from -- every tile within reach of a heavy one counts as heavy
+// there, the sum of lifetimes is inflated severalfold and no draw ever looks bound by its tail.
+__global__ __launch_bounds__(1024) void atmo_tile_class_totals_kernel(const uint32_t *__restrict__ cost, int n, uint32_t *__restrict__ class_totals) {
+    __shared__ uint32_t cnt[ORDER_CLASSES];
+    if (threadIdx.x < ORDER_CLASSES) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = 0; i < n; i += 1024) {
+        const bool valid = i + (int)threadIdx.x < n;
+        const uint32_t c = valid ? tile_cost_class(cost[i + threadIdx.x]) : 0u;
+        const unsigned long long m = match_class(c, valid);
+        if (valid && lanes_below(m) == 0) atomicAdd(&cnt[c], (uint32_t)__builtin_popcountll(m));   // one lane per class and wave
+    }
+    __syncthreads();
+    if (threadIdx.x < ORDER_CLASSES) class_totals[threadIdx.x] = cnt[threadIdx.x];
+}
+
 // scratch: ORDER_BLOCKS * ORDER_CLASSES uint32 (tile_order_scratch_bytes); tmp1 / tmp2: n uint32 each, used when rx | ry > 0
 size_t tile_order_scratch_bytes() { return (size_t)ORDER_BLOCKS * ORDER_CLASSES * sizeof(uint32_t); }
 hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int tiles_x, int tiles_y, int rx, int ry, uint32_t *tmp1, uint32_t *tmp2,
                              uint32_t *scratch, hipStream_t stream, uint32_t *order2, uint32_t *class_totals) {
     const int n = tiles_x * tiles_y;
     const uint32_t *key = cost;
+    if ((rx > 0 || ry > 0) && class_totals != nullptr) {   // the histogram the host reads: of the measured costs, not of the dilated key
+        hipLaunchKernelGGL(atmo_tile_class_totals_kernel, dim3(1), dim3(1024), 0, stream, cost, n, class_totals);
+        class_totals = nullptr;
+    }
     if ((rx > 0 || ry > 0) && (2 * rx + 1) * (2 * ry + 1) <= 81) {  // a small window (the in-stream sort's: a tile or two): one pass
         hipLaunchKernelGGL(atmo_tile_dilate_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cost, tmp2, tiles_x, tiles_y, rx, ry);
         key = tmp2;
@@ -2214,16 +2235,27 @@ hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int tiles_x, int t
 
 // atmo_render_tiles: the caller's tile list with every index beyond the launch grid replaced by `sentinel`, a tile that lies wholly below the
 // viewport (its lanes leave at shade_pixel's bounds test).  In front of the draw, on its stream; the render kernels stay untouched.
+// n_heavy > 0 (atmo_render_tiles_split): the first n_heavy tiles of the list are drawn with two lanes per ray -- their two half-height tiles in the
+// lane-split kernels' launch grid go to out2[2 i], out2[2 i + 1] (sentinel2: a tile of THAT grid below the viewport).
 __global__ __launch_bounds__(256) void atmo_tile_list_bound_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int n, uint32_t tiles_n,
-                                                                   uint32_t sentinel) {
+                                                                   uint32_t sentinel, uint32_t *__restrict__ out2, int n_heavy, int tiles_x,
+                                                                   uint32_t sentinel2) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const uint32_t t = in[i];
-        out[i] = t < tiles_n ? t : sentinel;
+        const bool ok = t < tiles_n;
+        out[i] = ok ? t : sentinel;
+        if (i < n_heavy) {
+            const uint32_t ty = t / (uint32_t)tiles_x, tx = t - ty * (uint32_t)tiles_x;
+            out2[2 * i] = ok ? (2u * ty) * (uint32_t)tiles_x + tx : sentinel2;
+            out2[2 * i + 1] = ok ? (2u * ty + 1u) * (uint32_t)tiles_x + tx : sentinel2;
+        }
     }
 }
-hipError_t launch_tile_list_bound(const uint32_t *in, uint32_t *out, int n, uint32_t tiles_n, uint32_t sentinel, hipStream_t stream) {
-    hipLaunchKernelGGL(atmo_tile_list_bound_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, in, out, n, tiles_n, sentinel);
+hipError_t launch_tile_list_bound(const uint32_t *in, uint32_t *out, int n, uint32_t tiles_n, uint32_t sentinel, hipStream_t stream, uint32_t *out2,
+                                  int n_heavy, int tiles_x, uint32_t sentinel2) {
+    hipLaunchKernelGGL(atmo_tile_list_bound_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, in, out, n, tiles_n, sentinel, out2, n_heavy, tiles_x,
+                       sentinel2);
     return hipGetLastError();
 }
 

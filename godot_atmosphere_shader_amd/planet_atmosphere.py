@@ -609,12 +609,18 @@ class PlanetAtmosphere:
         rc = self._lib.atmo_render(self._ctx, C.byref(nf), C.c_void_p(depth_ptr), C.c_void_p(out_ptr), C.c_void_p(stream or 0))
         N.check(self._ctx, rc)
 
-    def render_tiles_prepared(self, native_frame: N.AtmoFrame, depth_ptr: int, out_ptr: int, tiles_ptr: int, n_tiles: int, stream: int = 0):
+    def render_tiles_prepared(self, native_frame: N.AtmoFrame, depth_ptr: int, out_ptr: int, tiles_ptr: int, n_tiles: int, stream: int = 0,
+                              n_heavy: int = 0):
         """atmo_render_tiles: draw only the listed tiles (uint32 indices in device memory, row-major in the grid of
-        measure_tile_costs) of the frame's rect, in list order; `out_ptr` is addressed like render_prepared's."""
+        measure_tile_costs) of the frame's rect, in list order; `out_ptr` is addressed like render_prepared's.
+        n_heavy > 0 (atmo_render_tiles_split): the list's first n_heavy tiles on two lanes per ray beside the rest (sharding.heavy_tiles)."""
         self._bake_if_needed(stream)
-        rc = self._lib.atmo_render_tiles(self._ctx, C.byref(native_frame), C.c_void_p(depth_ptr), C.c_void_p(out_ptr), C.c_void_p(tiles_ptr),
-                                         int(n_tiles), C.c_void_p(stream or 0))
+        if n_heavy:
+            rc = self._lib.atmo_render_tiles_split(self._ctx, C.byref(native_frame), C.c_void_p(depth_ptr), C.c_void_p(out_ptr), C.c_void_p(tiles_ptr),
+                                                   int(n_tiles), int(n_heavy), C.c_void_p(stream or 0))
+        else:
+            rc = self._lib.atmo_render_tiles(self._ctx, C.byref(native_frame), C.c_void_p(depth_ptr), C.c_void_p(out_ptr), C.c_void_p(tiles_ptr),
+                                             int(n_tiles), C.c_void_p(stream or 0))
         N.check(self._ctx, rc)
 
     def measure_tile_costs(self, camera, depth, rect=None, stream=None, time: float = 0.0):

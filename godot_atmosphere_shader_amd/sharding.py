@@ -201,6 +201,21 @@ def lpt_strips(tile_cost, world_size: int, strip_tile_rows: int = STRIP_TILE_ROW
     return strips, tiles
 
 
+def heavy_tiles(costs_desc, resident_waves: int = 5120, trigger: float = 1.5, ratio: float = 0.3) -> int:
+    """How many of a share's tiles (measured costs = longest wavefront per tile in shader cycles, sorted heaviest first) are worth two lanes per ray
+    (PlanetAtmosphere.render_tiles_prepared(n_heavy=...), atmo_render_tiles_split): the library's own rule for whole frames (csrc/atmo_api.hip,
+    heavy_tile_count) on exact costs.  The share's duration is estimated as the sum of its wave lifetimes (two waves per tile) over the waves the GPU
+    holds (1024 SIMDs x 5); if the heaviest tile does not outlive `trigger` x that, the share is bound by throughput and nothing is split; otherwise the
+    tiles outliving `ratio` x it are, at most a third of the share."""
+    c = np.asarray(costs_desc, dtype=np.float64)
+    if c.size == 0 or c.sum() <= 0.0:
+        return 0
+    draw = c.sum() * 2.0 / float(resident_waves)
+    if not c[0] > trigger * draw:
+        return 0
+    return int(min(np.count_nonzero(c > ratio * draw), c.size // 3))
+
+
 class StripGather:
     """Gathers the strips each rank drew into the frame on rank `dst`.
 

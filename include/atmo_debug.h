@@ -77,6 +77,13 @@ const char *atmo_kernel_name(AtmoContext *ctx);
  * (read in atmo_create) turns it off; the picture does not depend on it, bit for bit. */
 int atmo_get_split_stats(AtmoContext *ctx, unsigned *split_draws, unsigned *heavy_tiles_last);
 
+/* atmo_render_tiles with the list's first n_heavy tiles drawn on two lanes per ray beside the rest (round 5; a sharding experiment, not bound by a Godot
+ * host): a GPU's share of ONE frame is as long as its heaviest wavefront from two GPUs on (profiles/round4/band_balance.txt), which is the regime where the
+ * lane-split kernel pays.  The caller orders its list heaviest first and picks n_heavy from the measured costs (sharding.heavy_tiles).  Ignored (n_heavy = 0)
+ * where the kernel family has no bit-identical lane-split form: the frame is the same bits either way. */
+int atmo_render_tiles_split(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, const uint32_t *tiles_dev, int n_tiles,
+                            int n_heavy, void *stream);
+
 /* How often calls of this context fell back to a device-wide host wait (hipDeviceSynchronize) where a stream-side wait on the device was
  * not possible: a remembered stream that the caller has destroyed since, or more draw streams than the context tracks (8).  0 in a host
  * that keeps its streams alive (tests/test_gpu_parity.py::test_texture_update_does_not_wait_for_unrelated_streams). */

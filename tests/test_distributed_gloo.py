@@ -403,3 +403,19 @@ def test_strip_gather_assembles_the_frame(tmp_path, world):
     mp.spawn(_strips_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert (tmp_path / f"ok_strips_{r}").exists()
+
+
+def test_heavy_tiles_rule_on_exact_costs():
+    """sharding.heavy_tiles (round 5): a share whose heaviest wavefront outlives 1.5 x the share's estimated duration gets the tiles that outlive
+    0.3 x it split (at most a third); a share bound by throughput gets none."""
+    from godot_atmosphere_shader_amd.sharding import heavy_tiles
+
+    uniform = np.full(4000, 1000.0)                       # 4000 equal tiles: duration 4000 * 1000 * 2 / 5120 = 1562 > any tile
+    assert heavy_tiles(uniform) == 0
+    few = np.sort(np.concatenate([np.full(60, 400000.0), np.full(2000, 500.0)]))[::-1]   # 60 long tiles among cheap ones: duration ~ 9766
+    n = heavy_tiles(few)
+    assert n == 60
+    assert heavy_tiles(few, trigger=100.0) == 0            # a trigger nothing reaches
+    assert heavy_tiles(np.zeros(10)) == 0 and heavy_tiles(np.zeros(0)) == 0
+    tail = np.sort(np.concatenate([np.full(900, 300000.0), np.full(100, 10.0)]))[::-1]   # nearly everything heavy: capped at a third
+    assert heavy_tiles(tail, trigger=0.0) == 1000 // 3

@@ -651,6 +651,22 @@ def test_tile_list_draws_partition_the_frame():
                 assert np.all(o[~mine] == 77.5), (config_name, world, r)          # nothing outside its strips is touched
                 got[mine] = o[mine]
             assert np.array_equal(got, want), (config_name, world)
+        # round 5: the same deal with every share's leading tiles on two lanes per ray (atmo_render_tiles_split): still the frame, bit for bit
+        # (where the kernel family has no lane-split form the count is ignored)
+        strips, tiles = lpt_strips(cost, 3)
+        got = np.full_like(want, np.nan)
+        for r in range(3):
+            out = torch.full(want.shape, 77.5, dtype=torch.float32, device="cuda")
+            t = torch.from_numpy(tiles[r].astype(np.int32)).cuda()
+            node.render_tiles_prepared(frame, depth.data_ptr(), out.data_ptr(), t.data_ptr(), t.numel(), stream, n_heavy=max(1, t.numel() // 3))
+            torch.cuda.synchronize()
+            o = out.cpu().numpy()
+            mine = np.zeros(want.shape[0], dtype=bool)
+            for k in strips[r]:
+                mine[max(0, gy0 - y0 + k * STRIP_TILE_ROWS * th):max(0, gy0 - y0 + (k + 1) * STRIP_TILE_ROWS * th)] = True
+            assert np.all(o[~mine] == 77.5), (config_name, r)
+            got[mine] = o[mine]
+        assert np.array_equal(got, want), (config_name, "split")
         # indices beyond the grid shade nothing and touch nothing (include/atmo.h; ADVICE r4: 0xFFFFFFFF on a one-tile-wide rect used to become
         # tile row -1): a list of nothing but such indices leaves a poisoned target as it was, and mixed into a real list they change nothing
         n_grid = cost.size

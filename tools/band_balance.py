@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from godot_atmosphere_shader_amd import scene as S  # noqa: E402
 from godot_atmosphere_shader_amd.demo import demo_params, demo_textures, make_node  # noqa: E402
-from godot_atmosphere_shader_amd.sharding import balanced_row_bands, band_rect, lpt_strips, row_bands  # noqa: E402
+from godot_atmosphere_shader_amd.sharding import balanced_row_bands, band_rect, heavy_tiles, lpt_strips, row_bands  # noqa: E402
 
 
 def band_ms(node, cam, depth, band, reps=30):
@@ -37,7 +37,7 @@ def band_ms(node, cam, depth, band, reps=30):
     return e0.elapsed_time(e1) / reps
 
 
-def tiles_ms(node, cam, depth, tiles, reps=30):
+def tiles_ms(node, cam, depth, tiles, reps=30, n_heavy=0):
     if tiles.size == 0:
         return 0.0
     out = torch.empty((cam.height, cam.width, 4), dtype=torch.float32, device="cuda")
@@ -45,12 +45,12 @@ def tiles_ms(node, cam, depth, tiles, reps=30):
     frame = node.prepare_frame(cam)
     stream = torch.cuda.current_stream().cuda_stream
     for _ in range(8):
-        node.render_tiles_prepared(frame, depth.data_ptr(), out.data_ptr(), t.data_ptr(), t.numel(), stream)
+        node.render_tiles_prepared(frame, depth.data_ptr(), out.data_ptr(), t.data_ptr(), t.numel(), stream, n_heavy=n_heavy)
         torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        node.render_tiles_prepared(frame, depth.data_ptr(), out.data_ptr(), t.data_ptr(), t.numel(), stream)
+        node.render_tiles_prepared(frame, depth.data_ptr(), out.data_ptr(), t.data_ptr(), t.numel(), stream, n_heavy=n_heavy)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
@@ -65,7 +65,7 @@ def main():
     if split2:
         print("# two lanes per ray (atmo_set_lane_split 2) in every draw of this table")
     print(f"# cubemap sampler of the cloud workloads: {'level 0 (atmo_set_sampler_lod 0)' if lod0 else 'as declared (linear-mipmap, implicit LOD: the default)'}")
-    print(f"# {'workload':16s} {'pose':9s} {'N':>2s} {'measured':>18s} {'analytic':>18s} {'equal rows':>18s} {'LPT tile strips':>18s}   whole frame")
+    print(f"# {'workload':16s} {'pose':9s} {'N':>2s} {'measured':>18s} {'analytic':>18s} {'equal rows':>18s} {'LPT tile strips':>18s} {'+ heavy tiles split':>22s}   whole frame")
     for wl in (("clouds_high_rm",) if split2 else ("clouds_high_rm", "clouds_high", "direct32x8")):
         for pose in ("P_space", "P_limb"):
             config_name = bench.WORKLOADS[wl][0]
@@ -85,7 +85,11 @@ def main():
                 _, tiles = lpt_strips(cost, world)
                 t = np.array([tiles_ms(node, cam, depth, tl) for tl in tiles])
                 cells.append(f"{t.max() / t.mean():5.2f} ({t.max():.4f})")
-                print(f"  {wl:16s} {pose:9s} {world:2d} " + " ".join(f"{c:>18s}" for c in cells) + f"   {whole:.4f}", flush=True)
+                # round 5: the same shares with their heavy tiles on two lanes per ray (atmo_render_tiles_split; declared-sampler cloud kernels)
+                nh = [heavy_tiles(cost.reshape(-1)[tl]) for tl in tiles]
+                t = np.array([tiles_ms(node, cam, depth, tl, n_heavy=k) for tl, k in zip(tiles, nh)])
+                cells.append(f"{t.max() / t.mean():5.2f} ({t.max():.4f}) h{max(nh)}")
+                print(f"  {wl:16s} {pose:9s} {world:2d} " + " ".join(f"{c:>18s}" for c in cells[:4]) + f" {cells[4]:>22s}" + f"   {whole:.4f}", flush=True)
             node.close()
 
 
