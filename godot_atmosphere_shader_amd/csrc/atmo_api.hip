@@ -165,7 +165,7 @@ struct AtmoContext {
     hipStream_t fb_stream = nullptr;                   // the sort kernels run here, beside the draws (high priority)
     hipStream_t split_stream = nullptr;                // the heavy tiles of a frame, on two lanes per ray, run here beside the rest of the draw
     int heavy_split = 1;                               // ATMO_HEAVY_SPLIT=0 (A/B): every tile with one lane per ray; 2 (tests): also the kernel without raymarched light, no trigger
-    float heavy_split_trigger = 1.5f;                  // ATMO_HEAVY_SPLIT_TRIGGER: only when the heaviest class lives longer than this x the draw's estimated duration ...
+    float heavy_split_trigger = 2.0f;                  // ATMO_HEAVY_SPLIT_TRIGGER: only when the heaviest class lives longer than this x the draw's estimated duration ...
     float heavy_split_trigger_moving = 2.0f;           // ATMO_HEAVY_SPLIT_TRIGGER_MOVING: the trigger while the order comes from the in-stream sort (a moving camera)
     float heavy_split_ratio = 0.3f;                    // ATMO_HEAVY_SPLIT_RATIO: ... the tiles whose longest wave lives longer than this x that estimate are heavy
     unsigned split_draws = 0, split_tiles_last = 0;    // atmo_get_split_stats
@@ -1597,7 +1597,7 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     if (ctx->heavy_split && order2 && class_totals && rc.tile_order && !tiles_dev && split == 1 && split_form)
         heavy = heavy_tile_count(class_totals, gx * gy, ctx->heavy_split_ratio,
                                  ctx->heavy_split == 2 ? 0.0f : (fb_instream ? ctx->heavy_split_trigger_moving : ctx->heavy_split_trigger),
-                                 1024 * ((flags & atmo::KF_CLOUD_LIGHT_RM) ? 5 : 6));
+                                 1024 * 6);   // both declared-sampler cloud kernels hold six waves per SIMD
     if (tiles_dev) heavy = n_heavy;   // a tile-list draw: the caller says how many of its leading tiles are heavy (atmo_render_tiles_split)
     const int total_tiles = tiles_dev ? n_tiles : gx * gy;
     if (heavy > 0) {

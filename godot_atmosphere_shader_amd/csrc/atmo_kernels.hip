@@ -1452,7 +1452,17 @@ __device__ __forceinline__ float rm_sample_weight(RmRecurrence &s, float density
 template <bool RM, bool PRECISE, int SPLIT, bool LOD = false>
 __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc_in, V3 dir_m, float t_begin, float t_end, float jitter, int half,
                                                QuadRegs *qregs = nullptr, const f32x4 *lvl = nullptr) {
-    static_assert(!(LOD && RM) || SPLIT == 2, "raymarched light under the declared sampler, one lane per ray: the lit-sample queue");
+    // ATMO_RM_INPLACE (1 since round 5): under the declared sampler the raymarched light is evaluated IN PLACE with one lane per ray as well -- this
+    // function instead of the lit-sample queue (march_clouds_rm_queue<.., LOD>, which 0 selects: round 4's kernel, the A/B arm).  Same bits (the
+    // queue's arithmetic, above); 73 VGPRs and no queue in LDS instead of 86 / 15 KB: six waves per SIMD instead of five, no twelve-word entries through
+    // LDS, no second whole-quad block per lit sample.  Measured (profiles/round5/ab_rm_inplace.txt): 3840x2160 -11.4 % (1.355 -> 1.201 ms, BASELINE
+    // configs[3]), 2560x1440 -9.4 %, from the ground -10.4 %, inside the layer -11..-12.5 %, from the limb -4.7 %, 1920x1080 pose P_space +1.6 %
+    // (bound by its tail there).  NOT for the level-0 sampler: its queue kernel (six-word entries, 10 KB, taps unrolled) is 11-30 % faster than its
+    // in-place form.
+#ifndef ATMO_RM_INPLACE
+#define ATMO_RM_INPLACE 1
+#endif
+    static_assert(!(LOD && RM) || SPLIT == 2 || ATMO_RM_INPLACE, "raymarched light under the declared sampler, one lane per ray: the lit-sample queue");
     // LOD && SPLIT == 2 (round 5, the heavy tiles of a frame): the two lanes of a ray are lane and lane ^ 4, a pixel quad keeps four consecutive
     // lanes (all at the same step); with RM the light taps are evaluated in place -- the partners' sample positions come from the quad
     // mates by the same whole-quad block the queue uses at enqueue -- and the recurrence runs in the lit-sample queue's arithmetic
@@ -1574,8 +1584,9 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc_in, V3 dir
     return make_float2(total_light, 1.0f - one_minus_alpha);
 }
 
-// ---- atmosphere_fragment ---------------------------------------------------------------------------
 // ---- raymarch_cloud with raymarched light, lit samples regrouped through LDS -------------------------------
+// (Since round 5 the kernels of the LEVEL-0 sampler and of the fast cloud mode: under the declared sampler the raymarched light is evaluated in place,
+//  march_clouds<RM, .., LOD> / ATMO_RM_INPLACE -- the same bits, 11 % faster at 3840x2160.  The LOD branches below are round 4's kernel, the A/B arm.)
 // In clouds_high_rm only the samples with density > 0 need get_light_raymarched (6 more density evaluations each), and in a
 // lock-step march they are a changing subset of the wave: 21 % of the issued lanes idle (VALUUtilization 78.7 %,
 // profiles/round2/pmc_clouds_high_rm_1920x1080.json).  The light value does not feed back into the march -- it only scales
@@ -1895,7 +1906,7 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
                 dir_m.y = M[1] * dir.x + M[5] * dir.y + M[9] * dir.z;
                 dir_m.z = M[2] * dir.x + M[6] * dir.y + M[10] * dir.z;
                 float2 rr;
-                if constexpr (RM && SPLIT == 1) {
+                if constexpr (RM && SPLIT == 1 && !(LOD && ATMO_RM_INPLACE)) {
                     __shared__ float rmq[(TILE_W * TILE_H / 64) * rmq_words_per_wave(LOD)];
                     rr = march_clouds_rm_queue<PRECISE, LOD>(rc, dir_m, c0, c1, jitter, rmq + wave * rmq_words_per_wave(LOD), &qregs, lvl_table);
                 } else {

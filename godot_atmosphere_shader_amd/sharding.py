@@ -201,11 +201,11 @@ def lpt_strips(tile_cost, world_size: int, strip_tile_rows: int = STRIP_TILE_ROW
     return strips, tiles
 
 
-def heavy_tiles(costs_desc, resident_waves: int = 5120, trigger: float = 1.5, ratio: float = 0.3) -> int:
+def heavy_tiles(costs_desc, resident_waves: int = 6144, trigger: float = 2.0, ratio: float = 0.3) -> int:
     """How many of a share's tiles (measured costs = longest wavefront per tile in shader cycles, sorted heaviest first) are worth two lanes per ray
     (PlanetAtmosphere.render_tiles_prepared(n_heavy=...), atmo_render_tiles_split): the library's own rule for whole frames (csrc/atmo_api.hip,
     heavy_tile_count) on exact costs.  The share's duration is estimated as the sum of its wave lifetimes (two waves per tile) over the waves the GPU
-    holds (1024 SIMDs x 5); if the heaviest tile does not outlive `trigger` x that, the share is bound by throughput and nothing is split; otherwise the
+    holds (1024 SIMDs x 6); if the heaviest tile does not outlive `trigger` x that, the share is bound by throughput and nothing is split; otherwise the
     tiles outliving `ratio` x it are, at most a third of the share."""
     c = np.asarray(costs_desc, dtype=np.float64)
     if c.size == 0 or c.sum() <= 0.0:

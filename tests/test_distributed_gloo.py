@@ -406,13 +406,13 @@ def test_strip_gather_assembles_the_frame(tmp_path, world):
 
 
 def test_heavy_tiles_rule_on_exact_costs():
-    """sharding.heavy_tiles (round 5): a share whose heaviest wavefront outlives 1.5 x the share's estimated duration gets the tiles that outlive
+    """sharding.heavy_tiles (round 5): a share whose heaviest wavefront outlives 2 x the share's estimated duration gets the tiles that outlive
     0.3 x it split (at most a third); a share bound by throughput gets none."""
     from godot_atmosphere_shader_amd.sharding import heavy_tiles
 
-    uniform = np.full(4000, 1000.0)                       # 4000 equal tiles: duration 4000 * 1000 * 2 / 5120 = 1562 > any tile
+    uniform = np.full(4000, 1000.0)                       # 4000 equal tiles: duration 4000 * 1000 * 2 / 6144 = 1302 > any tile
     assert heavy_tiles(uniform) == 0
-    few = np.sort(np.concatenate([np.full(60, 400000.0), np.full(2000, 500.0)]))[::-1]   # 60 long tiles among cheap ones: duration ~ 9766
+    few = np.sort(np.concatenate([np.full(60, 400000.0), np.full(2000, 500.0)]))[::-1]   # 60 long tiles among cheap ones: duration ~ 8138
     n = heavy_tiles(few)
     assert n == 60
     assert heavy_tiles(few, trigger=100.0) == 0            # a trigger nothing reaches
