@@ -33,7 +33,7 @@ def main():
     cam = S.Camera.from_pose(w, h, pose)
     depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
     out = None
-    for _ in range(12):  # paced like a frame loop: the tile-order feedback swaps a new order in when the HOST sees its sort done
+    for _ in range(int(os.environ.get("TIMELINE_FRAMES", "12"))):  # paced like a frame loop: the tile-order feedback swaps a new order in when the HOST sees its sort done
         out = node.render(cam, depth, out=out)
         torch.cuda.synchronize()
     fn = node._lib.atmo_debug_wave_trace
@@ -121,6 +121,21 @@ def main():
             if m.any():
                 print(f"  waves entering in {lo_ * 100:3.0f}-{hi_ * 100:3.0f} % of the span: {m.sum():6d}, duration us p50 {np.percentile(dur[m], 50):6.1f} "
                       f"p95 {np.percentile(dur[m], 95):6.1f} max {dur[m].max():6.1f}")
+    # is the launch order sorted by what the waves turn out to cost?  (slot = launch rank: 2 waves per workgroup, blockIdx order)
+    if os.environ.get("TIMELINE_RANKS"):
+        slot = np.nonzero(buf[:n, 1] > 0)[0]
+        nb = 24
+        edges_r = np.linspace(0, slot.max() + 1, nb + 1).astype(int)
+        print("launch rank (wave slots) -> entry us p50 | duration us p5 p50 p95 max | end us max")
+        for b in range(nb):
+            m = (slot >= edges_r[b]) & (slot < edges_r[b + 1])
+            if m.any():
+                print(f"  {edges_r[b]:6d}-{edges_r[b + 1]:6d}: entry {np.percentile(entry_us[m], 50):7.1f} | "
+                      "%7.1f %7.1f %7.1f %7.1f | %7.1f" % (tuple(np.percentile(dur[m], [5, 50, 95, 100])) + (e_us[m].max(),)))
+        last = np.argsort(-e_us)[:24]
+        print("the 24 waves that end last: slot, entry us, duration us, end us")
+        for i in last:
+            print(f"  {slot[i]:6d}  {entry_us[i]:7.1f}  {dur[i]:7.1f}  {e_us[i]:7.1f}")
     lifetime = e_us - entry_us
     print(f"wave lifetime from entry: mean {lifetime.mean():.1f} us = {lifetime.sum() / span / n_simd:.2f} resident waves per SIMD; "
           f"of which past the preamble {dur.sum() / lifetime.sum() * 100:.0f} %")
