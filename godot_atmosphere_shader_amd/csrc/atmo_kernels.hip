@@ -1993,6 +1993,9 @@ constexpr int render_min_waves(int flags) {
 #define ATMO_MIN_WAVES_ARG
 #endif
 // ATMO_SGPR_CAP_MASK: bit number (direct + 2 clouds + 4 lite) set = that kernel family runs under the cap (tools/ab_build.sh x -DATMO_SGPR_CAP_MASK=0x02)
+#ifndef ATMO_SGPR_CAP_VALUE
+#define ATMO_SGPR_CAP_VALUE 80
+#endif
 #ifndef ATMO_SGPR_CAP_MASK
 #define ATMO_SGPR_CAP_MASK 0x00
 #endif
@@ -2048,7 +2051,7 @@ __global__ __launch_bounds__(TILE_W *TILE_H ATMO_MIN_WAVES_ARG) void atmo_render
 }
 // the same kernel under an 80-SGPR cap (8 waves per SIMD), for the families render_sgpr_cap80 names (none in the shipped build)
 template <int FLAGS, int LSTEPS, int SPLIT = 1>
-__global__ __launch_bounds__(TILE_W *TILE_H ATMO_MIN_WAVES_ARG) __attribute__((amdgpu_num_sgpr(80))) void atmo_render_kernel_s80(const RenderConsts rc) {
+__global__ __launch_bounds__(TILE_W *TILE_H ATMO_MIN_WAVES_ARG) __attribute__((amdgpu_num_sgpr(ATMO_SGPR_CAP_VALUE))) void atmo_render_kernel_s80(const RenderConsts rc) {
     ATMO_RENDER_KERNEL_BODY
 }
 
