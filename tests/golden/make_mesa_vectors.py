@@ -154,6 +154,14 @@ def main():
             out[f"steps{steps}_rgba_{pose}"] = rgba
             worst_s = max(worst_s, float(np.abs(rgba - r3[f"steps{steps}_rgba_{pose}"]).max()))
         print(f"   {steps} view steps: max {worst_s:.2e}")
+    # the DOUBLE_PRECISION compile switch (planet_atmosphere_main.gdshaderinc:25,118-125): the text assigns to a component of its `mat4` PARAMETER
+    cam = RS.camera_from_fixture(z, W, H, "P_limb")
+    neg = RS.camera_from_fixture(z, W, H, "P_limb")
+    neg.inv_view = cam.inv_view.copy()
+    neg.inv_view[:3, 3] *= -1.0  # what a double-precision engine build hands the shader
+    rgba, _, _ = M.run_frame("planet_atmosphere_clouds", {"DOUBLE_PRECISION": ""}, params, np.eye(4), model, neg, z["depth_demo_P_limb"], tex)
+    out["rgba_double_precision_P_limb_planet_atmosphere_clouds"] = rgba
+    print(f"   #define DOUBLE_PRECISION, clouds, P_limb: {stats(rgba, z['rgba_double_precision_P_limb_planet_atmosphere_clouds'])}")
     print("\n## 5. the sampler the reference declares (linear-mipmap, implicit level of detail), 48 x 27 -- frames whose cubemap is MINIFIED 4-8x.  Here the level\n"
           "##    of detail is llvmpipe's own (its rho is taken from the derivatives of the direction vector; the interpreter follows the Vulkan text: the partner\n"
           "##    projected onto the lane's face): where lambda > 0 the two rules blend different mip levels.  Recorded, not a test:")
@@ -193,6 +201,16 @@ def main():
                 if common:
                     line += f" | rows {common} vs interpreter: max {relerr(rgba[common], src[f'rgba_{rk}'][[have.index(r) for r in common]]).max():.2e}"
             print(line + f"   [{time.time() - t0:.0f} s]", flush=True)
+    print("##    the other poses, clouds_high_rm 1920x1080, declared sampler, full frames against the oracle (report only, no vectors):")
+    for pose in ("P_limb", "P_ground", "P_night"):
+        cam = S.Camera.from_pose(1920, 1080, pose)
+        depth = S.depth_ground_sphere(cam)
+        shader = "planet_atmosphere_clouds_high_rm"
+        rgba, disc, _ = M.run_frame(shader, None, params, np.eye(4), model, cam, depth, btex, cube_chain=big_chain)
+        otex = dict(blue_noise=blue, shape=big["shape"], optical_depth=z["lut_demo"], cubemap=oracle.cubemap_mip_chain(big["cubemap"]))
+        orc, hits = oracle.render(oparams, otex, dict(RS.VARIANTS[shader], cube_lod=1), make_frame(cam, model, S.DEMO_SUN_POSITION, 0.0), depth, nthreads=8)
+        assert int((~disc).sum()) == hits, pose
+        print(f"   clouds_high_rm 1920x1080 {pose:8s} declared full frame vs oracle: {stats(rgba, orc)}; {hits} fragments kept by both   [{time.time() - t0:.0f} s]", flush=True)
     path = os.path.join(HERE, "reference_exec_mesa.npz")
     np.savez_compressed(path, **out)
     print(f"\n# wrote {os.path.relpath(path, ROOT)}: {os.path.getsize(path)} bytes, {len(out)} arrays")

@@ -154,6 +154,20 @@ def test_oracle_against_mesa_at_32_and_64_view_steps(oracle32, vm, mesa, texture
         assert e <= 5e-5, f"{steps} view steps {pose}: {e:.3e}"   # measured 3.2e-5 at 64 steps: 64 exponentials of 18 ulp each
 
 
+def test_double_precision_switch_against_mesa(oracle32, vm, mesa, textures):
+    """#define DOUBLE_PRECISION (planet_atmosphere_main.gdshaderinc:25,118-125: the text writes to components of its mat4 parameter) compiled by Mesa."""
+    params, model = _scene("demo")
+    cam = RS.camera_from_fixture(vm, RS.W, RS.H, "P_limb")
+    frame = make_frame(cam, model, S.DEMO_SUN_POSITION, 0.0)
+    inv_view = np.array(frame["inv_view_matrix"], dtype=np.float64).copy()
+    inv_view[12:15] *= -1.0
+    got, _ = oracle32.render(params, dict(textures, optical_depth=vm["lut_demo"]), dict(RS.VARIANTS["planet_atmosphere_clouds"], double_precision=1),
+                             dict(frame, inv_view_matrix=inv_view), vm["depth_demo_P_limb"])
+    want = mesa["rgba_double_precision_P_limb_planet_atmosphere_clouds"]
+    _check(got, want, "planet_atmosphere_clouds", "oracle vs Mesa, DOUBLE_PRECISION")
+    _check(vm["rgba_double_precision_P_limb_planet_atmosphere_clouds"], want, "planet_atmosphere_clouds", "interpreter vs Mesa, DOUBLE_PRECISION")
+
+
 def _rows_case(vm, mesa, shader, w, h, pose, sampler):
     from common import demo_textures
     key = f"rows_{sampler}_{w}x{h}_{pose}_{shader}"
