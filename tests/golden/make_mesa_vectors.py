@@ -163,8 +163,8 @@ def main():
     out["rgba_double_precision_P_limb_planet_atmosphere_clouds"] = rgba
     print(f"   #define DOUBLE_PRECISION, clouds, P_limb: {stats(rgba, z['rgba_double_precision_P_limb_planet_atmosphere_clouds'])}")
     print("\n## 5. the sampler the reference declares (linear-mipmap, implicit level of detail), 48 x 27 -- frames whose cubemap is MINIFIED 4-8x.  Here the level\n"
-          "##    of detail is llvmpipe's own (its rho is taken from the derivatives of the direction vector; the interpreter follows the Vulkan text: the partner\n"
-          "##    projected onto the lane's face): where lambda > 0 the two rules blend different mip levels.  Recorded, not a test:")
+          "##    of detail is llvmpipe's own; where lambda > 0 the two implementations blend different mip levels (why: section 11 -- the fetch sits in non-uniform\n"
+          "##    control flow, where GLSL leaves implicit derivatives undefined, and each implementation resolves that its own way).  Recorded, not a test:")
     chain = T.mip_chain(cube)
     for pose in RS.LOD_POSES:
         cam = RS.camera_from_fixture(z, W, H, pose)

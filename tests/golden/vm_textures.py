@@ -220,7 +220,8 @@ class CubeTextureLod:
         projections, written without cancellation), likewise t;
       * rho^2 = n^2 (ds^2 + dt^2) per axis, lambda = 0.5 log2(max(rho_x^2, rho_y^2)) clamped to [0, levels - 1];
       * result = mix(level floor(lambda), level floor(lambda) + 1, fract(lambda)), each level bilinear + seamless.
-    `alt`: sensitivity runs only -- "f64_plain" evaluates s' - s as the plain difference of the two projections in float64."""
+    `alt`: sensitivity runs only -- "f64_plain" evaluates s' - s as the plain difference of the two projections in float64; "fast_log2" takes
+    lambda from a piecewise-linear log2 as llvmpipe does (profiles/round5/mesa_pin.txt, section 11)."""
 
     needs_quad = True
 
@@ -257,7 +258,11 @@ class CubeTextureLod:
                     dt = ((dtc * ma - tc * dma) * inv).astype(F32)
                     r2 = ((ds * ds + dt * dt) * n2).astype(F32)
                 rho2 = np.where(ok, np.fmax(rho2, r2), rho2)
-            lam = np.where(rho2 > 0, F32(0.5) * np.log2(np.where(rho2 > 0, rho2, F32(1.0)).astype(np.float64)).astype(F32), F32(0.0)).astype(F32)  # log2 rounded once
+            if self.alt == "fast_log2":  # sensitivity runs only: llvmpipe's level-of-detail unit takes log2 piecewise linear (exponent + mantissa - 1)
+                m, e = np.frexp(np.where(rho2 > 0, rho2, F32(1.0)).astype(np.float64))
+                lam = np.where(rho2 > 0, F32(0.5) * ((e - 1) + (2.0 * m - 1.0)).astype(F32), F32(0.0)).astype(F32)
+            else:
+                lam = np.where(rho2 > 0, F32(0.5) * np.log2(np.where(rho2 > 0, rho2, F32(1.0)).astype(np.float64)).astype(F32), F32(0.0)).astype(F32)  # log2 rounded once
         lam = np.fmin(np.fmax(lam, F32(0.0)), F32(nl - 1))
         lf = np.floor(lam)
         lo = lf.astype(np.int64)
