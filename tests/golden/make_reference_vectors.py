@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Generates tests/golden/reference_exec.npz: outputs of the REFERENCE'S OWN SHADER SOURCE executed here.
 
-The reference (GDShader) ships no tests and neither Godot nor a GLSL compiler exists in this image, so this script runs
+The reference (GDShader) ships no tests and Godot does not exist in this image (a GLSL compiler does, found in round 5: Mesa's, see
+make_mesa_vectors.py -- the second, independent executor of the same text), so this script runs
 the shader text itself: tests/golden/gdshader_vm.py interprets the files under
 /root/reference/addons/zylann.atmosphere/shaders/ (read at generation time only -- nothing of them is stored) with IEEE
 binary32 arithmetic, the engine's texture units supplied by tests/golden/vm_textures.py under the conventions stated in
