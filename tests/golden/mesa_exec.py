@@ -92,7 +92,43 @@ def _default_value(ty, expr):
     return vals * n if len(vals) == 1 else vals
 
 
-def translate(shader_file, defines=None, force_defines=None, stage="fragment"):
+# exp and pow, correctly rounded, written in GLSL with double arithmetic (GL 4.x fp64, which llvmpipe executes natively) and substituted for llvmpipe's own
+# (18 ulp / 1e-6) by two #defines in front of the reference's text: the `exact` configuration of the Mesa pin.  GLSL leaves the accuracy of exp and
+# pow to the implementation; this one is the best the type allows, which is also what the interpreter and (to an ulp) the oracle use.  Everything else --
+# the compiler, the control flow, sqrt / division / normalize / mix / clamp / dot, the texture units -- stays Mesa's.
+EXACT_BUILTINS = """
+double mgl_exp_d(double x) {   // e^x, |error| < 1e-15lf relative for |x| < 700
+    const double LN2_HI = 0.693147180369123816490lf, LN2_LO = 1.90821492927058770002e-10lf, INV_LN2 = 1.44269504088896338700lf;
+    double n = round(x * INV_LN2);
+    double r = (x - n * LN2_HI) - n * LN2_LO;          // |r| <= 0.3466lf
+    double p = 1.0lf / 6227020800.0lf;                      // Taylor to r^13 (0.3466lf^14 / 14! = 4e-18lf)
+    p = p * r + 1.0lf / 479001600.0lf;  p = p * r + 1.0lf / 39916800.0lf;  p = p * r + 1.0lf / 3628800.0lf;  p = p * r + 1.0lf / 362880.0lf;
+    p = p * r + 1.0lf / 40320.0lf;  p = p * r + 1.0lf / 5040.0lf;  p = p * r + 1.0lf / 720.0lf;  p = p * r + 1.0lf / 120.0lf;
+    p = p * r + 1.0lf / 24.0lf;  p = p * r + 1.0lf / 6.0lf;  p = p * r + 0.5lf;  p = p * r + 1.0lf;  p = p * r + 1.0lf;
+    return ldexp(p, int(n));
+}
+double mgl_log_d(double x) {   // ln x for x > 0
+    int e;
+    double m = frexp(x, e);                             // x = m 2^e, m in [0.5lf, 1)
+    if (m < 0.70710678118654752440lf) { m *= 2.0lf; e -= 1; }
+    double s = (m - 1.0lf) / (m + 1.0lf), s2 = s * s;       // |s| <= 0.1716lf; ln m = 2 atanh s
+    double p = 1.0lf / 27.0lf;
+    p = p * s2 + 1.0lf / 25.0lf;  p = p * s2 + 1.0lf / 23.0lf;  p = p * s2 + 1.0lf / 21.0lf;  p = p * s2 + 1.0lf / 19.0lf;  p = p * s2 + 1.0lf / 17.0lf;
+    p = p * s2 + 1.0lf / 15.0lf;  p = p * s2 + 1.0lf / 13.0lf;  p = p * s2 + 1.0lf / 11.0lf;  p = p * s2 + 1.0lf / 9.0lf;  p = p * s2 + 1.0lf / 7.0lf;
+    p = p * s2 + 1.0lf / 5.0lf;  p = p * s2 + 1.0lf / 3.0lf;  p = p * s2 + 1.0lf;
+    return 2.0lf * s * p + double(e) * 0.69314718055994530942lf;
+}
+float mgl_exp(float x) { return (x == x && abs(x) < 100.0) ? float(mgl_exp_d(double(x))) : exp(x); }
+vec2 mgl_exp(vec2 x) { return vec2(mgl_exp(x.x), mgl_exp(x.y)); }
+vec3 mgl_exp(vec3 x) { return vec3(mgl_exp(x.x), mgl_exp(x.y), mgl_exp(x.z)); }
+vec4 mgl_exp(vec4 x) { return vec4(mgl_exp(x.x), mgl_exp(x.y), mgl_exp(x.z), mgl_exp(x.w)); }
+float mgl_pow(float x, float y) { return (x > 0.0 && x < 3.0e38 && abs(y) < 1.0e4) ? float(mgl_exp_d(double(y) * mgl_log_d(double(x)))) : pow(x, y); }
+#define exp mgl_exp
+#define pow mgl_pow
+"""
+
+
+def translate(shader_file, defines=None, force_defines=None, stage="fragment", exact=False):
     """-> (GLSL 4.50 fragment-shader source, {uniform: (type, [hints], default floats or None)})"""
     forced = {k: str(v) for k, v in (force_defines or {}).items()}
     text = flatten(shader_file, forced)
@@ -152,7 +188,7 @@ void main() {
     MGL_out = COLOR;
 }
 """
-    return "\n".join(head) + builtins + text + main, uniforms
+    return "\n".join(head) + builtins + (EXACT_BUILTINS if exact else "") + text + main, uniforms
 
 
 # ---------------------------------------------------------------------------------------------------- running
@@ -214,7 +250,7 @@ def _upload_uniforms(prog, uniforms, params, world_to_model, sun, source_color):
 
 
 def run_frame(shader, defines, params, world_to_model, model_matrix, cam, depth, textures, time_s=0.0, sun=None, force_defines=None,
-              cube_chain=None):
+              cube_chain=None, exact=False):
     """As make_reference_vectors.run_frame: vertex() once, fragment() for every pixel.  textures: dict(lut (H, W) f32, blue (256, 256) u8,
     shape (n, n, n) u8 [z, y, x], cubemap (6, n, n) u8); cube_chain: [(6, n, n), (6, n/2, n/2), ...] -> the declared linear-mipmap sampler.
     Returns rgba (H, W, 4) with discarded fragments zeroed, the discard mask, the two varyings."""
@@ -223,7 +259,7 @@ def run_frame(shader, defines, params, world_to_model, model_matrix, cam, depth,
     sun = S.DEMO_SUN_POSITION if sun is None else sun
     path = os.path.join(SHADERS, shader + ".gdshader")
     # vertex stage
-    vsrc, uniforms = translate(path, defines, force_defines, stage="vertex")
+    vsrc, uniforms = translate(path, defines, force_defines, stage="vertex", exact=exact)
     vp = Program(vsrc)
     _upload_uniforms(vp, uniforms, params, world_to_model, sun, S.srgb_to_linear)
     ident = np.eye(4, dtype=F32).reshape(-1)
@@ -236,7 +272,7 @@ def run_frame(shader, defines, params, world_to_model, model_matrix, cam, depth,
     vp.close()
     varyings = (v[0, 0, :3].copy(), v[0, 1, :3].copy())
     # fragment stage
-    fsrc, uniforms = translate(path, defines, force_defines, stage="fragment")
+    fsrc, uniforms = translate(path, defines, force_defines, stage="fragment", exact=exact)
     fp = Program(fsrc)
     _upload_uniforms(fp, uniforms, params, world_to_model, sun, S.srgb_to_linear)
     fp.set("VIEWPORT_SIZE", "vec2", [cam.width, cam.height])
@@ -278,9 +314,9 @@ def run_frame(shader, defines, params, world_to_model, model_matrix, cam, depth,
     return out, disc, varyings
 
 
-def run_bake(params, n=256):
+def run_bake(params, n=256, exact=False):
     """optical_depth.gdshader over the n x n target, then what the baker does with it (RGBA8 viewport -> bytes reinterpreted as R32F)."""
-    src, uniforms = translate(os.path.join(SHADERS, "optical_depth.gdshader"), stage="canvas")
+    src, uniforms = translate(os.path.join(SHADERS, "optical_depth.gdshader"), stage="canvas", exact=exact)
     p = Program(src)
     for k in ("u_planet_radius", "u_atmosphere_height", "u_density"):
         p.set(k, "float", [params[k]])

@@ -3,13 +3,15 @@ compiled by MESA'S GLSL compiler and executed by llvmpipe (Mesa 23.2.1, the imag
 interface: tests/golden/mesa_glsl_runner.c, mesa_exec.py, make_mesa_vectors.py; report: profiles/round5/mesa_pin.txt).  The repository's own
 interpreter (gdshader_vm.py) pins the oracle to 5e-7; this file checks that a third party's reading of the same text lands in the same place.
 
-What bounds the agreement is llvmpipe's arithmetic, not the oracle's: its exp is 1.1e-6 relative (18 ulp), pow 1e-6, log2 4e-7 absolute
-(measured, stored in the fixture) where the oracle and the interpreter are within an ulp -- so
+What bounds the agreement is llvmpipe's arithmetic, not the oracle's -- ulp-level choices the language leaves to the implementation, probed bit for bit
+(profiles/round5/mesa_pin.txt section 12): mix is a + (b - a) t there (the stated convention here: the GLSL text's a (1 - t) + b t), normalize goes through
+inversesqrt, dot sums in another order, exp is 1.1e-6 relative (18 ulp), pow 1e-6 (measured, stored in the fixture) -- so
   * the cloudless variants agree to 2e-5 (v2) / 5e-5 (v1: its products reach 1e14 before the clamp);
   * a cloud pixel's light is a product of up to 64 exponentials times an optical thickness of up to 250: most values agree to 1e-5, and the
     fp32-hypersensitive pixels (profiles/round4/fuzz_sensitive_pixels.txt: the fp32 ORACLE itself sits up to 2e-2 from the fp64 evaluation of
-    the same text on them) move by up to 6e-3.  Bars: >= 97.5 % of a frame's values within 1e-4, none beyond 1e-2, and every pixel within
-    16 x (2e-5 + that pixel's own |fp32 oracle - fp64 oracle|): Mesa's deviation is explained, pixel by pixel, by fp32 sensitivity;
+    the same text on them) move by up to 6e-3 -- with a correctly rounded exp substituted as well: any one-ulp difference moves them.  Bars: >= 97.5 %
+    of a frame's values within 1e-4, none beyond 1e-2, and every pixel within 16 x (2e-5 + that pixel's own |fp32 oracle - fp64 oracle|): Mesa's
+    deviation is explained, pixel by pixel, by fp32 sensitivity;
   * discard masks, the vertex-stage varyings and the LUT bake of the demo scene are compared EXACTLY (the bake: 65 536 of 65 536 texels bit-identical).
 
   -m "not gpu":  the CPU oracle against Mesa's vectors; the interpreter's vectors against Mesa's; where /root/reference and Mesa are present, a re-run.
