@@ -47,6 +47,25 @@ def relerr(a, b):
     return np.abs(a - b) / np.maximum(1.0, np.abs(b))
 
 
+BLOCK = 16
+
+
+def block_means(rgba, discarded):
+    """(H / 16, W / 16, 4) float32 means (accumulated in float64; the frame sizes used are multiples of 16 in width, the last block row of 1080 is 8 high)
+    and (H / 16, W / 16) uint16 counts of kept fragments."""
+    h, w = discarded.shape
+    by, bx = (h + BLOCK - 1) // BLOCK, (w + BLOCK - 1) // BLOCK
+    pad = np.zeros((by * BLOCK, bx * BLOCK, 4), dtype=np.float64)
+    pad[:h, :w] = rgba
+    cnt = np.zeros((by * BLOCK, bx * BLOCK), dtype=np.float64)
+    cnt[:h, :w] = 1.0
+    kept = np.zeros((by * BLOCK, bx * BLOCK), dtype=np.int64)
+    kept[:h, :w] = ~discarded
+    n = cnt.reshape(by, BLOCK, bx, BLOCK).sum((1, 3))
+    mean = pad.reshape(by, BLOCK, bx, BLOCK, 4).sum((1, 3)) / n[..., None]
+    return mean.astype(np.float32), kept.reshape(by, BLOCK, bx, BLOCK).sum((1, 3)).astype(np.uint16)
+
+
 def stats(a, b):
     e = relerr(a, b)
     return f"max {e.max():.2e}  p99 {np.percentile(e, 99):.1e}  p99.9 {np.percentile(e, 99.9):.1e}  beyond 1e-4: {100.0 * np.mean(e > 1e-4):.3f} %"
@@ -193,6 +212,15 @@ def main():
             assert np.array_equal(disc, np.all(orc == 0.0, axis=-1)) or int(disc.sum()) == orc.shape[0] * orc.shape[1] - hits
             key = f"rows_{sampler}_{w}x{h}_{pose}_{shader}"
             out[f"rgba_{key}"], out[f"which_{key}"], out[f"depth_{key}"] = rgba[list(rows)], np.asarray(rows), depth[list(rows)]
+            if pose == "P_space" and (declared or not ("clouds" in shader.replace("no_clouds", ""))):
+                # the WHOLE frame, compactly: per 16 x 16 block the mean of every channel and the number of kept fragments -- every pixel of a frame drawn
+                # elsewhere enters a comparison against Mesa's (tests/test_reference_mesa.py::test_*_whole_frame_blocks)
+                bm, bk = block_means(rgba, disc)
+                out[f"blockmean_{sampler}_{w}x{h}_{pose}_{shader}"], out[f"blockkept_{sampler}_{w}x{h}_{pose}_{shader}"] = bm, bk
+                om, ok = block_means(orc, np.all(orc == 0.0, axis=-1))
+                line_b = f"   {'':14s} {'':9s} {'':8s} {'':8s} 16 x 16 block means vs oracle: max {np.abs(bm - om).max():.2e}; kept-fragment counts identical in {int((bk == ok).sum())} of {bk.size} blocks"
+            else:
+                line_b = None
             line = f"   {shader.replace('planet_atmosphere_', ''):14s} {w}x{h} {pose:8s} {sampler:8s} full frame vs oracle: {stats(rgba, orc)}"
             src, rk = (r5, f"lodfull_{w}x{h}_{pose}_{shader}") if declared else (z, f"full_{w}x{h}_{pose}_{shader}")
             if f"rgba_{rk}" in src.files:
@@ -201,6 +229,8 @@ def main():
                 if common:
                     line += f" | rows {common} vs interpreter: max {relerr(rgba[common], src[f'rgba_{rk}'][[have.index(r) for r in common]]).max():.2e}"
             print(line + f"   [{time.time() - t0:.0f} s]", flush=True)
+            if line_b:
+                print(line_b, flush=True)
     print("##    the other poses, clouds_high_rm 1920x1080, declared sampler, full frames against the oracle (report only, no vectors):")
     for pose in ("P_limb", "P_ground", "P_night"):
         cam = S.Camera.from_pose(1920, 1080, pose)

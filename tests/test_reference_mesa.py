@@ -199,6 +199,45 @@ def test_oracle_against_mesa_at_baseline_sizes(oracle32, vm, mesa, case):
     print(f"\n{case}: max |oracle - Mesa| = {worst:.3e} over {want.shape[0] * want.shape[1]} pixels")
 
 
+# whole frames, compactly: per 16 x 16 block the mean of every channel and the number of kept fragments of the frame llvmpipe drew -- EVERY pixel of the frame
+# under test enters the comparison.  Bars: the largest block-mean deviation of the CPU oracle from Mesa, measured when the vectors were made, with headroom.
+BLOCKS = [("planet_atmosphere_no_clouds", 1920, 1080, "lod0", 2e-6),            # measured 5.1e-7
+          ("planet_atmosphere_clouds_high", 1920, 1080, "declared", 5e-4),      # 2.8e-4: one block holds a 3e-2 pixel of section 6
+          ("planet_atmosphere_clouds_high_rm", 3840, 2160, "declared", 2e-4)]   # 6.6e-5
+
+
+def _block_means(rgba):
+    from make_mesa_vectors import block_means
+    return block_means(rgba, np.all(rgba == 0.0, axis=-1))
+
+
+def _blocks_case(vm, mesa, shader, w, h, sampler):
+    from common import demo_textures
+    tex = demo_textures()
+    assert S.checksum(tex["shape"]) == int(mesa["crc_shape_full"]) and S.checksum(tex["cubemap"]) == int(mesa["crc_cubemap_full"])
+    cam = RS.camera_from_fixture(vm, w, h, "P_space")
+    key = f"{sampler}_{w}x{h}_P_space_{shader}"
+    return tex, cam, S.depth_ground_sphere(cam), mesa[f"blockmean_{key}"], mesa[f"blockkept_{key}"]
+
+
+@pytest.mark.parametrize("case", BLOCKS[:2], ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}-{c[3]}")
+def test_oracle_whole_frame_blocks_against_mesa(oracle32, vm, mesa, case):
+    """configs[1] and configs[2] at 1920x1080, every pixel (the 3840x2160 frame of configs[3] is left to the GPU test: a minute of oracle time)."""
+    shader, w, h, sampler, bar = case
+    tex, cam, depth, want_mean, want_kept = _blocks_case(vm, mesa, shader, w, h, sampler)
+    params, _ = _scene("demo")
+    cfg = RS.VARIANTS[shader]
+    if sampler == "declared":
+        tex, cfg = dict(tex, cubemap=oracle32.cubemap_mip_chain(tex["cubemap"])), dict(cfg, cube_lod=1)
+    got, hits = oracle32.render(params, dict(tex, optical_depth=vm["lut_demo"]), cfg, make_frame(cam, np.eye(4), S.DEMO_SUN_POSITION, 0.0), depth, nthreads=8)
+    mean, kept = _block_means(got)
+    assert int(want_kept.sum()) == hits                      # Mesa kept exactly the fragments the oracle shades ...
+    assert np.array_equal(kept, want_kept)                   # ... block by block (a kept fragment that evaluates to 0 would show here; none does)
+    err = float(np.abs(mean - want_mean).max())
+    print(f"\n{shader} {w}x{h} {sampler}: {want_kept.size} blocks, max |block mean: oracle - Mesa| = {err:.2e}")
+    assert err <= bar
+
+
 @pytest.mark.skipif(not (os.path.isdir("/root/reference/addons/zylann.atmosphere/shaders") and os.path.exists("/usr/lib/x86_64-linux-gnu/dri/swrast_dri.so")),
                     reason="needs the reference tree and Mesa's swrast_dri.so (the build container)")
 def test_mesa_vectors_reproduce_here(vm, mesa, textures):
@@ -266,3 +305,22 @@ def test_hip_against_mesa_at_baseline_sizes(vm, mesa, case):
     node.close()
     worst = _check(got, want, shader, f"HIP vs Mesa {case}")
     print(f"\n{case} {name}: max |HIP - Mesa| = {worst:.3e} over {want.shape[0] * want.shape[1]} pixels")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", BLOCKS, ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}-{c[3]}")
+def test_hip_whole_frame_blocks_against_mesa(vm, mesa, case):
+    """BASELINE configs[1], [2], [3] at their sizes with the library's default kernels: every pixel of the HIP frame, as 16 x 16 block means and kept-fragment
+    counts, against the frame llvmpipe drew from the reference's text."""
+    shader, w, h, sampler, bar = case
+    tex, cam, depth, want_mean, want_kept = _blocks_case(vm, mesa, shader, w, h, sampler)
+    params, _ = _scene("demo")
+    node = make_node(NODE_CONFIG[shader], tex, params)   # default sampler = the declared one for the cloud variants
+    got = _gpu_render(node, cam, depth)
+    name = node.kernel_name
+    node.close()
+    mean, kept = _block_means(got)
+    assert np.array_equal(kept, want_kept)
+    err = float(np.abs(mean - want_mean).max())
+    print(f"\n{shader} {w}x{h} {sampler} {name}: {want_kept.size} blocks ({w * h} pixels), max |block mean: HIP - Mesa| = {err:.2e}")
+    assert err <= bar
