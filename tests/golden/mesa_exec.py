@@ -78,7 +78,7 @@ def flatten(path, forced):
     return "\n".join(out)
 
 
-_UNIFORM = re.compile(r"^(\s*)uniform\s+(\w+)\s+(\w+)\s*(?::\s*([^=;]+?))?\s*(?:=\s*([^;]+?))?\s*;", re.M)
+_UNIFORM = re.compile(r"^([ \t]*)uniform[ \t]+(\w+)[ \t]+(\w+)[ \t]*(?::[ \t]*([^=;\n]+?))?[ \t]*(?:=[ \t]*([^;\n]+?))?[ \t]*;", re.M)
 
 
 def _default_value(ty, expr):
@@ -132,7 +132,7 @@ def translate(shader_file, defines=None, force_defines=None, stage="fragment", e
     """-> (GLSL 4.50 fragment-shader source, {uniform: (type, [hints], default floats or None)})"""
     forced = {k: str(v) for k, v in (force_defines or {}).items()}
     text = flatten(shader_file, forced)
-    text = re.sub(r"^\s*(shader_type|render_mode)\b[^;]*;", "", text, flags=re.M)
+    text = re.sub(r"^[ \t]*(shader_type|render_mode)\b[^;\n]*;", "", text, flags=re.M)
     uniforms = {}
 
     def uni(m):
@@ -142,7 +142,7 @@ def translate(shader_file, defines=None, force_defines=None, stage="fragment", e
         return f"{m.group(1)}uniform {ty} {name};"
 
     text = _UNIFORM.sub(uni, text)
-    text = re.sub(r"^(\s*)varying\s+", r"\1", text, flags=re.M)
+    text = re.sub(r"^([ \t]*)varying[ \t]+", r"\1", text, flags=re.M)
     text = re.sub(r",(\s*)\)", r"\1)", text)  # GDShader accepts a trailing comma in parameter and argument lists, GLSL does not
     head = ["#version 450 core"]
     for k, v in list((defines or {}).items()) + [(k, v) for k, v in forced.items() if not re.search(r"#\s*define\s+" + k + r"\b", text)]:

@@ -238,6 +238,51 @@ def test_oracle_whole_frame_blocks_against_mesa(oracle32, vm, mesa, case):
     assert err <= bar
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/addons/zylann.atmosphere/shaders"), reason="needs the reference tree (the build container)")
+def test_what_mesa_compiles_is_the_references_text():
+    """mesa_exec.translate: between the prelude it puts in front (the #version line, the engine built-ins) and the main() it appends, the source handed to
+    Mesa's compiler is the reference's files with their #includes pasted in, and every line that differs from the file on disk is one of the four
+    declared edits: a `uniform` declaration stripped of hints and default, a `varying` turned into a global, a `shader_type` / `render_mode` line
+    dropped, a trailing comma removed in front of `)`.  No statement inside a function body is touched."""
+    import re
+    import mesa_exec as M
+
+    shaders = sorted(f for f in os.listdir(M.SHADERS) if f.endswith(".gdshader"))
+    assert len(shaders) == 8
+    edited = {"uniform": 0, "varying": 0, "dropped": 0, "comma": 0}
+    total = 0
+    for f in shaders:
+        path = os.path.join(M.SHADERS, f)
+        original = M.flatten(path, {}).split("\n")
+        for stage in ("fragment", "vertex") if "planet_atmosphere" in f else ("canvas",):
+            src, _ = M.translate(path, stage=stage)
+            begin = src.index("out vec4 MGL_out;\n") + len("out vec4 MGL_out;\n")
+            body = src[begin:src.rindex("\nvoid main() {")].split("\n")
+            assert len(body) == len(original), f
+            for k, (a, b) in enumerate(zip(original, body)):
+                total += 1
+                if a == b:
+                    continue
+                if re.match(r"\s*uniform\s", a):
+                    ty, name = re.match(r"\s*uniform\s+(\w+)\s+(\w+)", a).groups()
+                    assert b.strip() == f"uniform {ty} {name};", (a, b)     # hints and default gone, nothing else
+                    edited["uniform"] += 1
+                elif re.match(r"\s*varying\s", a):
+                    assert b.strip() == a.strip()[len("varying"):].strip(), (a, b)
+                    edited["varying"] += 1
+                elif re.match(r"\s*(shader_type|render_mode)\b", a):
+                    assert re.sub(r"^\s*(shader_type|render_mode)\b[^;]*;", "", a) == b, (a, b)
+                    edited["dropped"] += 1
+                else:
+                    # a trailing comma in front of `)`: on this line, or at its end with the `)` opening the next line
+                    same_line = re.sub(r",(\s*)\)", r"\1)", a)
+                    line_end = (a.rstrip()[:-1] + a[len(a.rstrip()):]) if a.rstrip().endswith(",") and original[k + 1].lstrip().startswith(")") else None
+                    assert b in (same_line, line_end), (a, b)
+                    edited["comma"] += 1
+    print(f"\n{total} lines of reference text handed to Mesa over {len(shaders)} shaders x stages; edited: {edited}")
+    assert edited["uniform"] > 100 and edited["varying"] > 10 and edited["dropped"] > 10 and 0 < edited["comma"] < 400
+
+
 @pytest.mark.skipif(not (os.path.isdir("/root/reference/addons/zylann.atmosphere/shaders") and os.path.exists("/usr/lib/x86_64-linux-gnu/dri/swrast_dri.so")),
                     reason="needs the reference tree and Mesa's swrast_dri.so (the build container)")
 def test_mesa_vectors_reproduce_here(vm, mesa, textures):
