@@ -221,7 +221,9 @@ class CubeTextureLod:
       * rho^2 = n^2 (ds^2 + dt^2) per axis, lambda = 0.5 log2(max(rho_x^2, rho_y^2)) clamped to [0, levels - 1];
       * result = mix(level floor(lambda), level floor(lambda) + 1, fract(lambda)), each level bilinear + seamless.
     `alt`: sensitivity runs only -- "f64_plain" evaluates s' - s as the plain difference of the two projections in float64; "fast_log2" takes
-    lambda from a piecewise-linear log2 as llvmpipe does (profiles/round5/mesa_pin.txt, section 11)."""
+    lambda from a piecewise-linear log2 as llvmpipe does (profiles/round5/mesa_pin.txt, section 11); "unmasked" lets a quad partner that did NOT reach
+    the call contribute the coordinate its lane holds anyway (what an implementation that runs all four lanes of a quad under an execution mask
+    differences against); "fast_log2+unmasked" both."""
 
     needs_quad = True
 
@@ -242,7 +244,7 @@ class CubeTextureLod:
             rho2 = np.zeros(d.shape[1], dtype=F32)
             n2 = F32(self.n0) * F32(self.n0)
             for q in (self.qx, self.qy):
-                ok = (q >= 0) & reach[np.clip(q, 0, None)]
+                ok = (q >= 0) & (reach[np.clip(q, 0, None)] | (self.alt is not None and "unmasked" in self.alt))  # "unmasked": sensitivity runs only, see below
                 dv = (d[:, np.clip(q, 0, None)] - d).astype(F32)
                 dsc, dtc, dma = _face_frame(face, dv)
                 ma2 = (ma + dma).astype(F32)
@@ -258,7 +260,7 @@ class CubeTextureLod:
                     dt = ((dtc * ma - tc * dma) * inv).astype(F32)
                     r2 = ((ds * ds + dt * dt) * n2).astype(F32)
                 rho2 = np.where(ok, np.fmax(rho2, r2), rho2)
-            if self.alt == "fast_log2":  # sensitivity runs only: llvmpipe's level-of-detail unit takes log2 piecewise linear (exponent + mantissa - 1)
+            if self.alt is not None and "fast_log2" in self.alt:  # sensitivity runs only: llvmpipe's level-of-detail unit takes log2 piecewise linear (exponent + mantissa - 1)
                 m, e = np.frexp(np.where(rho2 > 0, rho2, F32(1.0)).astype(np.float64))
                 lam = np.where(rho2 > 0, F32(0.5) * ((e - 1) + (2.0 * m - 1.0)).astype(F32), F32(0.0)).astype(F32)
             else:
