@@ -169,15 +169,21 @@ unsigned mgl_program(const char *fs_src, char *log, int logsz) {
     GLuint vs = compile(GL_VERTEX_SHADER, VS, log, logsz);
     if (!vs) return 0;
     GLuint fs = compile(GL_FRAGMENT_SHADER, fs_src, log, logsz);
-    if (!fs) return 0;
+    if (!fs) {
+        p_glDeleteShader(vs);
+        return 0;
+    }
     GLuint prog = p_glCreateProgram();
     p_glAttachShader(prog, vs);
     p_glAttachShader(prog, fs);
     p_glLinkProgram(prog);
+    p_glDeleteShader(vs);   /* flagged for deletion; freed with the program */
+    p_glDeleteShader(fs);
     GLint ok = 0;
     p_glGetProgramiv(prog, GL_LINK_STATUS, &ok);
     if (!ok) {
         p_glGetProgramInfoLog(prog, logsz, NULL, log);
+        p_glDeleteProgram(prog);
         return 0;
     }
     p_glUseProgram(prog);
@@ -260,7 +266,12 @@ int mgl_draw(unsigned prog, int w, int h, float clear, float *rgba) {
     p_glGenFramebuffers(1, &fbo);
     p_glBindFramebuffer(GL_FRAMEBUFFER, fbo);
     p_glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, tex, 0);
-    if (p_glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) return fail("framebuffer incomplete");
+    if (p_glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) {
+        p_glBindFramebuffer(GL_FRAMEBUFFER, 0);
+        p_glDeleteFramebuffers(1, &fbo);
+        p_glDeleteTextures(1, &tex);
+        return fail("framebuffer incomplete");
+    }
     const GLenum bufs[] = {GL_COLOR_ATTACHMENT0};
     p_glDrawBuffers(1, bufs);
     p_glViewport(0, 0, w, h);
