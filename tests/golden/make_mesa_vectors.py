@@ -241,7 +241,53 @@ def main():
         orc, hits = oracle.render(oparams, otex, dict(RS.VARIANTS[shader], cube_lod=1), make_frame(cam, model, S.DEMO_SUN_POSITION, 0.0), depth, nthreads=8)
         assert int((~disc).sum()) == hits, pose
         print(f"   clouds_high_rm 1920x1080 {pose:8s} declared full frame vs oracle: {stats(rgba, orc)}; {hits} fragments kept by both   [{time.time() - t0:.0f} s]", flush=True)
+    headline(out, oracle, z)
     path = os.path.join(HERE, "reference_exec_mesa.npz")
+    np.savez_compressed(path, **out)
+    print(f"\n# wrote {os.path.relpath(path, ROOT)}: {os.path.getsize(path)} bytes, {len(out)} arrays")
+
+
+def headline(out, oracle, z):
+    """Section 13: BASELINE.json's headline configuration -- planet_atmosphere_no_clouds at 32 view steps with the DIRECT 8-step light march.  It has no shader
+    file of its own in the reference; mesa_exec.DIRECT_LIGHT_GLUE is the composition (the reference's ray_sphere and get_atmosphere_density in the loop of
+    optical_depth.gdshader:17-31, spliced in front of the reference's compute_atmosphere_v2, whose one LUT fetch a macro redirects)."""
+    params, model = RS.scenes()["demo"]
+    blue = S.make_blue_noise()
+    tex = dict(lut=z["lut_demo"], blue=blue)
+    oparams = dict(params, u_world_to_model_matrix=S.col_major(np.eye(4)))
+    ocfg = dict(view_steps=32, light_steps=8)
+    force = {"ATMOSPHERE_RAYMARCH_STEPS": 32}
+    print("\n## 13. BASELINE's headline configuration (32 view x 8 light steps, direct light march: the kernel bench.py's `value` is measured on), composed from the\n"
+          "##     reference's own functions (mesa_exec.DIRECT_LIGHT_GLUE: 14 lines of glue) and compiled by Mesa, against the CPU oracle's direct mode")
+    for pose in RS.POSES:
+        cam = RS.camera_from_fixture(z, RS.W, RS.H, pose)
+        depth = z[f"depth_demo_{pose}"]
+        rgba, disc, _ = M.run_frame("planet_atmosphere_no_clouds", None, params, np.eye(4), model, cam, depth, tex, force_defines=force, direct_light_steps=8)
+        orc, hits = oracle.render(oparams, dict(blue_noise=blue), ocfg, make_frame(cam, model, S.DEMO_SUN_POSITION, 0.0), depth, nthreads=8)
+        assert int((~disc).sum()) == hits
+        out[f"direct32x8_rgba_{pose}"] = rgba
+        print(f"   48x27 {pose:8s}: {hits} fragments kept by both; max |Mesa - oracle| {np.abs(rgba - orc).max():.2e}")
+    w, h, pose, rows = 1920, 1080, "P_space", (330, 539)
+    cam = RS.camera_from_fixture(z, w, h, pose)
+    depth = S.depth_ground_sphere(cam)
+    rgba, disc, _ = M.run_frame("planet_atmosphere_no_clouds", None, params, np.eye(4), model, cam, depth, tex, force_defines=force, direct_light_steps=8)
+    orc, hits = oracle.render(oparams, dict(blue_noise=blue), ocfg, make_frame(cam, model, S.DEMO_SUN_POSITION, 0.0), depth, nthreads=8)
+    assert int((~disc).sum()) == hits
+    bm, bk = block_means(rgba, disc)
+    om, ok = block_means(orc, np.all(orc == 0.0, axis=-1))
+    out["direct32x8_rows_rgba"], out["direct32x8_rows_which"] = rgba[list(rows)], np.asarray(rows)
+    out["direct32x8_blockmean"], out["direct32x8_blockkept"] = bm, bk
+    print(f"   1920x1080 P_space (BASELINE configs[1] as benchmarked), full frame vs oracle: {stats(rgba, orc)}; {hits} fragments kept by both;\n"
+          f"      16 x 16 block means: max {np.abs(bm - om).max():.2e}, kept-fragment counts identical in {int((bk == ok).sum())} of {bk.size} blocks")
+
+
+def main_headline():
+    from oracle.oracle import Oracle
+
+    path = os.path.join(HERE, "reference_exec_mesa.npz")
+    old = np.load(path)
+    out = {k: old[k] for k in old.files}
+    headline(out, Oracle("f32"), np.load(os.path.join(HERE, "reference_exec.npz")))
     np.savez_compressed(path, **out)
     print(f"\n# wrote {os.path.relpath(path, ROOT)}: {os.path.getsize(path)} bytes, {len(out)} arrays")
 
@@ -288,6 +334,8 @@ def fuzz_report():
 if __name__ == "__main__":
     if "--fuzz-report" in sys.argv:
         fuzz_report()
+    elif "--headline-only" in sys.argv:
+        main_headline()
     else:
         main()
         fuzz_report()

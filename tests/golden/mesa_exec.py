@@ -128,7 +128,30 @@ float mgl_pow(float x, float y) { return (x > 0.0 && x < 3.0e38 && abs(y) < 1.0e
 """
 
 
-def translate(shader_file, defines=None, force_defines=None, stage="fragment", exact=False):
+# BASELINE.json's headline configuration ("32 view x 8 light steps") has no shader file of its own in the reference: its light march is this repository's
+# composition -- the LUT fetch of compute_atmosphere_v2 replaced by the quantity the LUT tabulates (optical_depth.gdshader:17-31
+# with the chord of :56-65), evaluated at the 3-D sample position with N left-Riemann samples.  For Mesa that composition is these lines, spliced in front of
+# the reference's compute_atmosphere_v2 (whose body stays untouched: a macro redirects its one call) and built from the reference's own ray_sphere and
+# get_atmosphere_density:
+DIRECT_LIGHT_GLUE = """
+float mgl_marched_optical_depth(vec3 pos, vec3 dir, vec3 planet_center) {
+    vec2 rs = ray_sphere(planet_center, u_planet_radius + u_atmosphere_height, pos, dir);
+    float ray_len = rs.y - max(rs.x, 0.0);
+    float step_len = ray_len / float(MGL_LIGHT_STEPS);
+    float optical_depth = 0.0;
+    for (int i = 0; i < MGL_LIGHT_STEPS; ++i) {
+        vec3 p = pos + dir * step_len * float(i);
+        float d = length(p - planet_center);
+        float density = get_atmosphere_density(d);
+        optical_depth += density * step_len * u_density;
+    }
+    return optical_depth;
+}
+#define get_baked_optical_depth(p, d, c, t) mgl_marched_optical_depth(p, d, c)
+"""
+
+
+def translate(shader_file, defines=None, force_defines=None, stage="fragment", exact=False, direct_light_steps=None):
     """-> (GLSL 4.50 fragment-shader source, {uniform: (type, [hints], default floats or None)})"""
     forced = {k: str(v) for k, v in (force_defines or {}).items()}
     text = flatten(shader_file, forced)
@@ -144,6 +167,10 @@ def translate(shader_file, defines=None, force_defines=None, stage="fragment", e
     text = _UNIFORM.sub(uni, text)
     text = re.sub(r"^([ \t]*)varying[ \t]+", r"\1", text, flags=re.M)
     text = re.sub(r",(\s*)\)", r"\1)", text)  # GDShader accepts a trailing comma in parameter and argument lists, GLSL does not
+    if direct_light_steps:
+        anchor = "vec4 compute_atmosphere_v2("
+        assert text.count(anchor) == 1
+        text = text.replace(anchor, f"#define MGL_LIGHT_STEPS {int(direct_light_steps)}\n" + DIRECT_LIGHT_GLUE + anchor)
     head = ["#version 450 core"]
     for k, v in list((defines or {}).items()) + [(k, v) for k, v in forced.items() if not re.search(r"#\s*define\s+" + k + r"\b", text)]:
         head.append(f"#define {k} {v}")
@@ -250,7 +277,7 @@ def _upload_uniforms(prog, uniforms, params, world_to_model, sun, source_color):
 
 
 def run_frame(shader, defines, params, world_to_model, model_matrix, cam, depth, textures, time_s=0.0, sun=None, force_defines=None,
-              cube_chain=None, exact=False):
+              cube_chain=None, exact=False, direct_light_steps=None):
     """As make_reference_vectors.run_frame: vertex() once, fragment() for every pixel.  textures: dict(lut (H, W) f32, blue (256, 256) u8,
     shape (n, n, n) u8 [z, y, x], cubemap (6, n, n) u8); cube_chain: [(6, n, n), (6, n/2, n/2), ...] -> the declared linear-mipmap sampler.
     Returns rgba (H, W, 4) with discarded fragments zeroed, the discard mask, the two varyings."""
@@ -259,7 +286,7 @@ def run_frame(shader, defines, params, world_to_model, model_matrix, cam, depth,
     sun = S.DEMO_SUN_POSITION if sun is None else sun
     path = os.path.join(SHADERS, shader + ".gdshader")
     # vertex stage
-    vsrc, uniforms = translate(path, defines, force_defines, stage="vertex", exact=exact)
+    vsrc, uniforms = translate(path, defines, force_defines, stage="vertex", exact=exact, direct_light_steps=direct_light_steps)
     vp = Program(vsrc)
     _upload_uniforms(vp, uniforms, params, world_to_model, sun, S.srgb_to_linear)
     ident = np.eye(4, dtype=F32).reshape(-1)
@@ -272,7 +299,7 @@ def run_frame(shader, defines, params, world_to_model, model_matrix, cam, depth,
     vp.close()
     varyings = (v[0, 0, :3].copy(), v[0, 1, :3].copy())
     # fragment stage
-    fsrc, uniforms = translate(path, defines, force_defines, stage="fragment", exact=exact)
+    fsrc, uniforms = translate(path, defines, force_defines, stage="fragment", exact=exact, direct_light_steps=direct_light_steps)
     fp = Program(fsrc)
     _upload_uniforms(fp, uniforms, params, world_to_model, sun, S.srgb_to_linear)
     fp.set("VIEWPORT_SIZE", "vec2", [cam.width, cam.height])
@@ -284,6 +311,8 @@ def run_frame(shader, defines, params, world_to_model, model_matrix, cam, depth,
     unit = 0
     for name, (ty, hints, _) in uniforms.items():
         if not ty.startswith("sampler"):
+            continue
+        if fp.set(name, "int", [unit]) == -1:   # not active in this variant (declared by an include whose functions the variant does not call)
             continue
         if name == "u_depth_texture":
             d = np.ascontiguousarray(depth, dtype=F32)
