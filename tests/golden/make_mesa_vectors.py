@@ -242,6 +242,7 @@ def main():
         assert int((~disc).sum()) == hits, pose
         print(f"   clouds_high_rm 1920x1080 {pose:8s} declared full frame vs oracle: {stats(rgba, orc)}; {hits} fragments kept by both   [{time.time() - t0:.0f} s]", flush=True)
     headline(out, oracle, z)
+    composite(out, z)
     path = os.path.join(HERE, "reference_exec_mesa.npz")
     np.savez_compressed(path, **out)
     print(f"\n# wrote {os.path.relpath(path, ROOT)}: {os.path.getsize(path)} bytes, {len(out)} arrays")
@@ -281,13 +282,44 @@ def headline(out, oracle, z):
           f"      16 x 16 block means: max {np.abs(bm - om).max():.2e}, kept-fragment counts identical in {int((bk == ok).sum())} of {bk.size} blocks")
 
 
+COMPOSITE = [("P_limb", "planet_atmosphere_clouds_high_rm"), ("P_space", "planet_atmosphere_no_clouds")]
+
+
+def composite_scene():
+    """the scene colour buffer the atmosphere is blended onto: seeded noise, regenerated by the tests"""
+    return np.random.default_rng(7).uniform(0.0, 1.0, (RS.H, RS.W, 4)).astype(F32)
+
+
+def composite(out, z):
+    """Section 14: the draw WITH the renderer's blend stage -- the shader's (ALBEDO, ALPHA) through llvmpipe's fixed-function blender
+    set as a blend_mix material's is (colour SRC_ALPHA / ONE_MINUS_SRC_ALPHA, alpha ONE / ONE_MINUS_SRC_ALPHA), onto a colour buffer holding a scene."""
+    params, model = RS.scenes()["demo"]
+    tex = dict(lut=z["lut_demo"], blue=S.make_blue_noise(), shape=S.make_shape_texture(RS.SHAPE_N), cubemap=S.make_coverage_cubemap(RS.CUBE_N))
+    scene = composite_scene()
+    print("\n## 14. the draw with the blend stage: llvmpipe's fixed-function blender (blend_mix state) over a colour buffer of seeded noise, 48 x 27")
+    for pose, shader in COMPOSITE:
+        cam = RS.camera_from_fixture(z, RS.W, RS.H, pose)
+        blended, _, _ = M.run_frame(shader, None, params, np.eye(4), model, cam, z[f"depth_demo_{pose}"], tex, over=scene)
+        src = out[f"rgba_demo_{pose}_{shader}"]
+        disc = np.unpackbits(out[f"discard_demo_{pose}_{shader}"])[:RS.W * RS.H].reshape(RS.H, RS.W).astype(bool)
+        a = src[..., 3:4]
+        want = np.concatenate([src[..., :3] * a + scene[..., :3] * (F32(1.0) - a), a + scene[..., 3:] * (F32(1.0) - a)], axis=-1).astype(F32)
+        want[disc] = scene[disc]
+        out[f"composite_{pose}_{shader}"] = blended
+        print(f"   {pose:8s} {shader.replace('planet_atmosphere_', ''):16s}: discarded fragments leave the buffer untouched: {np.array_equal(blended[disc], scene[disc])};"
+              f" blender == src * a + dst * (1 - a), products rounded on their own: {int((blended == want).all(-1).sum())} of {disc.size} pixels bit-identical")
+
+
 def main_headline():
     from oracle.oracle import Oracle
 
     path = os.path.join(HERE, "reference_exec_mesa.npz")
     old = np.load(path)
     out = {k: old[k] for k in old.files}
-    headline(out, Oracle("f32"), np.load(os.path.join(HERE, "reference_exec.npz")))
+    zz = np.load(os.path.join(HERE, "reference_exec.npz"))
+    if "--composite-only" not in sys.argv:
+        headline(out, Oracle("f32"), zz)
+    composite(out, zz)
     np.savez_compressed(path, **out)
     print(f"\n# wrote {os.path.relpath(path, ROOT)}: {os.path.getsize(path)} bytes, {len(out)} arrays")
 
@@ -334,7 +366,7 @@ def fuzz_report():
 if __name__ == "__main__":
     if "--fuzz-report" in sys.argv:
         fuzz_report()
-    elif "--headline-only" in sys.argv:
+    elif "--headline-only" in sys.argv or "--composite-only" in sys.argv:
         main_headline()
     else:
         main()

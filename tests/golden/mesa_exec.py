@@ -48,6 +48,7 @@ def lib():
         L.mgl_texture.restype = C.c_uint
         L.mgl_texture.argtypes = [C.c_uint, C.c_char_p] + [C.c_int] * 8 + [C.c_void_p]
         L.mgl_draw.argtypes = [C.c_uint, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        L.mgl_draw_over.argtypes = [C.c_uint, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
         L.mgl_delete_texture.argtypes = [C.c_uint]
         L.mgl_delete_program.argtypes = [C.c_uint]
         if L.mgl_init(None) != 0:
@@ -243,9 +244,11 @@ class Program:
             raise RuntimeError(f"texture {sampler} failed")
         self.textures.append(t)
 
-    def draw(self, w, h, clear=-1.0):
+    def draw(self, w, h, clear=-1.0, over=None):
+        """over: (h, w, 4) float32 scene colours the draw is alpha-blended onto by the fixed-function blend stage (blend_mix); None: a cleared target"""
         out = np.empty((h, w, 4), dtype=F32)
-        if lib().mgl_draw(self.id, w, h, C.c_float(clear), out.ctypes.data_as(C.c_void_p)) != 0:
+        dst = None if over is None else np.ascontiguousarray(over, dtype=F32)
+        if lib().mgl_draw_over(self.id, w, h, C.c_float(clear), None if dst is None else dst.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) != 0:
             raise RuntimeError("draw: " + lib().mgl_error().decode())
         return out
 
@@ -277,7 +280,7 @@ def _upload_uniforms(prog, uniforms, params, world_to_model, sun, source_color):
 
 
 def run_frame(shader, defines, params, world_to_model, model_matrix, cam, depth, textures, time_s=0.0, sun=None, force_defines=None,
-              cube_chain=None, exact=False, direct_light_steps=None):
+              cube_chain=None, exact=False, direct_light_steps=None, over=None):
     """As make_reference_vectors.run_frame: vertex() once, fragment() for every pixel.  textures: dict(lut (H, W) f32, blue (256, 256) u8,
     shape (n, n, n) u8 [z, y, x], cubemap (6, n, n) u8); cube_chain: [(6, n, n), (6, n/2, n/2), ...] -> the declared linear-mipmap sampler.
     Returns rgba (H, W, 4) with discarded fragments zeroed, the discard mask, the two varyings."""
@@ -336,6 +339,10 @@ def run_frame(shader, defines, params, world_to_model, model_matrix, cam, depth,
         else:
             raise RuntimeError(f"no texture for sampler {name}")
         unit += 1
+    if over is not None:   # the draw with the renderer's blend stage: the frame is what the colour buffer holds afterwards
+        out = fp.draw(cam.width, cam.height, over=over)
+        fp.close()
+        return out, None, varyings
     out = fp.draw(cam.width, cam.height, clear=-1.0)
     fp.close()
     disc = np.all(out == -1.0, axis=-1)

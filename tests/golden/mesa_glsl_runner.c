@@ -59,7 +59,8 @@ static const __DRIextension *g_loader_exts[] = {&g_loader.base, NULL};
     X(PFNGLBINDFRAMEBUFFERPROC, glBindFramebuffer) X(PFNGLFRAMEBUFFERTEXTURE2DPROC, glFramebufferTexture2D)                                \
     X(PFNGLCHECKFRAMEBUFFERSTATUSPROC, glCheckFramebufferStatus) X(PFNGLDELETEFRAMEBUFFERSPROC, glDeleteFramebuffers)                      \
     X(PFNGLGENVERTEXARRAYSPROC, glGenVertexArrays) X(PFNGLBINDVERTEXARRAYPROC, glBindVertexArray) X(PFNGLACTIVETEXTUREPROC, glActiveTexture) \
-    X(PFNGLTEXIMAGE3DPROC, glTexImage3D) X(PFNGLGENERATEMIPMAPPROC, glGenerateMipmap) X(PFNGLDRAWBUFFERSPROC, glDrawBuffers)
+    X(PFNGLTEXIMAGE3DPROC, glTexImage3D) X(PFNGLGENERATEMIPMAPPROC, glGenerateMipmap) X(PFNGLDRAWBUFFERSPROC, glDrawBuffers) \
+    X(PFNGLBLENDFUNCSEPARATEPROC, glBlendFuncSeparate) X(PFNGLBLENDEQUATIONPROC, glBlendEquation)
 GL_FUNCS(GLF)
 /* GL 1.x entry points come through the same table: libGL.so here is libglvnd's, whose dispatch this context is not registered with */
 static void (*p_glGenTextures)(GLsizei, GLuint *);
@@ -254,13 +255,16 @@ unsigned mgl_texture(unsigned prog, const char *sampler, int unit, int dims, int
 void mgl_delete_texture(unsigned tex) { p_glDeleteTextures(1, &tex); }
 void mgl_delete_program(unsigned prog) { p_glDeleteProgram(prog); }
 
-/* one full-screen triangle into a w x h RGBA32F target cleared to `clear`; rgba: w * h * 4 floats, row 0 = the BOTTOM row (gl_FragCoord.y = 0.5) */
-int mgl_draw(unsigned prog, int w, int h, float clear, float *rgba) {
+/* one full-screen triangle into a w x h RGBA32F target; rgba: w * h * 4 floats, row 0 = the BOTTOM row (gl_FragCoord.y = 0.5).
+ * dst == NULL: the target is cleared to `clear`, no blending.  dst != NULL: the target starts as dst (the scene's colour buffer) and the fragment's
+ * (rgb, a) goes through the FIXED-FUNCTION blend stage as a blend_mix material's does: colour SRC_ALPHA / ONE_MINUS_SRC_ALPHA, alpha ONE /
+ * ONE_MINUS_SRC_ALPHA, equation ADD; a discarded fragment leaves the target as it was. */
+int mgl_draw_over(unsigned prog, int w, int h, float clear, const float *dst, float *rgba) {
     GLuint fbo, tex;
     p_glGenTextures(1, &tex);
     p_glActiveTexture(GL_TEXTURE0 + 15);
     p_glBindTexture(GL_TEXTURE_2D, tex);
-    p_glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA32F, w, h, 0, GL_RGBA, GL_FLOAT, NULL);
+    p_glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA32F, w, h, 0, GL_RGBA, GL_FLOAT, dst);
     p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
     p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
     p_glGenFramebuffers(1, &fbo);
@@ -275,11 +279,18 @@ int mgl_draw(unsigned prog, int w, int h, float clear, float *rgba) {
     const GLenum bufs[] = {GL_COLOR_ATTACHMENT0};
     p_glDrawBuffers(1, bufs);
     p_glViewport(0, 0, w, h);
-    p_glClearColor(clear, clear, clear, clear);
-    p_glClear(GL_COLOR_BUFFER_BIT);
+    if (dst) {
+        p_glEnable(GL_BLEND);
+        p_glBlendEquation(GL_FUNC_ADD);
+        p_glBlendFuncSeparate(GL_SRC_ALPHA, GL_ONE_MINUS_SRC_ALPHA, GL_ONE, GL_ONE_MINUS_SRC_ALPHA);
+    } else {
+        p_glClearColor(clear, clear, clear, clear);
+        p_glClear(GL_COLOR_BUFFER_BIT);
+    }
     p_glUseProgram(prog);
     p_glDrawArrays(GL_TRIANGLES, 0, 3);
     p_glFinish();
+    p_glDisable(GL_BLEND);
     p_glReadPixels(0, 0, w, h, GL_RGBA, GL_FLOAT, rgba);
     const GLenum e = p_glGetError();
     p_glBindFramebuffer(GL_FRAMEBUFFER, 0);
@@ -288,3 +299,5 @@ int mgl_draw(unsigned prog, int w, int h, float clear, float *rgba) {
     if (e != GL_NO_ERROR) { snprintf(g_err, sizeof g_err, "GL error 0x%x", e); return -1; }
     return 0;
 }
+
+int mgl_draw(unsigned prog, int w, int h, float clear, float *rgba) { return mgl_draw_over(prog, w, h, clear, NULL, rgba); }

@@ -227,6 +227,28 @@ def test_headline_configuration_against_mesa(oracle32, vm, mesa):
     assert err <= 5e-6   # measured 1.4e-6
 
 
+def test_blend_stage_against_mesa(oracle32, vm, mesa, textures):
+    """The draw with the renderer's blend stage: llvmpipe's FIXED-FUNCTION blender in blend_mix state over a colour buffer of seeded
+    noise.  Its result is src * a + dst * (1 - a) with the products rounded on their own, bit for bit, and a discarded fragment leaves the buffer
+    untouched (checked when the vectors were made: profiles/round5/mesa_pin.txt section 14) -- which is what atmo_render_composite computes.  Here: the
+    oracle's frame pushed through that equation against Mesa's blended frame."""
+    from make_mesa_vectors import COMPOSITE, composite_scene
+    params, model = _scene("demo")
+    scene = composite_scene()
+    for pose, shader in COMPOSITE:
+        cam = RS.camera_from_fixture(vm, RS.W, RS.H, pose)
+        src, _ = oracle32.render(params, dict(textures, optical_depth=vm["lut_demo"]), RS.VARIANTS[shader], make_frame(cam, model, S.DEMO_SUN_POSITION, 0.0),
+                                 vm[f"depth_demo_{pose}"], nthreads=4)
+        disc = np.unpackbits(mesa[f"discard_demo_{pose}_{shader}"])[:RS.W * RS.H].reshape(RS.H, RS.W).astype(bool)
+        a = src[..., 3:4]
+        got = np.concatenate([src[..., :3] * a + scene[..., :3] * (np.float32(1.0) - a), a + scene[..., 3:] * (np.float32(1.0) - a)], axis=-1).astype(np.float32)
+        got[disc] = scene[disc]
+        want = mesa[f"composite_{pose}_{shader}"]
+        assert np.array_equal(want[disc], scene[disc])
+        e = np.abs(got - want)
+        assert e.max() <= (1e-2 if _cloudy(shader) else 2e-5) and np.mean(e > 1e-4) <= CLOUD_SHARE_BEYOND_1E4, (pose, shader, e.max())
+
+
 # whole frames, compactly: per 16 x 16 block the mean of every channel and the number of kept fragments of the frame llvmpipe drew -- EVERY pixel of the frame
 # under test enters the comparison.  Bars: the largest block-mean deviation of the CPU oracle from Mesa, measured when the vectors were made, with headroom.
 BLOCKS = [("planet_atmosphere_no_clouds", 1920, 1080, "lod0", 2e-6),            # measured 5.1e-7
@@ -426,3 +448,25 @@ def test_hip_headline_kernel_against_mesa(vm, mesa):
     err = float(np.abs(mean - mesa["direct32x8_blockmean"]).max())
     print(f"\nheadline kernel <4, 8, 1>: max |HIP - Mesa| = {worst:.3e} (5 poses + 2 rows at 1920x1080); whole 1920x1080 frame, 8160 block means: {err:.2e}")
     assert worst <= 1e-4 and err <= 2e-5   # the kernel's own distance to the oracle is 1.6e-5 (regrouped sums, hardware exp2): TOL, not the oracle's bar
+
+
+@pytest.mark.gpu
+def test_hip_blend_stage_against_mesa(vm, mesa, textures):
+    """atmo_render_composite (the draw with the blend stage) against llvmpipe's fixed-function blender over the same scene colours."""
+    import torch
+    from make_mesa_vectors import COMPOSITE, composite_scene
+    params, model = _scene("demo")
+    scene = composite_scene()
+    for pose, shader in COMPOSITE:
+        node = make_node(NODE_CONFIG[shader], textures, params, sampler="lod0") if _cloudy(shader) else make_node(NODE_CONFIG[shader], textures, params)
+        cam = RS.camera_from_fixture(vm, RS.W, RS.H, pose)
+        buf = torch.from_numpy(scene.copy()).cuda()
+        node.render_composite(cam, torch.from_numpy(np.ascontiguousarray(vm[f"depth_demo_{pose}"])).cuda(), buf)
+        torch.cuda.synchronize()
+        node.close()
+        got, want = buf.cpu().numpy(), mesa[f"composite_{pose}_{shader}"]
+        disc = np.unpackbits(mesa[f"discard_demo_{pose}_{shader}"])[:RS.W * RS.H].reshape(RS.H, RS.W).astype(bool)
+        assert np.array_equal(got[disc], scene[disc])          # discarded fragments: the scene, bit for bit, in both
+        e = np.abs(got - want)
+        print(f"\nblend stage {pose} {shader}: max |HIP - Mesa| = {e.max():.3e}")
+        assert e.max() <= (1e-2 if _cloudy(shader) else 2e-5) and np.mean(e > 1e-4) <= CLOUD_SHARE_BEYOND_1E4
