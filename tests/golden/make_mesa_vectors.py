@@ -324,7 +324,7 @@ def main_headline():
     print(f"\n# wrote {os.path.relpath(path, ROOT)}: {os.path.getsize(path)} bytes, {len(out)} arrays")
 
 
-def fuzz_report():
+def fuzz_report(store=True):
     """Section 10 of the report: the 24 random scenes of reference_exec_fuzz.npz (other planet scales, moved and rotated planets, cameras inside the
     layer, cube sizes 17 .. 128, shape volumes 24 .. 64, scenes without a cubemap) on Mesa against the interpreter's committed vectors.  No new vectors:
     the interpreter's are what the oracle and the HIP path are held to (tests/test_reference_exec.py)."""
@@ -333,6 +333,7 @@ def fuzz_report():
     fz = np.load(os.path.join(HERE, "reference_exec_fuzz.npz"))
     print("\n## 10. the 24 random scenes of reference_exec_fuzz.npz, 40 x 24, level-0 sampler: Mesa against the interpreter's vectors")
     worst = {}
+    fout = {"mesa_info": np.array(M.info()), "gallivm_perf": np.array(os.environ["GALLIVM_PERF"])}
     for k in range(RS.FUZZ_SEEDS):
         params = {kk: (tuple(v) if isinstance(v, list) else v) for kk, v in json.loads(str(fz[f"params_{k}"])).items()}
         _, cam_args, _, _, _ = RS.random_scene(k)
@@ -347,6 +348,7 @@ def fuzz_report():
         for shader in RS.fuzz_variants(k):
             rgba, disc, vary = M.run_frame(shader, None, params, np.linalg.inv(model), model, cam, depth, mtex, sun=sun)
             want = fz[f"rgba_{k}_{shader}"]
+            fout[f"rgba_{k}_{shader}"] = rgba
             # (this fixture stores no discard mask: a discarded fragment and a kept one that evaluates to (0, 0, 0, 0) are the same pixel in it)
             same_disc = np.array_equal(np.all(rgba == 0.0, axis=-1), np.all(want == 0.0, axis=-1))
             note = "" if same_disc else "   ZERO SETS DIFFER"
@@ -361,6 +363,10 @@ def fuzz_report():
     print(f"   {'variant':18s} scenes   zero + finite sets identical      max      largest share beyond 1e-4")
     for fam, (a, b, n, ok) in worst.items():
         print(f"   {fam:18s} {n:4d}     {ok:4d}                            {a:8.2e}   {100 * b:6.3f} %")
+    if store:   # tests/golden/reference_exec_mesa_fuzz.npz: Mesa's frames of the random scenes (inputs: reference_exec_fuzz.npz)
+        path = os.path.join(HERE, "reference_exec_mesa_fuzz.npz")
+        np.savez_compressed(path, **fout)
+        print(f"   wrote {os.path.relpath(path, ROOT)}: {os.path.getsize(path)} bytes, {len(fout) - 2} frames")
 
 
 if __name__ == "__main__":

@@ -199,6 +199,50 @@ def test_oracle_against_mesa_at_baseline_sizes(oracle32, vm, mesa, case):
     print(f"\n{case}: max |oracle - Mesa| = {worst:.3e} over {want.shape[0] * want.shape[1]} pixels")
 
 
+@pytest.fixture(scope="module")
+def fuzz():
+    return np.load(os.path.join(GOLDEN, "reference_exec_fuzz.npz"))
+
+
+@pytest.fixture(scope="module")
+def mesa_fuzz():
+    return np.load(os.path.join(GOLDEN, "reference_exec_mesa_fuzz.npz"))
+
+
+def _check_fuzz(got, want, shader, what, sens):
+    """The random scenes: other planet scales (R = 1 .. 637), density scales and step lengths -- the fp32 sensitivity of a frame varies by orders of
+    magnitude between them (the v1 model's products reach 1e14; the fp32 oracle is 1e-1 from the fp64 one on seed 17), so the bar is the pixel's own:
+    |x - Mesa| <= 64 x (2e-5 + |fp32 oracle - fp64 oracle|) where the sensitivity is known (CPU), a flat 2e-2 with <= 2.5 % beyond 1e-4 otherwise."""
+    assert np.array_equal(np.all(got == 0.0, axis=-1), np.all(want == 0.0, axis=-1)), what
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin), what
+    e = np.where(fin, np.abs(got - want) / np.maximum(1.0, np.abs(np.where(fin, want, 0.0))), 0.0)
+    if sens is not None:
+        ratio = e.max(-1) / (SENS_BASE + sens)
+        if os.environ.get("MESA_PRINT_RATIO"):
+            print(f"{what}: ratio {ratio.max():.1f} max err {e.max():.2e}")
+        assert ratio.max() <= 64.0, f"{what}: a pixel deviates {ratio.max():.1f} x its own fp32 sensitivity"
+    else:
+        assert e.max() <= 2e-2 and np.mean(e > 1e-4) <= CLOUD_SHARE_BEYOND_1E4, f"{what}: {e.max():.3e}, {100 * np.mean(e > 1e-4):.2f} % beyond 1e-4"
+    return float(e.max())
+
+
+@pytest.mark.parametrize("k", range(RS.FUZZ_SEEDS))
+def test_oracle_against_mesa_random_scenes(oracle32, oracle64, fuzz, mesa_fuzz, k):
+    """The 24 random scenes of reference_exec_fuzz.npz (planets R = 1 .. 637, moved and rotated, cameras inside / outside the layer, cube sizes 17 .. 128,
+    non-power-of-two shape volumes, an unbound cubemap) as Mesa drew them: three shader files per scene."""
+    from test_reference_exec import _fuzz_case
+    params, cam, sun, model, tex, depth = _fuzz_case(fuzz, k)
+    lut = oracle32.bake_optical_depth(params["u_planet_radius"], params["u_atmosphere_height"], params["u_density"])
+    frame = make_frame(cam, model, sun, 0.0)
+    for shader in RS.fuzz_variants(k):
+        got, _ = oracle32.render(params, dict(tex, optical_depth=lut), RS.VARIANTS[shader], frame, depth, nthreads=4)
+        g64, _ = oracle64.render(params, dict(tex, optical_depth=lut), RS.VARIANTS[shader], frame, depth, nthreads=4)
+        with np.errstate(all="ignore"):
+            sens = np.nan_to_num(np.abs(got - g64.astype(np.float32)) / np.maximum(1.0, np.abs(got)), nan=0.0, posinf=0.0).max(-1)
+        _check_fuzz(got, mesa_fuzz[f"rgba_{k}_{shader}"], shader, f"oracle vs Mesa, seed {k} {shader}", sens)
+
+
 DIRECT_BAR = 5e-5   # 32 view steps x (3 exponentials + 8 light samples): measured 2.8e-5 (Mesa against the oracle, 1920x1080, every pixel)
 
 
@@ -470,3 +514,31 @@ def test_hip_blend_stage_against_mesa(vm, mesa, textures):
         e = np.abs(got - want)
         print(f"\nblend stage {pose} {shader}: max |HIP - Mesa| = {e.max():.3e}")
         assert e.max() <= (1e-2 if _cloudy(shader) else 2e-5) and np.mean(e > 1e-4) <= CLOUD_SHARE_BEYOND_1E4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", range(RS.FUZZ_SEEDS))
+def test_hip_against_mesa_random_scenes(fuzz, mesa_fuzz, k):
+    """The product path on the 24 random scenes against the frames Mesa drew from the reference's text."""
+    from godot_atmosphere_shader_amd import PlanetAtmosphere, load_shader
+    from godot_atmosphere_shader_amd.planet_atmosphere import LinearColor, _SOURCE_COLOR
+    from test_reference_exec import _fuzz_case
+
+    params, cam, sun, model, tex, depth = _fuzz_case(fuzz, k)
+    for shader in RS.fuzz_variants(k):
+        node = PlanetAtmosphere(blue_noise=tex["blue_noise"], cubemap_lod=False)  # these vectors: the text executed with the level-0 sampler
+        node.custom_shader = load_shader(shader)
+        node.planet_radius, node.atmosphere_height, node.sun_path = params["u_planet_radius"], params["u_atmosphere_height"], sun
+        for name, v in params.items():
+            if name in ("u_planet_radius", "u_atmosphere_height", "u_cloud_coverage_rotation", "u_world_to_model_matrix"):
+                continue
+            node.set(f"shader_params/{name}", LinearColor(v) if name in _SOURCE_COLOR else v)  # the fixture holds linear colours
+        node.global_transform = model
+        node._process(0.0, cam, time=0.0)
+        node.set_shader_parameter("u_cloud_coverage_rotation", np.asarray(params["u_cloud_coverage_rotation"], dtype=np.float32))
+        node.set_shader_parameter("u_cloud_shape_texture", tex["shape"])
+        if tex["cubemap"] is not None:
+            node.set_shader_parameter("u_cloud_coverage_cubemap", tex["cubemap"])
+        got = _gpu_render(node, cam, depth)
+        node.close()
+        _check_fuzz(got, mesa_fuzz[f"rgba_{k}_{shader}"], shader, f"HIP vs Mesa, seed {k} {shader}", None)
