@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+Both forms work for N > 1: typed WITHOUT a launcher (no WORLD_SIZE in the environment), `python bench.py --gpus N` starts the second
+command itself as a CHILD process -- before this process has imported torch or touched the GPU (self_launch below; never an exec) --
+passes its output through and exits with its code.
+
 A "step" is one pass of the hot path over one synthetic frame: BASELINE.json configs[1],
 `planet_atmosphere_no_clouds` at 1920x1080 with 32 view steps x 8 light steps (direct light mode), demo
 scene, pose P_space, analytic ground-sphere depth buffer, all inputs resident in HBM before the timed
@@ -194,7 +198,8 @@ def compact_record(result, detail_path=None):
     as name -> [Mrays/s, HBM fraction] -- no prose, <= COMPACT_LIMIT bytes whatever --also holds (round 3's full line was 41.7 KB and the
     driver, which keeps the last 8 KB of stdout, could not parse it: BENCH_r03.parsed = null).  The detail goes to write_detail()."""
     rec = {k: _r(result[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "timed_region_ms",
-                                      "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in result}
+                                      "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "ranks", "backend", "shard_mode",
+                                      "gather_mode", "stub") if k in result}
     cfg = result.get("config", {})
     c = _pick(cfg, ("width", "height", "kernel", "hit_fraction", "gather", "shard", "mrays_per_s_feedback_off", "mrays_per_s_no_gather",
                     "mrays_per_s_final_gather", "mrays_per_s_gather_every", "gather_ms_in_timed_region"))
@@ -284,6 +289,13 @@ def parse_args():
     ap.add_argument("--motion", default="", help="orbit:<deg/frame> or pan:<deg/frame>: a new camera pose every step (N = 1); "
                     "all frames and depth buffers are prepared before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N>1: torch.distributed backend; nccl (= RCCL, default) on MI355X.  gloo exists for the CPU test of the launch path "
+                         "(tests/test_host_logic.py) and is accepted only together with --stub-renderer")
+    ap.add_argument("--stub-renderer", action="store_true",
+                    help="TEST SWITCH, N>1 only: no kernel, no GPU -- every 'frame' is a torch fill on the CPU, so that self_launch, the rendezvous, "
+                         "the barrier/max-over-ranks timing and the gathers can be run where there is no MI355X.  The line it prints says "
+                         "\"stub\": true and data \"stub\"; its `value` is not a measurement of anything")
     ap.add_argument("--band-cost", default="measured", choices=["measured", "analytic"],
                     help="--shard bands: cut the viewport by MEASURED per-row costs (rank 0 draws the frame once through "
                          "atmo_measure_tile_costs and broadcasts the cuts; default) or by the analytic estimate cloud_row_cost")
@@ -814,8 +826,73 @@ def bench_two_viewports(torch, S, name, w, h, steps, warmup, textures, params, l
             "Mrays/s": 2 * w * h * steps / dt / 1e6, "ms_per_pair": dt / steps * 1e3, "steps": steps}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` typed as is (N > 1, no launcher: WORLD_SIZE unset): start
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py <same arguments>
+    as a CHILD process, pass its stdout through line by line (rank 0's JSON record stays the last line), and exit with its code.  Called
+    before torch is imported: this process never touches the GPU, and nothing is ever exec'ed (a process that has initialised HIP must not
+    replace itself; the N ranks are fresh interpreters).  Returns when there is nothing to launch."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = str(sock.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: no launcher in the environment, starting " + " ".join(cmd), file=sys.stderr, flush=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))  # dmabuf IPC: RCCL needs it on this pool
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=1, env=env)
+    try:
+        for line in proc.stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        rc = proc.wait()
+    except BaseException:
+        proc.terminate()   # the exact child this process started, never a pattern
+        proc.wait()
+        raise
+    raise SystemExit(rc)
+
+
+class StubNode:
+    """--stub-renderer (test switch): stands where the PlanetAtmosphere node stands in the N > 1 paths of main(); draws nothing."""
+    kernel_name = "none (--stub-renderer)"
+
+    def __init__(self, rank):
+        self.rank = rank
+        self.draws = 0
+
+    def prepare_frame(self, cam, rect=None):
+        from types import SimpleNamespace
+        x0, y0, x1, y1 = rect if rect is not None else (0, 0, cam.width, cam.height)
+        return SimpleNamespace(x0=x0, y0=y0, x1=x1, y1=y1)
+
+    def draw(self, buf):
+        self.draws += 1
+        buf.fill_(float(self.rank + 1))
+
+    def set_timing(self, on, every=1):
+        pass
+
+    def get_timing(self):
+        return 0, 0.0
+
+    def close(self):
+        pass
+
+
 def main():
     args = parse_args()
+    if args.stub_renderer and args.gpus < 2:
+        raise SystemExit("--stub-renderer tests the N > 1 launch path: give --gpus 2 or more")
+    if (args.backend == "gloo") != bool(args.stub_renderer):
+        raise SystemExit("--backend gloo and --stub-renderer go together (a test of the launch path on a host without a GPU); the product path is RCCL")
+    self_launch(args)
     if args.gather is None:
         args.gather = "every" if args.shard == "bands" else "final"
     if args.gather == "none-then-final":
@@ -833,15 +910,28 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    stub = bool(args.stub_renderer)
+    if not stub:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"--gpus {args.gpus}: rank {rank} has no GPU (this node shows {torch.cuda.device_count()})")
+        torch.cuda.set_device(local_rank)
     dist = None
     force_dist = os.environ.get("ATMO_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path with a 1-rank group
     if world > 1 or force_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     multi = world > 1 or force_dist
+    if stub and (args.shard == "tiles" or not multi):
+        raise SystemExit("--stub-renderer covers --shard viewports and --shard bands at N > 1")
+
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
 
     w, h = args.width, args.height
     config_name, desc = WORKLOADS[args.workload]
@@ -853,14 +943,15 @@ def main():
     pose = args.pose if (world == 1 or rank == 0 or strong) else S.orbit_pose(rank, world)
     cam = S.Camera.from_pose(w, h, pose)
     depth_np = S.depth_ground_sphere(cam)
-    depth = torch.from_numpy(depth_np).cuda()
+    device = torch.device("cpu") if stub else torch.device("cuda", local_rank)
+    depth = torch.from_numpy(depth_np).to(device)
     cloudy = bool(__import__("godot_atmosphere_shader_amd.demo", fromlist=["CONFIGS"]).CONFIGS[config_name][1].get("cloud_steps"))
     lod0 = args.sampler == "lod0" and cloudy
     explicit = os.environ.get("ATMO_BENCH_EXPLICIT_SAMPLER") == "1"   # tools/ab_bench.sh against libraries built before round 4
-    node = make_node(config_name, textures, params, device=local_rank,
-                     **dict(node_kwargs(args.workload), **(dict(cubemap_lod=False) if lod0 else (dict(cubemap_lod=cloudy) if explicit else {}))))
+    node = StubNode(rank) if stub else make_node(
+        config_name, textures, params, device=local_rank,
+        **dict(node_kwargs(args.workload), **(dict(cubemap_lod=False) if lod0 else (dict(cubemap_lod=cloudy) if explicit else {}))))
     rays = w * h
-    device = torch.device("cuda", local_rank)
 
     # ---- timed region ---------------------------------------------------------------------------------
     bands = None
@@ -884,30 +975,33 @@ def main():
             # cost (atmo_measure_tile_costs), sums per pixel row, cuts, and broadcasts the cuts (every rank must use the same);
             # analytic (--band-cost analytic): shell hits per row, cloud-shell hits weighted (cloud_row_cost).
             from godot_atmosphere_shader_amd.sharding import balanced_row_bands, band_rect
-            if args.band_cost == "measured":
+            if args.band_cost == "measured" and not stub:
                 bands = cut_bands_measured(torch, dist, device, world, rank, lambda: node.measure_row_costs(cam, depth))
             else:
                 bands = balanced_row_bands(cloud_row_cost(np, S, cam, "cloud" in config_name), world)
             frame = node.prepare_frame(cam, rect=band_rect(w, bands[rank]))
         else:
             frame = node.prepare_frame(cam)
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = 0 if stub else torch.cuda.current_stream().cuda_stream
 
         def render_into(buf):
             if buf.numel():
-                node.render_prepared(frame, depth.data_ptr(), buf.data_ptr(), stream)
+                if stub:
+                    node.draw(buf)
+                else:
+                    node.render_prepared(frame, depth.data_ptr(), buf.data_ptr(), stream)
 
         # untimed, before the W warm-up steps of the timed loop: frame-paced draws so the tile order settles, then ~25 ms
         # of work so the GPU is at its sustained clocks (see time_workload)
         prime = torch.empty((max(1, frame.y1 - frame.y0), max(1, frame.x1 - frame.x0), 4), dtype=torch.float32, device=device)
         for _ in range(4):
             render_into(prime)
-            torch.cuda.synchronize()
+            sync()
         t_warm = time.perf_counter()
         while time.perf_counter() - t_warm < 0.025:
             for _ in range(8):
                 render_into(prime)
-            torch.cuda.synchronize()
+            sync()
         del prime
         node_timing = (lambda: node.set_timing(True, every=TIMING_EVERY), node.get_timing)
         dt_max, launches, kernel_ms = timed_loop_distributed(
@@ -941,10 +1035,13 @@ def main():
         pmc = None if (strong or args.pose != "P_space" or motion is not None) else pmc_summary(args.workload + ("@lod0" if lod0 else ""), w, h)
         kernel_avg_ms = kernel_ms / launches if launches else 0.0
         launch_rays = rays if not strong else w * (bands[0][1] - bands[0][0])  # rank 0's kernel shades its band only
-        frame_img = node.render(cam, depth)
-        torch.cuda.synchronize()
-        hit_fraction = float((frame_img.abs().sum(dim=-1) > 0).float().mean().item())
-        del frame_img
+        if stub:
+            pmc, hit_fraction = None, 0.0
+        else:
+            frame_img = node.render(cam, depth)
+            torch.cuda.synchronize()
+            hit_fraction = float((frame_img.abs().sum(dim=-1) > 0).float().mean().item())
+            del frame_img
         result = {
             "metric": f"Mrays/s, {args.workload} at {w}x{h}" + ("; 32 view x 8 light steps" if args.workload == "direct32x8" else "")
                       + "; % HBM roofline" + (f"; gather {args.gather}" if multi else ""),
@@ -959,9 +1056,16 @@ def main():
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "stub" if stub else "synthetic",
+            "stub": stub,
+            # what ran: the process group's rank count and backend (nccl = RCCL), how frames were sharded and gathered (short forms; the prose is in config)
+            "ranks": dist.get_world_size() if dist is not None else 1,
+            "backend": dist.get_backend() if dist is not None else None,
+            "shard_mode": args.shard if multi else None,
+            "gather_mode": args.gather if multi else None,
             "config": {
-                "workload": f"{desc}{workload_suffix(config_name, 'lod0' if lod0 else None)}; {w}x{h}; demo scene, pose {args.pose}"
+                "workload": ("STUB RENDERER, no kernel ran (test of the launch path): " if stub else "")
+                            + f"{desc}{workload_suffix(config_name, 'lod0' if lod0 else None)}; {w}x{h}; demo scene, pose {args.pose}"
                             + ("" if world == 1 or strong else f" on rank 0, orbit poses on ranks 1..{world - 1}; one viewport per GPU"),
                 "width": w, "height": h, "rays_per_step_per_gpu": rays if not strong else None,
                 "hit_fraction": hit_fraction,
@@ -1031,7 +1135,7 @@ def main():
         result["extra"] = extra
     if multi and not strong and args.workload == "direct32x8" and os.environ.get("ATMO_BENCH_NO_CONFIG4") != "1":
         # BASELINE.json configs[4]: independent 3840x2160 clouds_high_rm viewports, one per GPU, gathered to rank 0 over xGMI
-        c4 = bench_config4(torch, dist, S, textures, params, local_rank, rank, world, max(5, args.steps // 8), 2)
+        c4 = bench_config4(torch, dist, S, textures, params, local_rank, rank, world, max(5, args.steps // 8), 2, stub=stub)
         if rank == 0:
             result.setdefault("extra", {})["config4_clouds_high_rm_3840x2160"] = c4
 
@@ -1141,6 +1245,7 @@ def main_tile_strips(args, torch, dist, S, textures, params, config_name, desc, 
             "metric": f"Mrays/s, {args.workload} at {w}x{h}; % HBM roofline; one viewport in tile strips over {world} GPUs, gather every",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "timed_region_ms": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ranks": dist.get_world_size(), "backend": dist.get_backend(), "shard_mode": "tiles", "gather_mode": "every",
             "config": {"workload": f"{desc}{workload_suffix(config_name, 'lod0' if lod0 else None)}; {w}x{h}; demo scene, pose {args.pose}",
                        "width": w, "height": h, "kernel": node.kernel_name, "gather": "strips of every frame gathered into the frame on rank 0, inside the timed region",
                        "shard": f"{len(strips[0]) and sum(len(s) for s in strips)} strips of {STRIP_TILE_ROWS * th} rows dealt LPT by measured cost: "
@@ -1159,28 +1264,32 @@ def main_tile_strips(args, torch, dist, S, textures, params, config_name, desc, 
     return result
 
 
-def bench_config4(torch, dist, S, textures, params, local_rank, rank, world, steps, warmup):
+def bench_config4(torch, dist, S, textures, params, local_rank, rank, world, steps, warmup, stub=False):
     """BASELINE.json configs[4]: `world` independent 3840x2160 planet_atmosphere_clouds_high_rm viewports (orbit poses), one
     per GPU; weak scaling, three rates: one final gather of every rank's last frame to rank 0 inside the timed region (north_star), every
     frame gathered to rank 0 (132.7 MB per rank per frame over xGMI), and no collective."""
     from godot_atmosphere_shader_amd.demo import make_node
 
-    w, h = 3840, 2160
+    w, h = (3840, 2160) if not stub else (96, 54)   # the stub (CPU test of the launch path) keeps the shape of the loop, not the size
     pose = "P_space" if rank == 0 else S.orbit_pose(rank, world)
     cam = S.Camera.from_pose(w, h, pose)
-    depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
-    node = make_node("clouds_high_rm", textures, params, device=local_rank)
+    device = torch.device("cpu") if stub else torch.device("cuda", local_rank)
+    depth = torch.from_numpy(S.depth_ground_sphere(cam)).to(device)
+    node = StubNode(rank) if stub else make_node("clouds_high_rm", textures, params, device=local_rank)
     frame = node.prepare_frame(cam)
-    stream = torch.cuda.current_stream().cuda_stream
-    device = torch.device("cuda", local_rank)
+    stream = 0 if stub else torch.cuda.current_stream().cuda_stream
 
     def render_into(buf):
-        node.render_prepared(frame, depth.data_ptr(), buf.data_ptr(), stream)
+        if stub:
+            node.draw(buf)
+        else:
+            node.render_prepared(frame, depth.data_ptr(), buf.data_ptr(), stream)
 
     prime = torch.empty((h, w, 4), dtype=torch.float32, device=device)
     for _ in range(6):  # frame-paced, untimed: lets the heaviest-first tile order settle (see time_workload)
         render_into(prime)
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
     del prime
     out = {}
     for mode in ("final", "every", "none"):
@@ -1190,7 +1299,7 @@ def bench_config4(torch, dist, S, textures, params, local_rank, rank, world, ste
         out[{"final": "Mrays/s_final_gather", "every": "Mrays/s_gather_every_frame", "none": "Mrays/s_no_gather"}[mode]] = world * w * h * steps / dt / 1e6
         out["ms_per_step_" + mode] = dt / steps * 1e3
         out["kernel_avg_ms_rank0"] = kernel_ms / launches if launches else None
-    out.update(workload=f"planet_atmosphere_clouds_high_rm, 3840x2160, one viewport per GPU x {world}", steps=steps, n_gpus=world,
+    out.update(workload=("STUB RENDERER: " if stub else "") + f"planet_atmosphere_clouds_high_rm, {w}x{h}, one viewport per GPU x {world}", steps=steps, n_gpus=world,
                kernel=node.kernel_name, scaling="weak")
     node.close()
     return out

@@ -433,6 +433,65 @@ def test_bench_detail_file(tmp_path, monkeypatch):
     assert bench.write_detail({"a": 1}) is None
 
 
+def _run_bench_as_typed(tmp_path, *argv):
+    """`python bench.py <argv>` exactly as a driver would type it: no launcher, no WORLD_SIZE / RANK in the environment."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "TORCHELASTIC_RUN_ID", "GROUP_RANK", "LOCAL_WORLD_SIZE")}
+    env["ATMO_BENCH_DETAIL"] = str(tmp_path / "detail.json")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    return p, (json.loads(lines[-1]) if lines and lines[-1].lstrip().startswith("{") else None)
+
+
+def test_bench_gpus_n_launches_its_own_ranks(tmp_path):
+    """`python3 bench.py --gpus N` typed WITHOUT torch.distributed.run used to exit with a message for N > 1, so the first
+    8-GPU node would have produced no scaling curve.  Now it starts the N ranks itself as a child process (bench.self_launch; before torch is
+    imported, never an exec).  Run here on CPU through the test switch --backend gloo --stub-renderer (no kernel, frames are torch fills): two
+    ranks rendezvous on 127.0.0.1, run the barrier / max-over-ranks timed loop with the final gather, the configs[4]-shaped loop after it,
+    and rank 0's JSON record is the LAST stdout line of the command the user typed -- saying what ran (ranks, backend, gather mode) and that
+    it was the stub."""
+    p, rec = _run_bench_as_typed(tmp_path, "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--stub-renderer",
+                                 "--width", "64", "--height", "36")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert rec is not None, p.stdout[-2000:]
+    assert rec["n_gpus"] == 2 and rec["ranks"] == 2 and rec["backend"] == "gloo" and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["gather_mode"] == "final" and rec["shard_mode"] == "viewports" and rec["scaling"] == "weak"
+    assert rec["stub"] is True and rec["data"] == "stub" and "STUB" in rec["config"]["workload"]
+    assert rec["value"] > 0 and rec["ms_per_step"] > 0 and rec["value"] == pytest.approx(2 * 64 * 36 * 3 / (rec["timed_region_ms"] * 1e-3) / 1e6, rel=1e-3)
+    assert rec["config"]["mrays_per_s_no_gather"] > 0 and rec["config"]["mrays_per_s_gather_every"] > 0
+    assert set(rec["extra"]["config4_clouds_high_rm_3840x2160"]) == {"Mrays/s_final_gather", "Mrays/s_gather_every_frame", "Mrays/s_no_gather"}
+    assert "torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1" in p.stderr   # it says what it started
+    # one frame in row bands, gathered every frame (strong scaling): same launch path
+    p, rec = _run_bench_as_typed(tmp_path, "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--stub-renderer",
+                                 "--width", "64", "--height", "36", "--shard", "bands")
+    assert p.returncode == 0 and rec["ranks"] == 2 and rec["scaling"] == "strong" and rec["gather_mode"] == "every" and rec["shard_mode"] == "bands"
+
+
+def test_bench_launch_errors_are_loud(tmp_path):
+    """The child's exit code is the command's exit code; the test switches cannot reach the product path."""
+    import bench
+
+    p, rec = _run_bench_as_typed(tmp_path, "--gpus", "2", "--backend", "gloo")           # gloo without the stub: refused before anything starts
+    assert p.returncode != 0 and rec is None and "--stub-renderer" in p.stderr
+    p, rec = _run_bench_as_typed(tmp_path, "--gpus", "1", "--stub-renderer", "--backend", "gloo")
+    assert p.returncode != 0 and rec is None
+    if not _has_gpu():
+        # the real N > 1 command on a host without GPUs: every rank fails loudly, the launcher's code comes back, no JSON line
+        p, rec = _run_bench_as_typed(tmp_path, "--gpus", "2", "--steps", "1", "--warmup", "0")
+        assert p.returncode != 0 and rec is None and "needs an MI355X" in p.stderr
+    # under a launcher (WORLD_SIZE set) nothing is launched again
+    os.environ["WORLD_SIZE"] = "2"
+    try:
+        assert bench.self_launch(type("A", (), {"gpus": 2})()) is None
+    finally:
+        del os.environ["WORLD_SIZE"]
+    assert bench.self_launch(type("A", (), {"gpus": 1})()) is None
+
+
 def test_whole_quad_exchange_registers_are_private():
     """The declared-sampler kernels read their quad partners' cube coordinates from the partner LANES inside inline-asm blocks that run in
     whole-quad mode (s_wqm_b64): lanes the compiler believes inactive write the blocks' registers.  tools/check_quad_regs.py compiles the
