@@ -21,14 +21,14 @@ ABI_VERSION = 4
 CORE_SYMBOLS = (
     "atmo_abi_version", "atmo_device_count", "atmo_create", "atmo_destroy", "atmo_set_param_f32", "atmo_get_param_f32",
     "atmo_set_texture", "atmo_get_texture_size", "atmo_set_sampler_lod", "atmo_bake_optical_depth",
-    "atmo_generate_noise_cubemap", "atmo_read_optical_depth", "atmo_render", "atmo_render_composite", "atmo_render_tiles", "atmo_measure_tile_costs", "atmo_set_precision",
+    "atmo_generate_noise_cubemap", "atmo_read_optical_depth", "atmo_render", "atmo_render_composite", "atmo_render_tiles", "atmo_render_tiles_split", "atmo_measure_tile_costs", "atmo_set_precision",
     "atmo_set_host_double_precision", "atmo_set_target_cleared", "atmo_set_tile_feedback", "atmo_last_error_string",
 )
 # every symbol include/atmo_debug.h declares: experiment knobs and diagnostics (tests, bench.py, tools/)
 DEBUG_SYMBOLS = (
     "atmo_set_lane_split", "atmo_debug_motion_px", "atmo_get_feedback_stats", "atmo_set_timing", "atmo_get_timing", "atmo_host_layout_cubemap", "atmo_host_layout_shape",
-    "atmo_host_layout_lut", "atmo_host_cubemap_mip", "atmo_read_texture_layout", "atmo_selftest_exact_math", "atmo_debug_marched_optical_depth", "atmo_kernel_name",
-    "atmo_get_host_wait_stats", "atmo_get_split_stats", "atmo_render_tiles_split", "atmo_debug_create_host_only", "atmo_debug_frame_constants",
+    "atmo_host_layout_lut", "atmo_host_cubemap_mip", "atmo_read_texture_layout", "atmo_selftest_exact_math", "atmo_debug_marched_optical_depth", "atmo_debug_log2_cr", "atmo_kernel_name",
+    "atmo_get_host_wait_stats", "atmo_get_split_stats", "atmo_debug_create_host_only", "atmo_debug_frame_constants",
 )
 EXPORTED_SYMBOLS = CORE_SYMBOLS + DEBUG_SYMBOLS
 
@@ -106,6 +106,7 @@ def load() -> C.CDLL:
         "atmo_get_timing": (ip, [vp, C.POINTER(ip), C.POINTER(C.c_double)]),
         "atmo_selftest_exact_math": (ip, [vp, C.c_uint32, C.c_uint32, C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
         "atmo_debug_marched_optical_depth": (ip, [vp, ip, vp, vp, ip, vp]),
+        "atmo_debug_log2_cr": (ip, [vp, ip, vp, vp]),
         "atmo_host_layout_cubemap": (ip, [vp, ip, vp]),
         "atmo_host_layout_shape": (ip, [vp, ip, vp]),
         "atmo_host_layout_lut": (ip, [vp, ip, ip, vp]),

@@ -1540,6 +1540,13 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         rc.wave_trace = (unsigned long long *)ctx->wave_trace.ptr;
     }
 #endif
+    if (tiles_dev) {   // (before anything is created or enqueued for this draw)
+        // the bounded copy of the list lives in a context-owned buffer that a later, longer list frees and reallocates -- a graph that had
+        // recorded this draw would replay on freed memory (and an allocation fails inside a global-mode capture anyway): refused, stated in atmo.h
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+            return fail(ctx, ATMO_E_STATE, "tile-list draws cannot be captured into a HIP graph (context-owned list buffer); capture atmo_render instead");
+    }
     const bool timed = ctx->timing > 0 && (ctx->launch_counter % ctx->timing) == 0;
     if (timed) {
         if (ctx->pending.size() >= 64) drain_timing(ctx, /*only_completed=*/true);  // a long loop with timing left on stays bounded
@@ -1605,6 +1612,7 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         { const int rc0 = order_after_stream(ctx, ctx->split_stream, s); if (rc0 != ATMO_OK) return rc0; }   // fork: behind everything the draw is behind
         atmo::RenderConsts rc2 = rc;
         rc2.tile_order = order2;                       // two half-height tiles per heavy tile, heaviest first
+        rc2.cost_rows_halved = 1;                      // ... whose costs belong to the one-lane grid's tile (only this launch: ADVICE r5)
         HIP_TRY(ctx, atmo::launch_render(flags, 2, rc2, ctx->split_stream, 2 * heavy));
         if (total_tiles - heavy > 0) {
             rc.tile_order += heavy;                    // the rest of the order, one lane per ray
@@ -1633,6 +1641,7 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         ctx->fb_sorts += 1;
     }
     if (fb) fb->n += 1;
+    hipEvent_t marker = nullptr;   // the draw stream's marker, when this draw recorded one (re-recorded behind the in-stream sort below)
     {   // remember the stream and put its marker behind this draw
         AtmoContext::DrawStream *ds = nullptr;
         for (AtmoContext::DrawStream &d : ctx->draw_streams) if (d.stream == s) ds = &d;
@@ -1661,6 +1670,7 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
                 if (!ds->last_draw) HIP_TRY(ctx, hipEventCreateWithFlags(&ds->last_draw, hipEventDisableTiming));
                 HIP_TRY(ctx, hipEventRecord(ds->last_draw, s));
                 ds->recorded = true;
+                marker = ds->last_draw;
             }
         }
     }
@@ -1678,6 +1688,10 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         fb->is_last_n = fb->n - 1;
         fb->last_record = fb->n - 1;
         ctx->fb_sorts += 1;
+        // that sort reads and writes the feedback state (cost, is_order, dil[], class_totals) on this stream BEHIND the marker recorded above,
+        // and whoever takes the state over (feedback_quiesce, order_after_draws_on: a recycled slot, a key handed to another stream) waits for the
+        // marker only -- so the marker goes behind the sort (the stream handle is alive: we are inside the caller's draw call)
+        if (marker) HIP_TRY(ctx, hipEventRecord(marker, s));
     }
     return ATMO_OK;
 }
@@ -1797,6 +1811,20 @@ int atmo_debug_marched_optical_depth(AtmoContext *ctx, int n, const float *pos_x
     if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return hip_fail(ctx, e, "atmo_debug_marched_optical_depth");
+    return ATMO_OK;
+}
+
+int atmo_debug_log2_cr(AtmoContext *ctx, int n, const float *x, float *out) {
+    if (!ctx) return ATMO_E_ARG;
+    if (n < 1 || !x || !out) return fail(ctx, ATMO_E_ARG, "atmo_debug_log2_cr: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *d = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d, 2 * (size_t)n * sizeof(float)));
+    hipError_t e = hipMemcpy(d, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = atmo::launch_log2_cr(d, d + n, n, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out, d + n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return hip_fail(ctx, e, "atmo_debug_log2_cr");
     return ATMO_OK;
 }
 

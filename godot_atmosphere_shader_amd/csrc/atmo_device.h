@@ -88,6 +88,7 @@ struct RenderConsts {
     float miss_k;                   // [host] (|c|^2 - R_atm^2) (1 - 1e-3)^2 when the test is usable, else 0
     int32_t gx0, gy0;               // [host] viewport pixel of the launch grid's first tile: (x0, y0), rounded down to even for the declared-sampler kernels
     int32_t store_discards;         // 1: a discarded fragment stores (0,0,0,0); 0: it stores nothing (composite, or atmo_set_target_cleared)
+    int32_t cost_rows_halved;       // 1: this launch draws HEAVY tiles of a one-lane grid as pairs of half-height tiles (render_impl's split path): tile_cost is indexed by the one-lane tile
 };
 
 struct BakeConsts {
@@ -128,6 +129,7 @@ void render_grid(const RenderConsts &rc, int split, int *tiles_x, int *tiles_y);
 void render_tile_size(int split, int *tile_w, int *tile_h);  // pixels per workgroup tile of a launch with `split` lanes per ray
 hipError_t launch_noise_cubemap(const NoiseCubemapConsts &nc, hipStream_t stream);
 const char *render_kernel_name(int flags, int light_steps, int split);
+hipError_t launch_log2_cr(const float *x_dev, float *out_dev, int n, hipStream_t stream);
 hipError_t launch_light_probe(const float *pos, const float *dir, int n, float planet_radius, float atmosphere_height, float density,
                               int light_steps, float *out, hipStream_t stream);
 hipError_t launch_selftest(uint32_t first_bits, uint32_t count, float c, float rc, unsigned int *mismatch_dev, hipStream_t stream);

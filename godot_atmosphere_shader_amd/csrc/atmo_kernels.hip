@@ -55,6 +55,16 @@ constexpr float LOG2E = 1.44269504088896340736f;
 // ---- hardware transcendental units (approximate, ~1 ulp) ---------------------------------------
 __device__ __forceinline__ float hw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float hw_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+// The declared sampler's lambda in the oracle's own operations (round 6; cube_lod_partner_coords, cube_lod_select).  0: rounds 2-5's arithmetic, the A/B arm.
+#ifndef ATMO_LOD_LAMBDA_EXACT
+#define ATMO_LOD_LAMBDA_EXACT 1
+#endif
+#ifndef ATMO_RCP_NR   // Newton steps of exact_rcp (1: checked on every significand by atmo_selftest_exact_math)
+#define ATMO_RCP_NR 1
+#endif
+#ifndef ATMO_LOD_LOG2_CR
+#define ATMO_LOD_LOG2_CR 1
+#endif
 __device__ __forceinline__ float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float hw_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float sat(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
@@ -66,6 +76,15 @@ __device__ __forceinline__ float mixf(float a, float b, float t) { return a * (1
 // __fsqrt_rn to the native (1 ulp) square root.  Used in the once-per-pixel prologue and the LUT bake.
 __device__ __forceinline__ float ieee_sqrt(float x) { return __builtin_sqrtf(x); }
 __device__ __forceinline__ float ieee_div(float a, float b) { return a / b; }
+// RN(1 / d) from v_rcp_f32 (1 ulp) and ATMO_RCP_NR Newton step(s): 3 instructions against the ~11 of the compiler's IEEE division (v_div_scale /
+// v_div_fmas / v_div_fixup).  Equal to 1.0f / d for every normal d whose reciprocal is normal: checked on the device over all 2^23 significands of
+// fifty binades (atmo_selftest_exact_math, the divide counter; v_rcp_f32's error depends on the significand alone).
+__device__ __forceinline__ float exact_rcp(float d) {
+    float r = hw_rcp(d);
+#pragma unroll
+    for (int k = 0; k < ATMO_RCP_NR; ++k) r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    return r;
+}
 
 // Correctly rounded sqrt for the per-step cloud chain, x >= 0 and not denormal/inf/nan (x = |pos|^2 ~ 1e4):
 // the hardware root is within 1 ulp, so the result is s-1ulp, s or s+1ulp; the sign of the exact FMA
@@ -174,6 +193,7 @@ __device__ __forceinline__ float swap_ray_lanes(float x) { return ACROSS_QUADS ?
 // products and sums that must NOT be contracted where the caller's block allows it (`#pragma clang fp contract` is lexical)
 __device__ __forceinline__ float mul_unfused(float a, float b) { return a * b; }
 __device__ __forceinline__ float add_unfused(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub_unfused(float a, float b) { return a - b; }
 
 // ---- exact (IEEE, unfused) helpers: must match a scalar fp32 evaluation bit for bit -------------
 struct V3 {
@@ -334,10 +354,24 @@ template <bool PRECISE>
 __device__ __forceinline__ float shape_sample(const uint32_t *__restrict__ fp, int n, int log2n, float px, float py, float pz, const float *__restrict__ f4 = nullptr) {
 #pragma clang fp contract(fast)
     const float nf = (float)n;
-    const float x = px * nf - 0.5f, y = py * nf - 0.5f, z = pz * nf - 0.5f;
-    const float xf = floorf(x), yf = floorf(y), zf = floorf(z);
-    const float fx = x - xf, fy = y - yf, fz = z - zf;
-    const ShapeAddr ad = shape_addr(n, log2n, (int)xf, (int)yf, (int)zf);
+    float fx, fy, fz;
+    ShapeAddr ad;
+    if (log2n >= 0) {   // ONE wave-uniform branch for coordinates and addresses alike (two on the same condition cost the declared-sampler kernels 1-2 %)
+        const float x = px * nf - 0.5f, y = py * nf - 0.5f, z = pz * nf - 0.5f;   // contracted: fma(p, n, -0.5) -- p * n is exact for a power of two
+        const float xf = floorf(x), yf = floorf(y), zf = floorf(z);
+        fx = x - xf; fy = y - yf; fz = z - zf;
+        ad = shape_addr(n, log2n, (int)xf, (int)yf, (int)zf);
+    } else {
+        // The reference rounds p * n before it subtracts (a scalar fp32 evaluation of `uvw * size - 0.5`).  For a power-of-two n the product is
+        // exact and an FMA returns the same bits; for any other size (24, 48 ...) it does not, and an ulp of the filter weight is what a
+        // hypersensitive cloud pixel amplifies to 1e-4 (round 6: seeds 442 / 658 / 890 of the 1 212-scene fuzz, all three with a 24^3 volume;
+        // profiles/round6/fuzz_four.txt).  The fast cloud mode keeps its FMAs.
+        const float x = PRECISE ? sub_unfused(mul_unfused(px, nf), 0.5f) : px * nf - 0.5f, y = PRECISE ? sub_unfused(mul_unfused(py, nf), 0.5f) : py * nf - 0.5f,
+                    z = PRECISE ? sub_unfused(mul_unfused(pz, nf), 0.5f) : pz * nf - 0.5f;
+        const float xf = floorf(x), yf = floorf(y), zf = floorf(z);
+        fx = x - xf; fy = y - yf; fz = z - zf;
+        ad = shape_addr(n, -1, (int)xf, (int)yf, (int)zf);
+    }
     if (PRECISE) {  // with a float copy of the footprints: two 16-byte gathers, no conversions
         f32x4 a, b;
         if (f4 != nullptr) {
@@ -417,8 +451,13 @@ __device__ __forceinline__ float cube_sample(const uint32_t *__restrict__ fp, in
     }
     // (0.5*(q + 1))*n - 0.5 with the reference's roundings: q + 1 rounds, the scalings are exact for power-of-two n
     const float hn = 0.5f * (float)n;
-    const float x = fmaf(qs + 1.0f, hn, -0.5f);
-    const float y = fmaf(qt + 1.0f, hn, -0.5f);
+    float x = fmaf(qs + 1.0f, hn, -0.5f);
+    float y = fmaf(qt + 1.0f, hn, -0.5f);
+    if (PRECISE && (n & (n - 1)) != 0) {  // a face size that is not a power of two (wave-uniform): the product (0.5 (q + 1)) n rounds in the reference
+        asm volatile("; cube_sample: face size not a power of two");   // (a scalar branch, not selects: see shape_sample)
+        x = sub_unfused(mul_unfused(0.5f * (qs + 1.0f), (float)n), 0.5f);
+        y = sub_unfused(mul_unfused(0.5f * (qt + 1.0f), (float)n), 0.5f);
+    }
     const float xf = floorf(x), yf = floorf(y);
     const float fx = x - xf, fy = y - yf;
     const int stride = n + 1;
@@ -539,13 +578,14 @@ __device__ __forceinline__ void quad_exchange_positions(float px, float py, floa
         : "scc");
 }
 
+constexpr int CUBE_LEVEL_TABLE = 16;   // rows of the per-level constants in LDS (cube_level_table_fill); log2_cr's table sits behind them
 // What a texture() call of the declared sampler needs to know about the pixel's two 2x2-quad partners; valid = the partner reaches the call.
 struct QuadNb {
     bool vx, vy;
     V3 px, py;         // position form (light taps of a queued sample): the horizontal / vertical partner's sample position (model space) ...
     V3 k;              // ... and the tap's offset from it (the partners evaluate the same tap from their own sample)
     float e2;          // >= |partner's position - this lane's|^2 for both partners that reach the call, scaled: cube_lod_scaled_spread
-    const f32x4 *lvl;  // LDS: per mip level {0.5 n_l, 4 n_l + 4, 4 (n_l + 1)^2, byte offset of footprint (0, 0) of face 0} (cube_level_table)
+    const f32x4 *lvl;  // LDS: per mip level {0.5 n_l, 4 n_l + 4, 4 (n_l + 1)^2, byte offset of footprint (0, 0) of face 0} (cube_level_table), then log2_cr's 32 rows
     QuadRegs *regs;    // lock-step form (the march): the whole-quad exchange registers
 };
 
@@ -563,6 +603,98 @@ __device__ __forceinline__ float cube_level_sample(const RenderConsts &rc, int f
     return bilinear_unorm8_exact(w, fx, fy);
 }
 
+// log2 of a float evaluated in double and rounded ONCE -- correctly rounded (the oracle's copy of this function equals (float)log2l(x) on every float of
+// [2^-4, 2^40): tests/test_oracle_kat.py) and, because it is a fixed sequence of IEEE double operations on a shared table (tools/make_log2_table.py;
+// the CPU checker under oracle/ carries the same text), the SAME BITS as the oracle's by construction: atmo_debug_log2_cr / test_gpu_parity.py compare the two.
+//   x = 2^k z, z in [OFF, 2 OFF) (32 bins, bin 19 centred on 1);  r = z invc - 1 (exact);  log2 x = (k + logc) + r (c1 + r (c2 + ... r c8)).
+// ~30 VALU instructions (v_fma_f64 issues at the f32 rate on gfx950), one LDS read; v_log_f32 is 1 ulp -- not the same bits as anything.
+// Domain: finite normal x > 0 (callers pass rho^2 > 1).
+/* generated by tools/make_log2_table.py -- do not edit by hand */
+#define LOG2CR_OFF 0x3f320000u
+__device__ const double LOG2CR_TAB[32][2] = {  /* {invc, logc = -log2(invc)} */
+    {0x1.6c16c20000000p+0, -0x1.042bd5e5bc697p-1},
+    {0x1.642c860000000p+0, -0x1.e7df61b2e23edp-2},
+    {0x1.5c98820000000p+0, -0x1.c819d91c72820p-2},
+    {0x1.5555560000000p+0, -0x1.a8ff99fab991dp-2},
+    {0x1.4e5e0a0000000p+0, -0x1.8a897eb027b02p-2},
+    {0x1.47ae140000000p+0, -0x1.6cb0f45c5ddccp-2},
+    {0x1.4141420000000p+0, -0x1.4f6fbe9a14f18p-2},
+    {0x1.3b13b20000000p+0, -0x1.32bff1d2620d3p-2},
+    {0x1.3521d00000000p+0, -0x1.169c06a7938bbp-2},
+    {0x1.2f684c0000000p+0, -0x1.f5fd8c01b8598p-3},
+    {0x1.29e4120000000p+0, -0x1.bfc6745e58544p-3},
+    {0x1.24924a0000000p+0, -0x1.8a898953f695dp-3},
+    {0x1.1f70480000000p+0, -0x1.563dc4114f416p-3},
+    {0x1.1a7b960000000p+0, -0x1.22dadb72090e4p-3},
+    {0x1.15b1e60000000p+0, -0x1.e0b1af47da109p-4},
+    {0x1.1111120000000p+0, -0x1.7d605d9f9a247p-4},
+    {0x1.0c97140000000p+0, -0x1.1bb314bc1250dp-4},
+    {0x1.0842100000000p+0, -0x1.773935884e226p-5},
+    {0x1.0410420000000p+0, -0x1.743f41d467d22p-6},
+    {0x1.0000000000000p+0, 0x0.0p+0},
+    {0x1.f07c200000000p-1, 0x1.6bad2043a8791p-5},
+    {0x1.e1e1e20000000p-1, 0x1.663f6e3b3cbb2p-4},
+    {0x1.d41d420000000p-1, 0x1.08c587b8a8459p-3},
+    {0x1.c71c720000000p-1, 0x1.5c01a22e68f24p-3},
+    {0x1.bacf920000000p-1, 0x1.acf5de2afc49ap-3},
+    {0x1.af286c0000000p-1, 0x1.fbc16a1ed20a6p-3},
+    {0x1.a41a420000000p-1, 0x1.2440796db68c3p-2},
+    {0x1.99999a0000000p-1, 0x1.49a7834b7d429p-2},
+    {0x1.8f9c180000000p-1, 0x1.6e22207523f6dp-2},
+    {0x1.8618620000000p-1, 0x1.91bba6c447dcfp-2},
+    {0x1.7d05f40000000p-1, 0x1.b47ebfcfdd47ap-2},
+    {0x1.745d180000000p-1, 0x1.d6753b2085b50p-2},
+};
+constexpr double LOG2CR_C[8] = {  /* (-1)^(n+1) / (n ln 2), n = 1 .. 8 */
+    0x1.71547652b82fep+0, -0x1.71547652b82fep-1, 0x1.ec709dc3a03fdp-2, -0x1.71547652b82fep-2, 0x1.2776c50ef9bfep-2, -0x1.ec709dc3a03fdp-3, 0x1.a61762a7aded9p-3, -0x1.71547652b82fep-3,
+};
+
+// The table in LDS (32 rows of {invc, logc}: LOG2CR_ROWS f32x4 behind the cube level table, filled by every wave for itself like that one) and the
+// coefficients as s_mov_b32 immediates issued right where they are used.  A 64-bit constant needs a register pair on gfx950 (no 64-bit literals), and
+// this function sits at the point of the highest register pressure of the declared-sampler kernels: as C++ literals (SGPR pairs the compiler hoists out
+// of the march loop -- the kernels are at the SGPR ceiling) or as plain loads (hoisted or clustered) the constants took the raymarched-light kernel from
+// 73 to 95-97 VGPRs (6 -> 4 waves per SIMD) and gave the others a stack frame; loaded one by one from global memory, each behind the Horner step before
+// it, every kernel kept its registers but a frame bound by its limb waves (where lambda > 0 lives) paid nine dependent cache misses per call: clouds_high_rm
+// 1920x1080 +49 % (profiles/round6/ab_lambda_exact.txt, first table).  An asm volatile is not hoisted, SALU issue is free beside VALU work, LDS answers in
+// ~64 cycles.
+constexpr int LOG2CR_ROWS = 32;
+__device__ __forceinline__ void log2_cr_table_fill(f32x4 *tab, int lane) {   // tab: LOG2CR_ROWS f32x4 in LDS
+    if (lane < LOG2CR_ROWS) tab[lane] = *reinterpret_cast<const f32x4 *>(&LOG2CR_TAB[lane][0]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+}
+template <uint64_t BITS>
+__device__ __forceinline__ double log2_cr_const() {
+    uint32_t lo, hi;
+    asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "i"((uint32_t)BITS), "i"((uint32_t)(BITS >> 32)));
+    return __hiloint2double((int)hi, (int)lo);
+}
+__device__ __forceinline__ float log2_cr(float x, const f32x4 *tab) {
+    const uint32_t ix = __float_as_uint(x);
+    const uint32_t tmp = ix - LOG2CR_OFF;
+    const uint32_t i = (tmp >> 18) & 31u;
+    const float z = __uint_as_float(ix - (tmp & 0xff800000u));
+    const int k = (int)tmp >> 23;
+    const f32x4 row = tab[i];
+    const double invc = __hiloint2double(__float_as_int(row.y), __float_as_int(row.x)), logc = __hiloint2double(__float_as_int(row.w), __float_as_int(row.z));
+    const double r = __builtin_fma((double)z, invc, -1.0);
+    // LOG2CR_C[7] .. [0] as bit patterns (the asm takes integers); held to the generated table at compile time:
+    static_assert(__builtin_bit_cast(uint64_t, LOG2CR_C[7]) == 0xbfc71547652b82feull && __builtin_bit_cast(uint64_t, LOG2CR_C[6]) == 0x3fca61762a7aded9ull &&
+                  __builtin_bit_cast(uint64_t, LOG2CR_C[5]) == 0xbfcec709dc3a03fdull && __builtin_bit_cast(uint64_t, LOG2CR_C[4]) == 0x3fd2776c50ef9bfeull &&
+                  __builtin_bit_cast(uint64_t, LOG2CR_C[3]) == 0xbfd71547652b82feull && __builtin_bit_cast(uint64_t, LOG2CR_C[2]) == 0x3fdec709dc3a03fdull &&
+                  __builtin_bit_cast(uint64_t, LOG2CR_C[1]) == 0xbfe71547652b82feull && __builtin_bit_cast(uint64_t, LOG2CR_C[0]) == 0x3ff71547652b82feull,
+                  "log2_cr: the immediates below are LOG2CR_C");
+    double p = log2_cr_const<0xbfc71547652b82feull>();
+    p = __builtin_fma(p, r, log2_cr_const<0x3fca61762a7aded9ull>());
+    p = __builtin_fma(p, r, log2_cr_const<0xbfcec709dc3a03fdull>());
+    p = __builtin_fma(p, r, log2_cr_const<0x3fd2776c50ef9bfeull>());
+    p = __builtin_fma(p, r, log2_cr_const<0xbfd71547652b82feull>());
+    p = __builtin_fma(p, r, log2_cr_const<0x3fdec709dc3a03fdull>());
+    p = __builtin_fma(p, r, log2_cr_const<0xbfe71547652b82feull>());
+    p = __builtin_fma(p, r, log2_cr_const<0x3ff71547652b82feull>());
+    const double y0 = logc + (double)k;
+    return (float)__builtin_fma(p, r, y0);
+}
+
 // (sc, tc, signed major) of v in the frame of the face selected by (isz, isy, pos): the linear maps of the Vulkan table
 __device__ __forceinline__ void cube_frame(bool isz, bool isy, bool pos, V3 v, float &sc, float &tc, float &ma) {
     sc = isz ? (pos ? v.x : -v.x) : (isy ? v.x : (pos ? -v.z : v.z));
@@ -574,7 +706,7 @@ __device__ __forceinline__ void cube_frame(bool isz, bool isy, bool pos, V3 v, f
 // texture(u_cloud_coverage_cubemap, d).r with the implicit LOD of a linear-mipmap sampler: finite differences inside the
 // pixel quad, transformed to the selected face in the cancellation-free form s' - s = 0.5 (dsc ma - sc dma) / (ma ma'),
 // lambda = 0.5 log2(max rho^2) clamped to the bound levels, linear mix of the two nearest levels.
-__device__ __forceinline__ float cube_sample_lod(const RenderConsts &rc, V3 d, bool vx, V3 dx, bool vy, V3 dy) {
+__device__ __forceinline__ float cube_sample_lod(const RenderConsts &rc, V3 d, bool vx, V3 dx, bool vy, V3 dy, const f32x4 *lvl) {
     const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
     const bool isz = az >= ax && az >= ay, isy = !isz && ay >= ax;
     const float r = isz ? d.z : (isy ? d.y : d.x);
@@ -592,13 +724,21 @@ __device__ __forceinline__ float cube_sample_lod(const RenderConsts &rc, V3 d, b
         cube_frame(isz, isy, pos, dv, dsc, dtc, dma);
         const float ma2 = ma + dma;
         if (!(ma2 > 0.0f)) return;
-        const float inv = ieee_div(0.5f, ma * ma2);
+    #if ATMO_LOD_DIV_FORM == 0
+    const float inv = ieee_div(0.5f, ma * ma2);
+#else
+    const float inv = 0.5f * exact_rcp(ma * ma2);   // 0.5 / d = 0.5 RN(1 / d): the scaling is exact
+#endif
         const float ds = (dsc * ma - sc * dma) * inv, dt = (dtc * ma - tc * dma) * inv;
         rho2 = fmaxf(rho2, (ds * ds + dt * dt) * n2);
     };
     axis(vx, dx);
     axis(vy, dy);
+#if ATMO_LOD_LAMBDA_EXACT && ATMO_LOD_LOG2_CR
+    float lambda = rho2 > 1.0f ? 0.5f * log2_cr(rho2, lvl + CUBE_LEVEL_TABLE) : 0.0f;   // correctly rounded, see cube_lod_select; rho2 <= 1: clamped to 0 below anyway
+#else
     float lambda = rho2 > 0.0f ? 0.5f * __builtin_amdgcn_logf(rho2) : 0.0f;  // v_log_f32 = log2
+#endif
     lambda = fminf(fmaxf(lambda, 0.0f), (float)(rc.cube_levels - 1));
     const float lf = floorf(lambda), fr = lambda - lf;
     const int lo = (int)lf, hi = lo + 1 < rc.cube_levels ? lo + 1 : lo;
@@ -624,7 +764,6 @@ __device__ __forceinline__ float cube_sample_lod(const RenderConsts &rc, V3 d, b
 // (33.6 MB for the whole chain at n = 1024), i.e. exact in fp32.  For the float copy of the chain (rc.cube_f4: 16-byte footprints)
 // s4, F and G are stored times four -- multiples of 16 below 2^28, as exact.  Each wave fills the table itself before it reads it (identical
 // values from both waves of a workgroup: no barrier).
-constexpr int CUBE_LEVEL_TABLE = 16;
 __device__ __forceinline__ void cube_level_table_fill(const RenderConsts &rc, f32x4 *lvl, int lane) {
     if (lane < CUBE_LEVEL_TABLE) {
         const float nf = (float)rc.cube_n, l = (float)lane;
@@ -691,7 +830,7 @@ __device__ __forceinline__ V3 cube_dir_from_coords(float fid, float sc, float tc
 // signed copies of one component each (so scp - sc = +-(q.c - d.c), the same rounding), and 0.5 |v_cubema| is the major component with
 // the face's sign on both.
 __device__ __forceinline__ float cube_lod_partner_coords(float fid, float sc, float tc, float ma2x, float ma, V3 d, bool valid, float fidp,
-                                                         float scp, float tcp, float masp, float n2, float rho2) {
+                                                         float scp, float tcp, float masp, float n2q, float rho2) {
     float dsc = scp - sc, dtc = tcp - tc, dma = 0.5f * fabsf(masp) - ma;
     if (valid && fidp != fid) {
         // (the face frame is built HERE, inside the branch only the quads across a cube edge take: computed in front of it, its dozen compares
@@ -704,16 +843,28 @@ __device__ __forceinline__ float cube_lod_partner_coords(float fid, float sc, fl
         dtc = f.b1 * dv.y + f.b2 * dv.z;
         dma = f.sgn * (f.mx * dv.x + f.my * dv.y + f.mz * dv.z);
     }
-    // rho^2 of this partner exactly as rounds 2-3 evaluated it (the arithmetic the executed-reference vectors were pinned with): fused numerators,
-    // one approximate reciprocal per partner.  A cheaper form (both partners' numerators compared by cross-multiplication, ONE reciprocal; round 4,
-    // first attempt) is the same real function and differs by an ulp or two of lambda -- which is enough to move a hypersensitive pixel (a
-    // `clouds` march of 8 long steps at a high density scale: 1 ulp of lambda x 135 (density ramp) x ~250 (optical thickness per unit density)) by
-    // 5e-4: extended fuzz, seed 128, profiles/round4/fuzz_sensitive_pixels.txt.  Bit-identity with the pinned kernels was worth its 3 %.
-    // (written with explicit FMAs: under `fp contract(fast)` hipcc chooses which product of a difference to fuse, and that choice is part of the bits)
+    // rho^2 of this partner.  ATMO_LOD_LAMBDA_EXACT (1 since round 6): the operations of a scalar fp32 evaluation of the stated convention, one for
+    // one -- the IEEE quotient 0.5 / (ma ma'), every product and sum of the numerators and of rho^2 rounded on its own (the CPU checker under oracle/,
+    // sample_cube_lod) -- so that lambda is the oracle's BIT FOR BIT (with the correctly rounded logarithm of cube_lod_select).  One ulp of lambda moves
+    // a hypersensitive pixel (a `clouds` march of 8 long steps at a high density scale: x 135 (density ramp) x ~250 (optical thickness per unit
+    // density)) by 5e-4 -- profiles/round4/fuzz_sensitive_pixels.txt; seed 1040 of the 1 212-scene fuzz sat at 2.0e-4 for three rounds.
+    //   * 0.5 / d = 0.5 RN(1 / d), and a factor 0.5 commutes with every rounding behind it: ds = N RN(1 / d) is twice the oracle's, its square four
+    //     times, and n2q = n^2 / 4 (exact) makes rho^2 the same bits -- the multiplication by 0.5 is never issued;
+    //   * RN(1 / d) = exact_rcp: v_rcp_f32 and Newton steps, equal to the IEEE quotient on every significand (atmo_selftest_exact_math).
+    // What it costs, and what was tried to hide it (a fused-form screen in front of a from-scratch exact pass: worse, the limb's waves take the exact
+    // pass for most samples): profiles/round6/ab_lambda_exact.txt.  0 = rounds 2-5: fused numerators, one approximate reciprocal per partner (the same
+    // real function, an ulp or two of lambda away).
     const float ma2 = ma + dma;
-    const float inv = 0.5f * hw_rcp(ma * ma2);
+#if ATMO_LOD_LAMBDA_EXACT
+    const float r = exact_rcp(ma * ma2);
+    const float ds = (dsc * ma - sc * dma) * r, dt = (dtc * ma - tc * dma) * r;   // (no contraction in this function)
+    const float r2 = (ds * ds + dt * dt) * n2q;
+#else
+    // (written with explicit FMAs: under `fp contract(fast)` hipcc chooses which product of a difference to fuse, and that choice is part of the bits)
+    const float inv = hw_rcp(ma * ma2);
     const float ds = __builtin_fmaf(ma, dsc, -(sc * dma)) * inv, dt = __builtin_fmaf(ma, dtc, -(tc * dma)) * inv;
-    const float r2 = __builtin_fmaf(dt, dt, ds * ds) * n2;
+    const float r2 = __builtin_fmaf(dt, dt, ds * ds) * n2q;
+#endif
     return (valid && ma2 > 0.0f) ? fmaxf(rho2, r2) : rho2;
 }
 
@@ -722,10 +873,19 @@ struct CubeLod {
     int lo;
     float fr;
 };
-__device__ __forceinline__ CubeLod cube_lod_select(const RenderConsts &rc, float rho2) {
-    // clamp(0.5 log2(rho2), 0, levels - 1); rho2 <= 1 (or 0, or NaN) => lambda = 0: the lower clamp as a max in front of the logarithm (the same bits
-    // as `rho2 > 0 ? 0.5 log2(rho2) : 0` clamped: log2(1) = 0, and v_max returns the other operand for a NaN)
+__device__ __forceinline__ CubeLod cube_lod_select(const RenderConsts &rc, float rho2, const f32x4 *lvl) {
+    // clamp(0.5 log2(rho2), 0, levels - 1); rho2 <= 1 (or 0, or NaN) => lambda = 0
+#if ATMO_LOD_LAMBDA_EXACT && ATMO_LOD_LOG2_CR
+    // log2 correctly rounded and the oracle's bits (log2_cr); only the lanes with rho^2 > 1 pay for it -- most samples that get here are magnified all
+    // the same (the certificate is a bound over the whole march) and keep lambda = 0 (log2(1) = 0)
+    float l2 = 0.0f;
+    if (rho2 > 1.0f) l2 = log2_cr(rho2, lvl + CUBE_LEVEL_TABLE);
+    const float lambda = fminf(0.5f * l2, (float)(rc.cube_levels - 1));
+#else
+    // the lower clamp as a max in front of the logarithm (the same bits as `rho2 > 0 ? 0.5 log2(rho2) : 0` clamped: log2(1) = 0, and v_max returns the other
+    // operand for a NaN)
     const float lambda = fminf(0.5f * __builtin_amdgcn_logf(fmaxf(rho2, 1.0f)), (float)(rc.cube_levels - 1));  // v_log_f32 = log2
+#endif
 #if defined(ATMO_WAVE_TRACE) && ATMO_RMQ_STATS  // diagnostic build: how many of these samples select level 0 alone (words 40..43 of the statistics block)
     if (rc.wave_trace != nullptr) {
         unsigned long long *st_ = rc.wave_trace + 16ull * gridDim.x * gridDim.y - 64 + 40;
@@ -844,12 +1004,12 @@ __device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3
             return V3{rc.cov_rot[0] * x + rc.cov_rot[2] * z, y, rc.cov_rot[1] * x + rc.cov_rot[3] * z};
         };
         const V3 dx = at(nb->px), dy = at(nb->py);
-        const float nf = (float)rc.cube_n, n2 = nf * nf;
+        const float nf = (float)rc.cube_n, n2 = 0.25f * (nf * nf);   // n^2 / 4: see cube_lod_partner_coords
         rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, nb->vx, __builtin_amdgcn_cubeid(dx.x, dx.y, dx.z), __builtin_amdgcn_cubesc(dx.x, dx.y, dx.z),
                                        __builtin_amdgcn_cubetc(dx.x, dx.y, dx.z), __builtin_amdgcn_cubema(dx.x, dx.y, dx.z), n2, rho2);
         rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, nb->vy, __builtin_amdgcn_cubeid(dy.x, dy.y, dy.z), __builtin_amdgcn_cubesc(dy.x, dy.y, dy.z),
                                        __builtin_amdgcn_cubetc(dy.x, dy.y, dy.z), __builtin_amdgcn_cubema(dy.x, dy.y, dy.z), n2, rho2);
-        lod = cube_lod_select(rc, rho2);
+        lod = cube_lod_select(rc, rho2, nb->lvl);
     }
     return cube_lod_finish(rc, fid, qs, qt, lod, nb->lvl);
 }
@@ -872,11 +1032,11 @@ __device__ __forceinline__ float cube_sample_lod_quad(const RenderConsts &rc, fl
         QuadRegs &q = *nb->regs;
         quad_exchange_coords(px, py, pz, rc.cov_rot[0], rc.cov_rot[1], rc.cov_rot[2], rc.cov_rot[3], q);  // q.fid, sc, tc, mas, qx, qz: the values above
         if (!rc.cube_lod_fast)  // faces that are not a power of two (or above 1024): the general sampler on the partners' directions
-            return cube_sample_lod(rc, d, nb->vx, cube_dir_from_coords(q.fidx, q.scx, q.tcx, q.masx), nb->vy, cube_dir_from_coords(q.fidy, q.scy, q.tcy, q.masy));
-        const float nf = (float)rc.cube_n, n2 = nf * nf;
+            return cube_sample_lod(rc, d, nb->vx, cube_dir_from_coords(q.fidx, q.scx, q.tcx, q.masx), nb->vy, cube_dir_from_coords(q.fidy, q.scy, q.tcy, q.masy), nb->lvl);
+        const float nf = (float)rc.cube_n, n2 = 0.25f * (nf * nf);   // n^2 / 4: see cube_lod_partner_coords
         rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, nb->vx, q.fidx, q.scx, q.tcx, q.masx, n2, rho2);
         rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, nb->vy, q.fidy, q.scy, q.tcy, q.masy, n2, rho2);
-        lod = cube_lod_select(rc, rho2);
+        lod = cube_lod_select(rc, rho2, nb->lvl);
     }
     return cube_lod_finish(rc, fid, qs, qt, lod, nb->lvl);
 }
@@ -1270,7 +1430,7 @@ __device__ __forceinline__ float cloud_density_precise(const RenderConsts &rc, f
                 return V3{rc.cov_rot[0] * x + rc.cov_rot[2] * z, y, rc.cov_rot[1] * x + rc.cov_rot[3] * z};
             };
             if (rc.cube_lod_fast) coverage = cube_sample_lod_fast(rc, V3{qx, py, qz}, nb);
-            else coverage = cube_sample_lod(rc, V3{qx, py, qz}, nb->vx, at(nb->px), nb->vy, at(nb->py));
+            else coverage = cube_sample_lod(rc, V3{qx, py, qz}, nb->vx, at(nb->px), nb->vy, at(nb->py), nb->lvl);
         } else {
             coverage = cube_sample<true>(rc.cube, rc.cube_n, qx, py, qz, rc.cube_f4);
         }
@@ -1780,8 +1940,9 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
     const f32x4 *lvl_table = nullptr;
     if constexpr (LOD) {  // the declared sampler's per-level constants (cube_level_table_fill), written by every wave before any lane leaves
-        __shared__ f32x4 lvl_lds[CUBE_LEVEL_TABLE];
+        __shared__ f32x4 lvl_lds[CUBE_LEVEL_TABLE + LOG2CR_ROWS];
         cube_level_table_fill(rc, lvl_lds, lane);
+        log2_cr_table_fill(lvl_lds + CUBE_LEVEL_TABLE, lane);   // (round 6) the table of the declared sampler's logarithm
         lvl_table = lvl_lds;
     }
     // SPLIT = 2: lanes 2r, 2r+1 share ray r; a wave covers WAVE_W x (32 / WAVE_W) pixels, the workgroup TILE_W x TILE_H / 2
@@ -2038,9 +2199,13 @@ constexpr bool render_sgpr_cap80(int flags) {
     if (rc.tile_cost != nullptr && (threadIdx.x & 63) == 0) {                                                    \
         uint64_t dt = __builtin_amdgcn_s_memtime() - t0;                                                         \
         uint32_t cost_tile = tile;                                                                               \
-        if constexpr (SPLIT == 2 && (FLAGS & KF_CUBE_LOD) != 0) { /* a heavy tile drawn split: the cost map stays the one-lane grid's */ \
-            cost_tile = (tile_y >> 1) * (uint32_t)rc.tiles_x + tile_x;                                           \
-            dt *= 2;                                                                                             \
+        if constexpr (SPLIT == 2 && (FLAGS & KF_CUBE_LOD) != 0) {                                                \
+            /* a heavy tile of a one-lane frame drawn split: the cost map stays the one-lane grid's.  Only there: a WHOLE frame   */ \
+            /* on two lanes per ray (atmo_set_lane_split 2, --shard tiles --lanes 2) has a cost map of its own, half-height grid.          */ \
+            if (rc.cost_rows_halved) {                                                                           \
+                cost_tile = (tile_y >> 1) * (uint32_t)rc.tiles_x + tile_x;                                       \
+                dt *= 2;                                                                                         \
+            }                                                                                                    \
         }                                                                                                        \
         atomicMax(&rc.tile_cost[cost_tile], (uint32_t)(dt > 0xffffffffull ? 0xffffffffull : dt));                \
     }
@@ -2508,9 +2673,24 @@ __global__ __launch_bounds__(256) void atmo_selftest_kernel(uint32_t first_bits,
             if ((hc_fast > 0.0f) || (hc_ieee > 0.0f) || (x == 0.0f && __float_as_int(exact_sqrt(x)) != want)) ++bad_sqrt;
         } else if (__float_as_int(exact_sqrt(x)) != want || __float_as_int(exact_sqrt_pos(x)) != want) ++bad_sqrt;
         if (__float_as_int(exact_div_uniform(x, c, rc)) != __float_as_int(ieee_div(x, c))) ++bad_div;
+        // round 6: exact_rcp (the declared sampler's lambda: 0.5 / (ma ma')) against the IEEE reciprocal, wherever both are normal
+        if (fabsf(x) >= 7.8886091e-31f && fabsf(x) <= 1.2676506e30f && __float_as_int(exact_rcp(x)) != __float_as_int(ieee_div(1.0f, x))) ++bad_div;
     }
     if (bad_sqrt) atomicAdd(&mismatch[0], bad_sqrt);
     if (bad_div) atomicAdd(&mismatch[1], bad_div);
+}
+
+// log2_cr over an array (atmo_debug_log2_cr: compared with the oracle's copy of the function bit for bit)
+__global__ __launch_bounds__(256) void atmo_log2_cr_kernel(const float *__restrict__ x, float *__restrict__ out, int n) {
+    __shared__ f32x4 tab[LOG2CR_ROWS];
+    log2_cr_table_fill(tab, threadIdx.x);   // (every wave of the block writes the same 32 rows)
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = log2_cr(x[i], tab);
+}
+hipError_t launch_log2_cr(const float *x_dev, float *out_dev, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(atmo_log2_cr_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x_dev, out_dev, n);
+    return hipGetLastError();
 }
 
 hipError_t launch_selftest(uint32_t first_bits, uint32_t count, float c, float rc, unsigned int *mismatch_dev, hipStream_t stream) {

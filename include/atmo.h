@@ -212,6 +212,18 @@ int atmo_render_composite(AtmoContext *ctx, const AtmoFrame *frame, const float 
  */
 int atmo_render_tiles(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, const uint32_t *tiles_dev, int n_tiles,
                       void *stream);
+/*
+ * atmo_render_tiles with the list's first n_heavy tiles drawn on two lanes per ray beside the rest (what `bench.py --shard tiles` and
+ * sharding.heavy_tiles use: product API of the tile-sharded path; in atmo_debug.h until round 6): a GPU's share of ONE frame is as long as its
+ * heaviest wavefront from two GPUs on (profiles/round4/band_balance.txt), which is the regime where the lane-split kernel pays.  The caller orders
+ * its list heaviest first and picks n_heavy from the measured costs.  Ignored (n_heavy = 0) where the kernel family has no bit-identical
+ * lane-split form: the frame is the same bits either way.
+ * Both tile-list draws keep a bounded copy of the caller's list in a buffer the CONTEXT owns and grows on demand, so neither may be recorded into a
+ * HIP graph: on a capturing stream they return ATMO_E_STATE (a replay would read a buffer a later, longer list has freed; atmo_render allocates
+ * nothing and can be captured).
+ */
+int atmo_render_tiles_split(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, const uint32_t *tiles_dev, int n_tiles,
+                            int n_heavy, void *stream);
 
 /*
  * Sharding aid (no reference counterpart: the reference is single-GPU): draws the rect like atmo_render and

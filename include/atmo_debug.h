@@ -58,7 +58,8 @@ int atmo_read_texture_layout(AtmoContext *ctx, const char *name, void *out_host,
 
 /* Diagnostics (no reference counterpart): on the device, compares the kernels' cheap correctly-rounded sqrt and
  * divide-by-uniform helpers with the compiler's IEEE expansions over `count` consecutive float bit patterns
- * starting at `first_bits`, and reports the number of mismatches (must be 0). */
+ * starting at `first_bits`, and reports the number of mismatches (must be 0).  Since round 6 the divide counter also holds exact_rcp(x) != 1 / x
+ * (the reciprocal inside the declared sampler's lambda) for 2^-100 <= |x| <= 2^100. */
 int atmo_selftest_exact_math(AtmoContext *ctx, uint32_t first_bits, uint32_t count, float divisor,
                              uint32_t *sqrt_mismatches, uint32_t *div_mismatches);
 
@@ -68,6 +69,11 @@ int atmo_selftest_exact_math(AtmoContext *ctx, uint32_t first_bits, uint32_t cou
  * texel-centre geometry (shaders/optical_depth.gdshader:45-65) this is the integral the reference bakes into that texel. */
 int atmo_debug_marched_optical_depth(AtmoContext *ctx, int n, const float *pos_xyz, const float *dir_xyz, int light_steps, float *out);
 
+/* Diagnostics (no reference counterpart): the kernels' log2_cr -- log2 of a float evaluated in double and rounded once, the logarithm of the declared
+ * cubemap sampler's lambda since round 6 -- for n host floats (finite, normal, > 0), host array out.  The oracle carries the same operation sequence
+ * on the same table (tools/make_log2_table.py); tests/test_gpu_parity.py holds the two to the same bits. */
+int atmo_debug_log2_cr(AtmoContext *ctx, int n, const float *x, float *out);
+
 /* Name of the kernel the most recent atmo_render of this context launched, "atmo_render_kernel<FLAGS, LSTEPS, SPLIT>"
  * (before the first launch: the one-lane-per-ray form), for matching rocprofv3 kernel traces. */
 const char *atmo_kernel_name(AtmoContext *ctx);
@@ -76,13 +82,6 @@ const char *atmo_kernel_name(AtmoContext *ctx);
  * drew their heaviest tiles with the lane-split kernel beside the rest, and how many tiles the last such draw split.  ATMO_HEAVY_SPLIT=0
  * (read in atmo_create) turns it off; the picture does not depend on it, bit for bit. */
 int atmo_get_split_stats(AtmoContext *ctx, unsigned *split_draws, unsigned *heavy_tiles_last);
-
-/* atmo_render_tiles with the list's first n_heavy tiles drawn on two lanes per ray beside the rest (round 5; a sharding experiment, not bound by a Godot
- * host): a GPU's share of ONE frame is as long as its heaviest wavefront from two GPUs on (profiles/round4/band_balance.txt), which is the regime where the
- * lane-split kernel pays.  The caller orders its list heaviest first and picks n_heavy from the measured costs (sharding.heavy_tiles).  Ignored (n_heavy = 0)
- * where the kernel family has no bit-identical lane-split form: the frame is the same bits either way. */
-int atmo_render_tiles_split(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, const uint32_t *tiles_dev, int n_tiles,
-                            int n_heavy, void *stream);
 
 /* How often calls of this context fell back to a device-wide host wait (hipDeviceSynchronize) where a stream-side wait on the device was
  * not possible: a remembered stream that the caller has destroyed since, or more draw streams than the context tracks (8).  0 in a host

@@ -391,6 +391,22 @@ class Oracle:
         fn.argtypes = [C.POINTER(OracleTextures), C.POINTER(self.real), C.POINTER(self.real), C.POINTER(C.c_int)]
         return float(fn(C.byref(t), self._vec(d), nb, valid))
 
+    def log2_cr(self, x):
+        """log2_cr (the declared sampler's logarithm: evaluated in double, rounded once) over an array of floats."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        fn = self.lib.oracle_log2_cr
+        fn.restype, fn.argtypes = None, [C.c_void_p, C.c_void_p, C.c_long]
+        fn(x.ctypes.data, out.ctypes.data, x.size)
+        return out
+
+    def log2_cr_check(self, first_bits, count):
+        """Mismatches of log2_cr against (float)log2l(x) on `count` consecutive float bit patterns; returns (mismatches, first bad bits)."""
+        fn = self.lib.oracle_log2_cr_check
+        fn.restype, fn.argtypes = C.c_long, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        fb = C.c_uint32(0)
+        return int(fn(first_bits, count, C.byref(fb))), int(fb.value)
+
     def noise_cubemap_atlas(self, faces):
         faces = np.ascontiguousarray(faces, dtype=np.uint8)
         n = faces.shape[1]
