@@ -829,6 +829,7 @@ __device__ __forceinline__ V3 cube_dir_from_coords(float fid, float sc, float tc
 // the differences of the coordinates ARE the face frame applied to the rounded difference of the directions, bit for bit: sc and tc are
 // signed copies of one component each (so scp - sc = +-(q.c - d.c), the same rounding), and 0.5 |v_cubema| is the major component with
 // the face's sign on both.
+template <bool EXACT>
 __device__ __forceinline__ float cube_lod_partner_coords(float fid, float sc, float tc, float ma2x, float ma, V3 d, bool valid, float fidp,
                                                          float scp, float tcp, float masp, float n2q, float rho2) {
     float dsc = scp - sc, dtc = tcp - tc, dma = 0.5f * fabsf(masp) - ma;
@@ -843,28 +844,29 @@ __device__ __forceinline__ float cube_lod_partner_coords(float fid, float sc, fl
         dtc = f.b1 * dv.y + f.b2 * dv.z;
         dma = f.sgn * (f.mx * dv.x + f.my * dv.y + f.mz * dv.z);
     }
-    // rho^2 of this partner.  ATMO_LOD_LAMBDA_EXACT (1 since round 6): the operations of a scalar fp32 evaluation of the stated convention, one for
-    // one -- the IEEE quotient 0.5 / (ma ma'), every product and sum of the numerators and of rho^2 rounded on its own (the CPU checker under oracle/,
-    // sample_cube_lod) -- so that lambda is the oracle's BIT FOR BIT (with the correctly rounded logarithm of cube_lod_select).  One ulp of lambda moves
-    // a hypersensitive pixel (a `clouds` march of 8 long steps at a high density scale: x 135 (density ramp) x ~250 (optical thickness per unit
-    // density)) by 5e-4 -- profiles/round4/fuzz_sensitive_pixels.txt; seed 1040 of the 1 212-scene fuzz sat at 2.0e-4 for three rounds.
-    //   * 0.5 / d = 0.5 RN(1 / d), and a factor 0.5 commutes with every rounding behind it: ds = N RN(1 / d) is twice the oracle's, its square four
-    //     times, and n2q = n^2 / 4 (exact) makes rho^2 the same bits -- the multiplication by 0.5 is never issued;
-    //   * RN(1 / d) = exact_rcp: v_rcp_f32 and Newton steps, equal to the IEEE quotient on every significand (atmo_selftest_exact_math).
-    // What it costs, and what was tried to hide it (a fused-form screen in front of a from-scratch exact pass: worse, the limb's waves take the exact
-    // pass for most samples): profiles/round6/ab_lambda_exact.txt.  0 = rounds 2-5: fused numerators, one approximate reciprocal per partner (the same
-    // real function, an ulp or two of lambda away).
+    // rho^2 of this partner, in two forms of the same real function:
+    //   EXACT   the operations of a scalar fp32 evaluation of the stated convention, one for one -- the IEEE quotient 0.5 / (ma ma'), every product and
+    //           sum of the numerators and of rho^2 rounded on its own (the CPU checker under oracle/, sample_cube_lod) -- so that lambda is the oracle's
+    //           BIT FOR BIT (with log2_cr).  One ulp of lambda moves a hypersensitive pixel (a `clouds` march of 8 long steps at a high density scale:
+    //           x 135 (density ramp) x ~250 (optical thickness per unit density)) by 5e-4 -- profiles/round4/fuzz_sensitive_pixels.txt; seed 1040 of the
+    //           1 212-scene fuzz sat at 2.0e-4 for three rounds.
+    //           * 0.5 / d = 0.5 RN(1 / d), and a factor 0.5 commutes with every rounding behind it: ds = N RN(1 / d) is twice the oracle's, its square
+    //             four times, and n2q = n^2 / 4 (exact) makes rho^2 the same bits -- the multiplication by 0.5 is never issued;
+    //           * RN(1 / d) = exact_rcp: v_rcp_f32 and a Newton step, equal to the IEEE quotient on every significand (atmo_selftest_exact_math).
+    //   !EXACT  rounds 2-5's arithmetic: fused numerators, the approximate reciprocal.  An ulp or two of lambda away -- since round 6 the light taps' form
+    //           (cube_sample_lod_fast: "WHERE exactness is needed").
     const float ma2 = ma + dma;
-#if ATMO_LOD_LAMBDA_EXACT
-    const float r = exact_rcp(ma * ma2);
-    const float ds = (dsc * ma - sc * dma) * r, dt = (dtc * ma - tc * dma) * r;   // (no contraction in this function)
-    const float r2 = (ds * ds + dt * dt) * n2q;
-#else
-    // (written with explicit FMAs: under `fp contract(fast)` hipcc chooses which product of a difference to fuse, and that choice is part of the bits)
-    const float inv = hw_rcp(ma * ma2);
-    const float ds = __builtin_fmaf(ma, dsc, -(sc * dma)) * inv, dt = __builtin_fmaf(ma, dtc, -(tc * dma)) * inv;
-    const float r2 = __builtin_fmaf(dt, dt, ds * ds) * n2q;
-#endif
+    float r2;
+    if (EXACT) {
+        const float r = exact_rcp(ma * ma2);
+        const float ds = (dsc * ma - sc * dma) * r, dt = (dtc * ma - tc * dma) * r;   // (no contraction in this function)
+        r2 = (ds * ds + dt * dt) * n2q;
+    } else {
+        // (written with explicit FMAs: under `fp contract(fast)` hipcc chooses which product of a difference to fuse, and that choice is part of the bits)
+        const float inv = hw_rcp(ma * ma2);
+        const float ds = __builtin_fmaf(ma, dsc, -(sc * dma)) * inv, dt = __builtin_fmaf(ma, dtc, -(tc * dma)) * inv;
+        r2 = __builtin_fmaf(dt, dt, ds * ds) * n2q;
+    }
     return (valid && ma2 > 0.0f) ? fmaxf(rho2, r2) : rho2;
 }
 
@@ -873,19 +875,19 @@ struct CubeLod {
     int lo;
     float fr;
 };
+template <bool EXACT>
 __device__ __forceinline__ CubeLod cube_lod_select(const RenderConsts &rc, float rho2, const f32x4 *lvl) {
     // clamp(0.5 log2(rho2), 0, levels - 1); rho2 <= 1 (or 0, or NaN) => lambda = 0
-#if ATMO_LOD_LAMBDA_EXACT && ATMO_LOD_LOG2_CR
-    // log2 correctly rounded and the oracle's bits (log2_cr); only the lanes with rho^2 > 1 pay for it -- most samples that get here are magnified all
-    // the same (the certificate is a bound over the whole march) and keep lambda = 0 (log2(1) = 0)
-    float l2 = 0.0f;
-    if (rho2 > 1.0f) l2 = log2_cr(rho2, lvl + CUBE_LEVEL_TABLE);
-    const float lambda = fminf(0.5f * l2, (float)(rc.cube_levels - 1));
-#else
-    // the lower clamp as a max in front of the logarithm (the same bits as `rho2 > 0 ? 0.5 log2(rho2) : 0` clamped: log2(1) = 0, and v_max returns the other
-    // operand for a NaN)
-    const float lambda = fminf(0.5f * __builtin_amdgcn_logf(fmaxf(rho2, 1.0f)), (float)(rc.cube_levels - 1));  // v_log_f32 = log2
-#endif
+    float lambda;
+    if (EXACT && ATMO_LOD_LOG2_CR) {
+        // log2 correctly rounded and the oracle's bits (log2_cr); rho^2 <= 1: lambda = 0 (log2(1) = 0)
+        float l2 = 0.0f;
+        if (rho2 > 1.0f) l2 = log2_cr(rho2, lvl + CUBE_LEVEL_TABLE);
+        lambda = fminf(0.5f * l2, (float)(rc.cube_levels - 1));
+    } else {
+        // v_log_f32 = log2 to 1 ulp; the lower clamp as a max in front of it (log2(1) = 0, and v_max returns the other operand for a NaN)
+        lambda = fminf(0.5f * __builtin_amdgcn_logf(fmaxf(rho2, 1.0f)), (float)(rc.cube_levels - 1));
+    }
 #if defined(ATMO_WAVE_TRACE) && ATMO_RMQ_STATS  // diagnostic build: how many of these samples select level 0 alone (words 40..43 of the statistics block)
     if (rc.wave_trace != nullptr) {
         unsigned long long *st_ = rc.wave_trace + 16ull * gridDim.x * gridDim.y - 64 + 40;
@@ -983,9 +985,25 @@ __device__ __forceinline__ float quad_march_spread2(const RenderConsts &rc, floa
     return cube_lod_scaled_spread(rc, r * r);
 }
 
+// ---- lambda of a march sample: exact (round 6) -----------------------------------------------------------------------------------------------------------
+// WHERE exactness is needed.  One ulp of lambda moves the filtered coverage by <= 2^-24 |level l+1 - level l|, the density ramp multiplies by 135, and a
+// MARCH sample's density enters the pixel through exp(-density step_len u_cloud_density_scale) -- an optical thickness per unit density of ~250 in an
+// 8-step march over a thick layer: 5e-4 of the pixel (profiles/round4/fuzz_sensitive_pixels.txt).  A light TAP's density enters through
+// exp(-sum_i density_i step_i scale) with step_i = 0.15 thickness / 6 x 1.2^i -- 3 to 7.5 per unit density in the demo scene, 25 at the extreme of
+// the fuzz's parameter range -- and then only as a factor of the sample's light: 1e-5 of the pixel at the very worst, unobservable against the 1e-4
+// contract (the four scenes of the 1 212-scene soak that exceeded it were all march samples; none was a raymarched-light scene).  So the march's samples
+// (cube_sample_lod_quad) take the oracle's operations bit for bit, and the light taps (cube_sample_lod_fast) keep rounds 2-5's arithmetic: evaluated
+// exactly they cost clouds_high_rm +12.6 % at 1920x1080 and +11 % from the limb for nothing a test can see (profiles/round6/ab_lambda_exact.txt).
+// WHAT the march pays for it: clouds_high +4 % at 1920x1080 pose P_space, +7.4 % from the limb, where lambda > 0 is the rule (1.4 / 1.8 % of that for
+// the exact rho^2, the rest for log2_cr: ~30 instructions where v_log_f32 is one).  Tried and measured against it (same file): a fused-form screen
+// (rho^2_fused <= 0.98 proves lambda = 0) in front of a from-scratch exact pass (+8 % / +27 %: the limb's waves take both), and the coverage from
+// v_log_f32 as an ESTIMATE whose early-outs are tested at +- its error bound, the exact logarithm only for samples whose outcome depends on the value
+// (+5 % / +38 %: along a grazing ray most samples with lambda > 0 do reach the shape fetch, and pay the level taps twice).
+
 // position form (the light taps of a queued sample): the partners' sample positions and the tap offset are given.  Their cube coordinates come
 // from the hardware cube instructions as well (4 instructions instead of the face frame applied to a difference: 13), and
 // cube_lod_partner_coords takes it from there -- the same bits as the frame form on the lane's own face, the frame form itself elsewhere.
+// Rounds 2-5's arithmetic (fused rho^2, v_log_f32): see "WHERE exactness is needed" above.
 __device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3 d, const QuadNb *nb) {
     const float fid = __builtin_amdgcn_cubeid(d.x, d.y, d.z);
     const float sc = __builtin_amdgcn_cubesc(d.x, d.y, d.z);
@@ -1004,17 +1022,17 @@ __device__ __forceinline__ float cube_sample_lod_fast(const RenderConsts &rc, V3
             return V3{rc.cov_rot[0] * x + rc.cov_rot[2] * z, y, rc.cov_rot[1] * x + rc.cov_rot[3] * z};
         };
         const V3 dx = at(nb->px), dy = at(nb->py);
-        const float nf = (float)rc.cube_n, n2 = 0.25f * (nf * nf);   // n^2 / 4: see cube_lod_partner_coords
-        rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, nb->vx, __builtin_amdgcn_cubeid(dx.x, dx.y, dx.z), __builtin_amdgcn_cubesc(dx.x, dx.y, dx.z),
-                                       __builtin_amdgcn_cubetc(dx.x, dx.y, dx.z), __builtin_amdgcn_cubema(dx.x, dx.y, dx.z), n2, rho2);
-        rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, nb->vy, __builtin_amdgcn_cubeid(dy.x, dy.y, dy.z), __builtin_amdgcn_cubesc(dy.x, dy.y, dy.z),
-                                       __builtin_amdgcn_cubetc(dy.x, dy.y, dy.z), __builtin_amdgcn_cubema(dy.x, dy.y, dy.z), n2, rho2);
-        lod = cube_lod_select(rc, rho2, nb->lvl);
+        const float nf = (float)rc.cube_n, n2q = 0.25f * (nf * nf);   // n^2 / 4: see cube_lod_partner_coords
+        rho2 = cube_lod_partner_coords<false>(fid, sc, tc, ma2x, ma, d, nb->vx, __builtin_amdgcn_cubeid(dx.x, dx.y, dx.z), __builtin_amdgcn_cubesc(dx.x, dx.y, dx.z),
+                                              __builtin_amdgcn_cubetc(dx.x, dx.y, dx.z), __builtin_amdgcn_cubema(dx.x, dx.y, dx.z), n2q, rho2);
+        rho2 = cube_lod_partner_coords<false>(fid, sc, tc, ma2x, ma, d, nb->vy, __builtin_amdgcn_cubeid(dy.x, dy.y, dy.z), __builtin_amdgcn_cubesc(dy.x, dy.y, dy.z),
+                                              __builtin_amdgcn_cubetc(dy.x, dy.y, dy.z), __builtin_amdgcn_cubema(dy.x, dy.y, dy.z), n2q, rho2);
+        lod = cube_lod_select<false>(rc, rho2, nb->lvl);
     }
     return cube_lod_finish(rc, fid, qs, qt, lod, nb->lvl);
 }
 // lock-step form (the march): the partners' cube coordinates come out of the whole-quad exchange -- which only the lanes without a certificate
-// enter (their quad mates, certain or gone through an early-out, are its helper lanes)
+// enter (their quad mates, certain or gone through an early-out, are its helper lanes).  The oracle's operations, bit for bit (round 6).
 __device__ __forceinline__ float cube_sample_lod_quad(const RenderConsts &rc, float px, float py, float pz, const QuadNb *nb) {
     const float qx = rc.cov_rot[0] * px + rc.cov_rot[2] * pz, qz = rc.cov_rot[1] * px + rc.cov_rot[3] * pz;
     const V3 d = {qx, py, qz};
@@ -1026,19 +1044,15 @@ __device__ __forceinline__ float cube_sample_lod_quad(const RenderConsts &rc, fl
     float qs, qt;
     cube_exact_quotients(sc, tc, ma, qs, qt);
     if (cube_lod_level0_certain(rc, qs, qt, ma, nb->e2)) return cube_lod_level0(rc, fid, qs, qt, nb->lvl);   // (never when !cube_lod_fast: 1 / C = inf)
-    CubeLod lod;
-    {
-        float rho2 = 0.0f;
-        QuadRegs &q = *nb->regs;
-        quad_exchange_coords(px, py, pz, rc.cov_rot[0], rc.cov_rot[1], rc.cov_rot[2], rc.cov_rot[3], q);  // q.fid, sc, tc, mas, qx, qz: the values above
-        if (!rc.cube_lod_fast)  // faces that are not a power of two (or above 1024): the general sampler on the partners' directions
-            return cube_sample_lod(rc, d, nb->vx, cube_dir_from_coords(q.fidx, q.scx, q.tcx, q.masx), nb->vy, cube_dir_from_coords(q.fidy, q.scy, q.tcy, q.masy), nb->lvl);
-        const float nf = (float)rc.cube_n, n2 = 0.25f * (nf * nf);   // n^2 / 4: see cube_lod_partner_coords
-        rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, nb->vx, q.fidx, q.scx, q.tcx, q.masx, n2, rho2);
-        rho2 = cube_lod_partner_coords(fid, sc, tc, ma2x, ma, d, nb->vy, q.fidy, q.scy, q.tcy, q.masy, n2, rho2);
-        lod = cube_lod_select(rc, rho2, nb->lvl);
-    }
-    return cube_lod_finish(rc, fid, qs, qt, lod, nb->lvl);
+    QuadRegs &q = *nb->regs;
+    quad_exchange_coords(px, py, pz, rc.cov_rot[0], rc.cov_rot[1], rc.cov_rot[2], rc.cov_rot[3], q);  // q.fid, sc, tc, mas, qx, qz: the values above
+    if (!rc.cube_lod_fast)  // faces that are not a power of two (or above 1024): the general sampler on the partners' directions (exact as it stands)
+        return cube_sample_lod(rc, d, nb->vx, cube_dir_from_coords(q.fidx, q.scx, q.tcx, q.masx), nb->vy, cube_dir_from_coords(q.fidy, q.scy, q.tcy, q.masy), nb->lvl);
+    const float nf = (float)rc.cube_n, n2q = 0.25f * (nf * nf);   // n^2 / 4: see cube_lod_partner_coords
+    constexpr bool EXACT = ATMO_LOD_LAMBDA_EXACT != 0;
+    float rho2 = cube_lod_partner_coords<EXACT>(fid, sc, tc, ma2x, ma, d, nb->vx, q.fidx, q.scx, q.tcx, q.masx, n2q, 0.0f);
+    rho2 = cube_lod_partner_coords<EXACT>(fid, sc, tc, ma2x, ma, d, nb->vy, q.fidy, q.scy, q.tcy, q.masy, n2q, rho2);
+    return cube_lod_finish(rc, fid, qs, qt, cube_lod_select<EXACT>(rc, rho2, nb->lvl), nb->lvl);
 }
 
 // The direct light march of one view sample (ATMO_LIGHT_DIRECT; SURVEY.md 8d "N view x M light steps"): the quantity the LUT
