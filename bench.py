@@ -58,7 +58,7 @@ SPEC_CLOCK_GHZ = 2.4
 #      while another wave's fast ops use the second: a mix costs max(4.1 S, 2.2 (S + F)).
 ISSUE_SPEC = {"valu": 2.0, "trans": 8.0}
 ISSUE_MEASURED = {"fast": 2.2, "slow": 4.1, "trans": 8.1, "poison_cycles_per_trans": 3.4}
-PROFILE_DIR = "profiles/round5"  # no fallback to earlier rounds: "clouds_high" meant the LOD-0 sampler there
+PROFILE_DIR = "profiles/round6"  # no fallback to earlier rounds: "clouds_high" meant the LOD-0 sampler there
 COMPACT_LIMIT = 6144         # bytes of the final stdout line (the driver keeps the last 8 KB of stdout)
 
 
@@ -72,18 +72,35 @@ def pmc_summary(workload, w, h):
     with open(os.path.join(ROOT, path)) as f:
         d = json.load(f)
     c = {k: v["mean_per_launch"] for k, v in d.get("pmc_per_launch", {}).items()}
-    out = {"source": path, "counters": c, "profiled_kernel_ns": d.get("kernel_stats", {}).get("avg_ns")}
+    out = {"source": path, "counters": c, "profiled_kernel_ns": d.get("kernel_stats", {}).get("avg_ns"), "build_id": d.get("build_id")}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         out["hbm_bytes"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    # these numbers are read from a committed file, not measured in this run -- they are the timed kernels' only if the library that was
+    # profiled is the library loaded now (same sources, same flags: build.source_id compiled in as atmo_build_id)
+    out["stale"] = out["build_id"] is None or out["build_id"] != loaded_build_id()
     return out
+
+
+_BUILD_ID = None
+
+
+def loaded_build_id():
+    global _BUILD_ID
+    if _BUILD_ID is None:
+        try:
+            from godot_atmosphere_shader_amd import _native
+            _BUILD_ID = _native.load().atmo_build_id().decode()
+        except Exception:  # an A/B library from before round 6 has no stamp: never equal to a profile's
+            _BUILD_ID = "unknown"
+    return _BUILD_ID
 
 
 def valu_roofline(pmc, kernel_avg_ms):
     """The resource that actually binds: VALU instruction issue.  Dynamic instruction counts per launch from the PMC
     passes (SQ_INSTS_VALU and its class counters, calibrated on single-opcode kernels: tools/calibrate_counters.sh),
     priced twice: at the guide's rates ("spec") and with the measured issue model.  Returns None without counters."""
-    if pmc is None or "SQ_INSTS_VALU" not in pmc["counters"] or not kernel_avg_ms:
-        return None
+    if pmc is None or pmc.get("stale") or "SQ_INSTS_VALU" not in pmc["counters"] or not kernel_avg_ms:
+        return None   # (no counters, or counters of another build: instruction counts of other kernels say nothing about these)
     c = pmc["counters"]
     n, t = c["SQ_INSTS_VALU"], c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
     # fast class upper bound: every f32 FMA/ADD/MUL (the counters cannot see SGPR operands) + the half of INT32 that is
@@ -139,6 +156,10 @@ def hbm_roofline(kernel_avg_ms, launches, launch_rays, pmc, isolated_ms=None):
         "frac": None if achieved is None else achieved / HBM_PEAK_GBS,
         "traffic": None if pmc is None else pmc.get("hbm_bytes"),
         "traffic_source": None if pmc is None else pmc["source"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bytes per launch)",
+        # true: the committed counters were collected on a library built from other sources than the one timed here (or carry no stamp)
+        "traffic_stale": None if pmc is None else bool(pmc.get("stale")),
+        "traffic_build_id": None if pmc is None else pmc.get("build_id"),
+        "build_id": loaded_build_id(),
         "kernel_avg_ms": kernel_avg_ms or None,
         "kernel_launches_timed": launches,
         "kernel_timing": "ONE pair of HIP events on the launch stream around the whole run of K un-bracketed launches of the timed "
@@ -209,7 +230,7 @@ def compact_record(result, detail_path=None):
         c["shard"] = c["shard"][:160]
     rec["config"] = c
     rec["roofline"] = _pick(result.get("roofline"), ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_avg_ms",
-                                                     "algorithmic_bytes_per_launch"))
+                                                     "algorithmic_bytes_per_launch", "traffic_stale", "build_id"))
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         rec["roofline"].setdefault(k, None)
     if result.get("valu_roofline"):

@@ -27,7 +27,7 @@ CORE_SYMBOLS = (
 # every symbol include/atmo_debug.h declares: experiment knobs and diagnostics (tests, bench.py, tools/)
 DEBUG_SYMBOLS = (
     "atmo_set_lane_split", "atmo_debug_motion_px", "atmo_get_feedback_stats", "atmo_set_timing", "atmo_get_timing", "atmo_host_layout_cubemap", "atmo_host_layout_shape",
-    "atmo_host_layout_lut", "atmo_host_cubemap_mip", "atmo_read_texture_layout", "atmo_selftest_exact_math", "atmo_debug_marched_optical_depth", "atmo_debug_log2_cr", "atmo_kernel_name",
+    "atmo_host_layout_lut", "atmo_host_cubemap_mip", "atmo_read_texture_layout", "atmo_selftest_exact_math", "atmo_debug_marched_optical_depth", "atmo_debug_log2_cr", "atmo_kernel_name", "atmo_build_id",
     "atmo_get_host_wait_stats", "atmo_get_split_stats", "atmo_debug_create_host_only", "atmo_debug_frame_constants",
 )
 EXPORTED_SYMBOLS = CORE_SYMBOLS + DEBUG_SYMBOLS
@@ -111,6 +111,7 @@ def load() -> C.CDLL:
         "atmo_host_layout_shape": (ip, [vp, ip, vp]),
         "atmo_host_layout_lut": (ip, [vp, ip, ip, vp]),
         "atmo_kernel_name": (cp, [vp]),
+        "atmo_build_id": (cp, []),
         "atmo_get_host_wait_stats": (ip, [vp, C.POINTER(C.c_uint)]),
         "atmo_get_split_stats": (ip, [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
         "atmo_render_tiles_split": (ip, [vp, C.POINTER(AtmoFrame), vp, vp, vp, ip, ip, vp]),

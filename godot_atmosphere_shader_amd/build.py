@@ -42,10 +42,24 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_id() -> str:
+    """What a library was built from: sha256 over the kernel / API sources, their headers and the compiler flags, 16 hex digits.  Compiled into the
+    library (atmo_build_id) and written into every profiles/round<N>/pmc_*.json by tools/profile.sh, so that bench.py can tell when committed
+    counters belong to other kernels than the ones it is timing (VERDICT r5 #11)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def build_native(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP extension if it is missing or stale; returns the library path."""
     if force or needs_build():
-        cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+        cmd = [_hipcc()] + HIPCC_FLAGS + [f'-DATMO_BUILD_ID="{source_id()}"', "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True, cwd=CSRC)

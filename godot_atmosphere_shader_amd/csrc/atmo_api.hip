@@ -751,6 +751,10 @@ int feedback_state(AtmoContext *ctx, int gx, int gy, int split, hipStream_t s, A
 extern "C" {
 
 int atmo_abi_version(void) { return ATMO_ABI_VERSION; }
+#ifndef ATMO_BUILD_ID
+#define ATMO_BUILD_ID "unstamped"   /* a library not built through godot_atmosphere_shader_amd/build.py (tools/ab_build.sh ...) */
+#endif
+const char *atmo_build_id(void) { return ATMO_BUILD_ID; }
 
 int atmo_device_count(void) {
     int n = 0;

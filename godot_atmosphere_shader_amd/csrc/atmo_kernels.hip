@@ -1956,7 +1956,7 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
     if constexpr (LOD) {  // the declared sampler's per-level constants (cube_level_table_fill), written by every wave before any lane leaves
         __shared__ f32x4 lvl_lds[CUBE_LEVEL_TABLE + LOG2CR_ROWS];
         cube_level_table_fill(rc, lvl_lds, lane);
-        log2_cr_table_fill(lvl_lds + CUBE_LEVEL_TABLE, lane);   // (round 6) the table of the declared sampler's logarithm
+        log2_cr_table_fill(lvl_lds + CUBE_LEVEL_TABLE, lane);   // (round 6) the table of the declared sampler's logarithm (not what the kernels' +1 % is: ab_lambda_exact.txt, 8)
         lvl_table = lvl_lds;
     }
     // SPLIT = 2: lanes 2r, 2r+1 share ray r; a wave covers WAVE_W x (32 / WAVE_W) pixels, the workgroup TILE_W x TILE_H / 2

@@ -74,6 +74,11 @@ int atmo_debug_marched_optical_depth(AtmoContext *ctx, int n, const float *pos_x
  * on the same table (tools/make_log2_table.py); tests/test_gpu_parity.py holds the two to the same bits. */
 int atmo_debug_log2_cr(AtmoContext *ctx, int n, const float *x, float *out);
 
+/* What this library was built from: 16 hex digits of sha256 over the two .hip sources under csrc/, their headers and the compiler flags (godot_atmosphere_shader_amd/build.py,
+ * source_id), "unstamped" for a build made any other way.  tools/profile.sh stamps the rocprofv3 counter files with it, bench.py compares
+ * (`traffic_stale`): counters of other kernels than the ones being timed are not presented as theirs. */
+const char *atmo_build_id(void);
+
 /* Name of the kernel the most recent atmo_render of this context launched, "atmo_render_kernel<FLAGS, LSTEPS, SPLIT>"
  * (before the first launch: the one-lane-per-ray form), for matching rocprofv3 kernel traces. */
 const char *atmo_kernel_name(AtmoContext *ctx);
@@ -91,8 +96,10 @@ int atmo_get_host_wait_stats(AtmoContext *ctx, unsigned *device_syncs);
 /*
  * The host side WITHOUT a device (round 5; for the CPU test suite and the sanitizer build of libatmo_hip.so, `make sanitize-host`): a
  * context that owns nothing on a GPU -- the uniform table (atmo_set_param_f32 / atmo_get_param_f32), atmo_set_precision,
- * atmo_set_sampler_lod, atmo_set_host_double_precision, atmo_set_target_cleared work on it; every entry point that needs the device
- * fails with ATMO_E_HIP; atmo_destroy frees it.  Arguments as atmo_create (minus the device index).
+ * atmo_set_sampler_lod, atmo_set_host_double_precision, atmo_set_target_cleared work on it; an entry point that needs the device
+ * fails -- with ATMO_E_ARG / ATMO_E_STATE where its argument and state checks come first, with ATMO_E_HIP (hipSetDevice(-1)) where the device is
+ * the first thing it touches -- and never succeeds; atmo_set_timing / atmo_get_timing only keep their bookkeeping (no events exist without draws);
+ * atmo_destroy frees it.  Arguments as atmo_create (minus the device index).
  * atmo_debug_frame_constants evaluates the per-frame (pixel-independent) expressions of the shader exactly as a draw would
  * (fill_consts: main:136,164; v2:47-51; clouds:104-115,186-206,260-261,285-294; the level-0 certificate's constant for faces of
  * cube_n texels) and returns them as floats, in the order documented at its definition in csrc/atmo_api.hip (81 values).

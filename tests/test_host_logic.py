@@ -421,6 +421,38 @@ def test_bench_final_line_is_compact():
     assert rec3["config"]["mrays_per_s_gather_every"] == 1.25
 
 
+def test_bench_marks_counters_of_another_build_as_stale(tmp_path, monkeypatch):
+    """roofline.traffic and valu_roofline are READ from committed rocprofv3 summaries (profiles/round<N>/pmc_*.json), not measured in the
+    run that prints them.  Every summary now carries the build id of the library that was profiled (tools/profile.sh -> atmo_build_id: sha256 of the
+    kernel sources, headers and flags); when it differs from the loaded library's -- a kernel changed and nobody re-profiled -- the line says
+    traffic_stale: true and carries no valu_roofline."""
+    import json
+
+    import bench
+    from godot_atmosphere_shader_amd import _native as N, build
+
+    assert N.load().atmo_build_id().decode() == build.source_id() == bench.loaded_build_id()
+    d = tmp_path / "profiles" / "roundX"
+    d.mkdir(parents=True)
+    counters = {k: {"dispatches": 6, "mean_per_launch": v} for k, v in dict(FETCH_SIZE=8100.0, WRITE_SIZE=32400.0, SQ_INSTS_VALU=5.0e7, SQ_INSTS_VALU_TRANS_F32=4.0e6).items()}
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "PROFILE_DIR", "profiles/roundX")
+    for stamp, stale in ((build.source_id(), False), ("0123456789abcdef", True), (None, True)):
+        doc = {"pmc_per_launch": counters, "kernel_stats": {"avg_ns": 87000.0}}
+        if stamp:
+            doc["build_id"] = stamp
+        (d / "pmc_direct32x8_1920x1080.json").write_text(json.dumps(doc))
+        pmc = bench.pmc_summary("direct32x8", 1920, 1080)
+        assert pmc["stale"] is stale and pmc["hbm_bytes"] == (8100.0 + 32400.0) * 1024.0
+        rf = bench.hbm_roofline(0.087, 20, 1920 * 1080, pmc)
+        assert rf["traffic_stale"] is stale and rf["build_id"] == build.source_id() and rf["traffic"] == pmc["hbm_bytes"]
+        vr = bench.valu_roofline(pmc, 0.087)
+        assert (vr is None) == stale
+        rec = bench.compact_record({"metric": "m", "value": 1.0, "config": {}, "roofline": rf, **({"valu_roofline": vr} if vr else {})})
+        assert rec["roofline"]["traffic_stale"] is stale and ("valu_roofline" in rec) == (not stale)
+    assert bench.pmc_summary("no_such_workload", 1, 1) is None
+
+
 def test_bench_detail_file(tmp_path, monkeypatch):
     import json
 

@@ -11,6 +11,8 @@ R=$PWD
 PY=$(python3 -c 'import sys,os;print(os.path.realpath(sys.executable))')
 OUT=$R/gpurun_out/prof_${WL}_${W}x${H}$( [ "$POSE" = P_space ] || echo _$POSE )
 mkdir -p $OUT
+# which kernels these counters belong to (bench.py compares it with the library it is timing: traffic_stale)
+$PY -c "import sys; sys.path.insert(0, '$R'); from godot_atmosphere_shader_amd import _native as N; print(N.load().atmo_build_id().decode())" > $OUT/build_id.txt 2>/dev/null
 export TMPDIR=/tmp
 cd /tmp
 ARGS="--workload $WLN --sampler $SAMPLER --width $W --height $H --pose $POSE --no-cpu-baseline --also ,"

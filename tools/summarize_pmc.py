@@ -5,6 +5,9 @@ import collections, csv, glob, json, os, sys
 
 src, dst = sys.argv[1], sys.argv[2]
 out = {"source": os.path.basename(src)}
+bid = os.path.join(src, "build_id.txt")
+if os.path.exists(bid):   # round 6: what the profiled library was built from (build.source_id)
+    out["build_id"] = open(bid).read().strip()
 stats = glob.glob(os.path.join(src, "stats", "*kernel_stats.csv"))
 if stats:
     for r in csv.DictReader(open(stats[0])):
