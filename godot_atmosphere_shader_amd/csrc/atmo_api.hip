@@ -86,8 +86,10 @@ struct DeviceBuffer {
 // Largest textures that get a float copy of their footprints (tools/texsize_probe.py, profiles/round3/ab_float_footprints.txt).  Of the cubemap
 // a frame touches only the visible part: the copy wins up to the 1024^2 faces the fp32-addressed sampler handles.  The shape volume repeats, so
 // every XCD touches all of it in every frame, and its copy has to fit into an XCD's 4 MB L2 beside everything else: at 32^3 (0.5 MB) it is worth
-// 4 %, at 64^3 (4 MB) 1 % of the kernel time for 27 MB more fabric traffic per 1920x1080 frame, at 128^3 (34 MB) it COSTS 50 %.
-constexpr int F4_MAX_CUBE_N = 1024, F4_MAX_SHAPE_N = 48;
+// 4 %, at 64^3 (4 MB) it was worth 1 % of round 3's kernel time for 27 MB more fabric traffic per 1920x1080 frame -- and is worth 2-5 % of round 6's
+// (the kernels issue 1.4x fewer VALU instructions since: the texture path is what they wait for; profiles/round6/ab_gathers.txt) --, at 128^3 (34 MB)
+// it COSTS 50 %.
+constexpr int F4_MAX_CUBE_N = 1024, F4_MAX_SHAPE_N = 64;   // (64 since round 6: profiles/round6/ab_gathers.txt; ATMO_F4_SHAPE_MAX overrides for A/B)
 
 thread_local std::string g_create_error = "";
 
@@ -101,6 +103,7 @@ struct AtmoContext {
     Params p;
     DeviceBuffer lut, blue, shape, cube;
     DeviceBuffer cube_f4, shape_f4;  // float copies of the level-0 cubemap / shape footprints (16 B each): what the precise samplers read
+    int f4_max_shape_n = F4_MAX_SHAPE_N;   // ATMO_F4_SHAPE_MAX (A/B): largest volume that gets the float copy
     DeviceBuffer lut4;  // footprint copy of `lut` (derived on the device whenever `lut` is written): what the kernels sample
     int lut_w = 0, lut_h = 0, shape_n = 0, cube_n = 0;
     int cube_levels = 0;                 // mip levels bound (footprint arrays packed level after level in `cube`)
@@ -817,6 +820,7 @@ int atmo_create(int device, int variant, int view_steps, int cloud_steps, int li
     if (const char *ev = std::getenv("ATMO_LANE_SPLIT")) ctx->env_split = ev[0] == '1' ? 1 : (ev[0] == '2' ? 2 : 0);
     if (const char *ev = std::getenv("ATMO_TILE_FEEDBACK")) ctx->env_feedback = ev[0] == '1' ? 1 : 0;
     if (const char *ev = std::getenv("ATMO_F4")) ctx->f4_footprints = std::atoi(ev) & 3;
+    if (const char *ev = std::getenv("ATMO_F4_SHAPE_MAX")) ctx->f4_max_shape_n = std::atoi(ev);
     if (const char *ev = std::getenv("ATMO_LOD0_CERT")) ctx->env_lod0_cert = ev[0] == '0' ? 0 : 1;
     if (const char *ev = std::getenv("ATMO_HEAVY_SPLIT")) ctx->heavy_split = ev[0] == '0' ? 0 : (ev[0] == '2' ? 2 : 1);
     if (const char *ev = std::getenv("ATMO_HEAVY_SPLIT_RATIO")) ctx->heavy_split_ratio = (float)std::atof(ev);
@@ -1045,7 +1049,7 @@ int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h,
         if (rc == ATMO_OK) rc = stage_texels(ctx, data, (size_t)w * w * w, memory, s, 0, &raw);
         if (rc == ATMO_OK) rc = tex_alloc(ctx, ctx->shape, (size_t)w * w * w * sizeof(uint32_t));
         // the float copy (16 B per footprint) only for volumes small enough to stay L2-resident; larger ones are sampled from the byte footprints
-        const bool f4 = w <= F4_MAX_SHAPE_N;
+        const bool f4 = w <= ctx->f4_max_shape_n;
         if (rc == ATMO_OK) { if (f4) rc = tex_alloc(ctx, ctx->shape_f4, (size_t)w * w * w * 16); else dev_free(ctx->shape_f4); }
         if (rc != ATMO_OK) {
             dev_free(ctx->shape);

@@ -133,7 +133,7 @@ int atmo_get_param_f32(AtmoContext *ctx, const char *name, float *v, int n);
  * that sends updates down its draw stream pays nothing at all: stream order is all there is (a marker costs 3-4 us
  * per draw; a host with a separate upload stream pays that on its draws).
  * Device memory per bound texture: 4 bytes per texel position for the two cloud textures (bilinear footprints) plus, up to
- * 1024^2 faces (cubemap, whole chain) and 48^3 (shape volume), a float copy of the same footprints at 16 bytes each, which
+ * 1024^2 faces (cubemap, whole chain) and 64^3 (shape volume; 48^3 until round 6), a float copy of the same footprints at 16 bytes each, which
  * the precise cloud kernels sample (same bits, fewer instructions); larger textures are sampled from the 4-byte footprints.
  */
 int atmo_set_texture(AtmoContext *ctx, const char *name, int kind, int w, int h, int d, int mips,

@@ -1784,12 +1784,12 @@ def test_float_footprint_copies_do_not_change_a_bit(monkeypatch):
     """Round 3: the precise samplers read a float copy of the cloud textures' footprints (four exact byte / 255 values per 16-byte
     footprint: one gather, no conversions).  The copy holds the very floats the byte path computes, so frames are bit-identical with
     the copy (default) and without it (ATMO_F4=0, read once in atmo_create) -- LOD 0 and implicit LOD, both cloud light modes -- and
-    a texture UPDATE refreshes the copy too.  (The shape volume gets a copy only up to 48^3, the cubemap up to 1024^2 faces.)"""
+    a texture UPDATE refreshes the copy too.  (The shape volume gets a copy up to 64^3 -- 48^3 until round 6 --, the cubemap up to 1024^2 faces.)"""
     params = demo_params()
     w, h = 320, 180
     for config_name, lod, pose, shape_n in (("clouds_high", False, "P_space", 32), ("clouds_high_rm", False, "P_clouds", 32),
                                             ("clouds_high_rm", True, "P_space", 64), ("clouds", True, "P_limb", 32)):
-        tex = demo_textures(256, shape_n)  # 32^3: cubemap AND shape volume have a float copy; 64^3 (the demo's): the cubemap only
+        tex = demo_textures(256, shape_n)  # cubemap AND shape volume have a float copy at both sizes (64^3, the demo's, since round 6)
         cam = S.Camera.from_pose(w, h, pose)
         depth = S.depth_ground_sphere(cam)
         frames = []
@@ -1820,7 +1820,7 @@ def test_float_footprint_copies_do_not_change_a_bit(monkeypatch):
 
 
 def test_shape_volume_too_large_for_a_float_copy_still_matches_the_oracle(oracle32):
-    """A 160^3 shape volume (not a power of two: the general wrap; far above the 48^3 limit of the float copy) is sampled
+    """A 160^3 shape volume (not a power of two: the general wrap; far above the 64^3 limit of the float copy) is sampled
     from the byte footprints; parity against the oracle as for every other scene."""
     tex, params = demo_textures(), demo_params()
     tex = dict(tex, shape=S.make_shape_texture(160))
