@@ -114,8 +114,13 @@ typedef struct OracleConfig {
     int32_t light_steps;     /* 0 => baked LUT (reference); >0 => inline sun-ray march of that many steps */
     int32_t lite;            /* 1 => ATMOSPHERE_LITE: compute_atmosphere of atmosphere_funcs_v1.gdshaderinc */
     int32_t cube_lod;        /* 0 => cubemap LOD 0 (stated convention of round 1); 1 => implicit LOD from 2x2 pixel quads, see
-                                sample_cube_lod in atmo_oracle.c (needs OracleTextures.cube_mips > 1) */
+                                sample_cube_lod in atmo_oracle.c (needs OracleTextures.cube_mips > 1); 2 => the same with LOCK-STEP quads
+                                (round 6): a partner that does not reach the fetch -- discarded, cloud gates false, outside the viewport --
+                                contributes the coordinate its lane would hold had it executed the same statements on its own inputs
+                                (what llvmpipe's masked SIMD lanes and a GPU's helper invocations do: profiles/round5/mesa_pin.txt 11e) */
     int32_t double_precision;/* 1 => DOUBLE_PRECISION (main:25,118-125): the engine hands INV_VIEW_MATRIX with its origin negated */
+    int32_t lod_log2_fast;   /* CHECKER OPTION (no product counterpart): 1 => lambda's log2 piecewise linear (exponent + mantissa - 1), as
+                                llvmpipe's level-of-detail unit takes it (mesa_pin.txt 11b); for comparisons with Mesa's frames only */
 } OracleConfig;
 
 #ifdef __cplusplus

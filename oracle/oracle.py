@@ -80,6 +80,7 @@ class OracleConfig(C.Structure):
         ("lite", C.c_int32),
         ("cube_lod", C.c_int32),
         ("double_precision", C.c_int32),
+        ("lod_log2_fast", C.c_int32),
     ]
 
 
@@ -269,7 +270,8 @@ class Oracle:
     def make_config(config: dict) -> OracleConfig:
         return OracleConfig(int(config["view_steps"]), int(config.get("cloud_steps", 0)),
                             int(config.get("cloud_light_rm", 0)), int(config.get("light_steps", 0)),
-                            int(config.get("lite", 0)), int(config.get("cube_lod", 0)), int(config.get("double_precision", 0)))
+                            int(config.get("lite", 0)), int(config.get("cube_lod", 0)), int(config.get("double_precision", 0)),
+                            int(config.get("lod_log2_fast", 0)))
 
     # ---- entry points --------------------------------------------------------------------
     def render(self, params: dict, textures: dict, config: dict, frame: dict, depth: np.ndarray,
