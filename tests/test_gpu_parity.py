@@ -952,6 +952,65 @@ def test_render_is_hip_graph_capturable():
     node.close()
 
 
+def test_tile_list_draws_refuse_graph_capture():
+    """a tile-list draw keeps a bounded copy of the caller's list in a context-owned buffer that grows on demand -- a graph that had recorded it
+    would replay on memory a later, longer list has freed.  On a capturing stream atmo_render_tiles / atmo_render_tiles_split return ATMO_E_STATE (stated in
+    atmo.h) and leave the capture usable: atmo_render into the same graph still works, and outside a capture the draw works as before."""
+    from godot_atmosphere_shader_amd import _native as N
+
+    tex = demo_textures(cube_n=64, shape_n=32)
+    cam = S.Camera.from_pose(320, 180, "P_space")
+    depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
+    node = make_node("clouds_high", tex)
+    ref = node.render(cam, depth).clone()
+    cost, tw, th = node.measure_tile_costs(cam, depth)
+    tiles = torch.arange(cost.size, dtype=torch.int32, device="cuda")
+    frame = node.prepare_frame(cam)
+    out = torch.zeros_like(ref)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            with pytest.raises(N.AtmoError) as ei:
+                node.render_tiles_prepared(frame, depth.data_ptr(), out.data_ptr(), tiles.data_ptr(), tiles.numel(), side.cuda_stream)
+            assert ei.value.code == N.ATMO_E_STATE
+            node.render_prepared(frame, depth.data_ptr(), out.data_ptr(), side.cuda_stream)
+    torch.cuda.synchronize()
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    out.zero_()
+    node.render_tiles_prepared(frame, depth.data_ptr(), out.data_ptr(), tiles.data_ptr(), tiles.numel(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    node.close()
+
+
+def test_whole_frame_on_two_lanes_per_ray_has_a_cost_map_of_its_own_grid():
+    """the cost-index remap of the heavy-tile split -- a half-height tile's cost belongs to the one-lane grid's tile -- was compiled into
+    every SPLIT == 2 declared-sampler kernel, so a WHOLE frame drawn on two lanes per ray (atmo_set_lane_split 2; bench --shard tiles --lanes 2) got its costs
+    written into the top half of its own (twice as tall) cost map and zeros below: lpt_strips then dealt the lower half of the frame as free.  The remap applies
+    only to the heavy launch now (RenderConsts.cost_rows_halved)."""
+    tex = demo_textures(cube_n=64, shape_n=32)
+    cam = S.Camera.from_pose(640, 360, "P_ground")   # every pixel marches: every tile has a cost
+    depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
+    for config_name in ("clouds_high_rm", "clouds_high"):
+        one = make_node(config_name, tex)
+        c1, tw1, th1 = one.measure_tile_costs(cam, depth)
+        one.close()
+        two = make_node(config_name, tex, lane_split=2)
+        c2, tw2, th2 = two.measure_tile_costs(cam, depth)
+        assert two.kernel_name.endswith(", 2>") and int(two.kernel_name.split("<")[1].split(",")[0]) & 32, two.kernel_name
+        two.close()
+        assert (tw2, th2) == (tw1, th1 // 2) and c2.shape == (2 * c1.shape[0], c1.shape[1])
+        assert (c2 > 0).all(), f"{config_name}: {int((c2 == 0).sum())} tiles of the two-lane frame's cost map are empty"
+        # ... and it is the same picture's: the lower half of the frame holds the share of the cost it holds in the one-lane map
+        share1 = c1[c1.shape[0] // 2:].astype(np.float64).sum() / c1.astype(np.float64).sum()
+        share2 = c2[c2.shape[0] // 2:].astype(np.float64).sum() / c2.astype(np.float64).sum()
+        assert abs(share2 - share1) < 0.15, (config_name, share1, share2)
+
+
 @pytest.mark.parametrize("config_name,pose,sampler", [("no_clouds_32x8_direct", "P_space", "declared"), ("clouds_high_rm", "P_ground", "declared"),
                                                       ("clouds_high_rm", "P_ground", "lod0"), ("v1_clouds", "P_space", "declared"),
                                                       ("v1_clouds", "P_space", "lod0")])
