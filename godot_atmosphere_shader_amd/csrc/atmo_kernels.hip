@@ -1626,17 +1626,13 @@ __device__ __forceinline__ float rm_sample_weight(RmRecurrence &s, float density
 template <bool RM, bool PRECISE, int SPLIT, bool LOD = false>
 __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc_in, V3 dir_m, float t_begin, float t_end, float jitter, int half,
                                                QuadRegs *qregs = nullptr, const f32x4 *lvl = nullptr) {
-    // ATMO_RM_INPLACE (1 since round 5): under the declared sampler the raymarched light is evaluated IN PLACE with one lane per ray as well -- this
-    // function instead of the lit-sample queue (march_clouds_rm_queue<.., LOD>, which 0 selects: round 4's kernel, the A/B arm).  Same bits (the
-    // queue's arithmetic, above); 73 VGPRs and no queue in LDS instead of 86 / 15 KB: six waves per SIMD instead of five, no twelve-word entries through
-    // LDS, no second whole-quad block per lit sample.  Measured (profiles/round5/ab_rm_inplace.txt): 3840x2160 -11.4 % (1.355 -> 1.201 ms, BASELINE
-    // configs[3]), 2560x1440 -9.4 %, from the ground -10.4 %, inside the layer -11..-12.5 %, from the limb -4.7 %, 1920x1080 pose P_space +1.6 %
-    // (bound by its tail there).  NOT for the level-0 sampler: its queue kernel (six-word entries, 10 KB, taps unrolled) is 11-30 % faster than its
-    // in-place form.
-#ifndef ATMO_RM_INPLACE
-#define ATMO_RM_INPLACE 1
-#endif
-    static_assert(!(LOD && RM) || SPLIT == 2 || ATMO_RM_INPLACE, "raymarched light under the declared sampler, one lane per ray: the lit-sample queue");
+    // Under the declared sampler the raymarched light is evaluated IN PLACE with one lane per ray as well (round 5) -- this function instead of the
+    // lit-sample queue, whose arithmetic it keeps (same bits): 73 VGPRs and no queue in LDS instead of 86 / 15 KB, six waves per SIMD instead of five, no
+    // twelve-word entries through LDS, no second whole-quad block per lit sample.  Measured then (profiles/round5/ab_rm_inplace.txt): 3840x2160 -11.4 %
+    // (BASELINE configs[3]), from the ground -10.4 %, 1920x1080 pose P_space +1.6 %; on round 6's kernels the queue form loses everywhere, by 2-22 %, also
+    // when pushed to six waves (profiles/round6/ab_rm_tile_choice.txt, 3) -- its declared-sampler branches, kept through round 5 as the A/B arm
+    // ATMO_RM_INPLACE=0, are gone (the last commit that holds them: 9e43032).  NOT for the level-0 sampler: its queue kernel (six-word entries, 10 KB, taps
+    // unrolled) is 11-30 % faster than its in-place form.
     // LOD && SPLIT == 2 (round 5, the heavy tiles of a frame): the two lanes of a ray are lane and lane ^ 4, a pixel quad keeps four consecutive
     // lanes (all at the same step); with RM the light taps are evaluated in place -- the partners' sample positions come from the quad
     // mates by the same whole-quad block the queue uses at enqueue -- and the recurrence runs in the lit-sample queue's arithmetic
@@ -1759,8 +1755,7 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc_in, V3 dir
 }
 
 // ---- raymarch_cloud with raymarched light, lit samples regrouped through LDS -------------------------------
-// (Since round 5 the kernels of the LEVEL-0 sampler and of the fast cloud mode: under the declared sampler the raymarched light is evaluated in place,
-//  march_clouds<RM, .., LOD> / ATMO_RM_INPLACE -- the same bits, 11 % faster at 3840x2160.  The LOD branches below are round 4's kernel, the A/B arm.)
+// (The kernels of the LEVEL-0 sampler and of the fast cloud mode: under the declared sampler the raymarched light is evaluated in place, march_clouds<RM, .., LOD>.)
 // In clouds_high_rm only the samples with density > 0 need get_light_raymarched (6 more density evaluations each), and in a
 // lock-step march they are a changing subset of the wave: 21 % of the issued lanes idle (VALUUtilization 78.7 %,
 // profiles/round2/pmc_clouds_high_rm_1920x1080.json).  The light value does not feed back into the march -- it only scales
@@ -1784,29 +1779,20 @@ __device__ __forceinline__ float2 march_clouds(const RenderConsts &rc_in, V3 dir
 #endif
 // (Round 3, measured and dropped: summing a half-chunk one half later so that no partial batch is lit at the chunk ends fills the
 // batches to 97 % instead of 93 % -- tools/rmq_stats.py -- and is 0.7-2 % slower: profiles/round3/rmq_stage_stats.txt.)
-// The declared-sampler kernel's entries are twice as long (12 x 128 queue words per wave): with 8 slot rows its workgroup needs 16.9 KB of LDS, 9
-// workgroups = 4.5 waves per SIMD, and since the level-0 certificate (round 4) the kernel is short enough for that to bind (a wave waits 34 % of its
-// cycles, occupancy 51 %: profiles/round4/pmc_clouds_high_rm_3840x2160.json).  5 rows: 15.1 KB, 10 workgroups = the 5 waves its 90 VGPRs allow:
-// -3.5 % at 1920x1080 and 3840x2160, -4.5 % from the ground, +3 % on the tail-bound limb frame; 6 rows (still 9 workgroups) +2 %, 4 rows -3 %, 3 rows
-// -2.5 % (more chunk-end partial batches); the LOD-0 kernel loses 3 % with 4 rows (profiles/round4/lod0_certificate.txt, section 6).
-#ifndef ATMO_RMQ_CHUNK_LOD
-#define ATMO_RMQ_CHUNK_LOD 5
-#endif
 constexpr int RMQ_CAP = 128;
-constexpr int rmq_chunk(bool lod) { return lod ? ATMO_RMQ_CHUNK_LOD : ATMO_RMQ_CHUNK; }
-constexpr int rmq_words_per_wave(bool lod) { return (lod ? 12 : 6) * RMQ_CAP + rmq_chunk(lod) * 64; }
+constexpr int RMQ_CHUNK = ATMO_RMQ_CHUNK;
+constexpr int RMQ_WORDS_PER_WAVE = 6 * RMQ_CAP + RMQ_CHUNK * 64;
 
-template <bool PRECISE, bool LOD = false>
+template <bool PRECISE>
 __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, V3 dir_m, float t_begin, float t_end, float jitter,
-                                                        float *__restrict__ lds, QuadRegs *qregs = nullptr, const f32x4 *lvl = nullptr) {
+                                                        float *__restrict__ lds) {
     // (no cloud_uniforms_to_vgprs here: eight more VGPRs take the declared-sampler kernel from 88 to 103 -- 4 waves per SIMD, +9 % -- and under a
     //  96-VGPR bound it spills for a gain of 1 %; three or four of them (93-95 VGPRs, one short of the step) bought 0.5-1.5 %; the level-0 kernel,
     //  bound to 80 VGPRs, is 0.5-1.3 % slower with them: profiles/round4/ab_vgpr_uniforms.txt)
     float *qx = lds, *qy = lds + RMQ_CAP, *qz = lds + 2 * RMQ_CAP, *qh = lds + 3 * RMQ_CAP;
     uint32_t *qs = reinterpret_cast<uint32_t *>(lds + 4 * RMQ_CAP);
     float *qd = lds + 5 * RMQ_CAP;  // the sample's own density = light tap 0
-    float *qn = lds + 6 * RMQ_CAP;  // LOD: partner positions, 6 arrays of RMQ_CAP
-    float *slot = lds + (LOD ? 12 : 6) * RMQ_CAP;
+    float *slot = lds + 6 * RMQ_CAP;
     const int lane = threadIdx.x & 63;
     const unsigned long long active = __builtin_amdgcn_ballot_w64(true);  // the lanes of this wave that march
     auto rank_in = [&](unsigned long long m) {
@@ -1836,14 +1822,6 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
     RmRecurrence rec = {1.0f, 1.0f, 0.0f};
     const float scale_step = rc.cloud_density_scale * step_len;
     const float neg_scale_step_log2e = -scale_step * LOG2E;
-    QuadNb nb;
-    if (LOD) {  // the partners that march (= reach the texture() calls of this march): the quad mates among the active lanes
-        nb.vx = (active >> (lane ^ 1)) & 1ull; nb.vy = (active >> (lane ^ 2)) & 1ull;
-        nb.lvl = lvl; nb.regs = qregs;
-        nb.e2 = quad_march_spread2(rc, px, py, pz, ddx, ddy, ddz, nb.vx, nb.vy);
-        asm volatile("" : "+v"(sx), "+v"(sy), "+v"(sz));
-    }
-
     auto light_batch = [&](int avail) {  // phase B: lane `rank` lights queue entry qhead + rank
         RMQ_STAT_BATCH(avail);
         RMQ_STAT_B_BEGIN();
@@ -1851,26 +1829,14 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
         if (rank < avail) {
             const int e = (qhead + rank) & (RMQ_CAP - 1);
             const float ex = qx[e], ey = qy[e], ez = qz[e], eh = qh[e], ed = qd[e];
-            uint32_t sl = qs[e];
-            QuadNb enb;
-            if (LOD) {
-                enb.vx = (sl >> 10) & 1u; enb.vy = (sl >> 11) & 1u; enb.lvl = lvl; enb.regs = nullptr;
-                enb.px = V3{qn[e], qn[RMQ_CAP + e], qn[2 * RMQ_CAP + e]};
-                enb.py = V3{qn[3 * RMQ_CAP + e], qn[4 * RMQ_CAP + e], qn[5 * RMQ_CAP + e]};
-                enb.k = V3{0.0f, 0.0f, 0.0f};
-                // the same three differences at every tap of this sample (the partners add the same offset), up to an ulp of |p| (the reserve in C)
-                auto dist2 = [&](V3 p) { const float a = p.x - ex, b = p.y - ey, c = p.z - ez; return __builtin_fmaf(a, a, __builtin_fmaf(b, b, c * c)); };
-                enb.e2 = cube_lod_scaled_spread(rc, fmaxf(enb.vx ? dist2(enb.px) : 0.0f, enb.vy ? dist2(enb.py) : 0.0f) * 1.001f);
-                sl &= 1023u;
-            }
-            const float light = light_raymarched<PRECISE, LOD>(rc, ex, ey, ez, eh, ed, sx, sy, sz, LOD ? &enb : nullptr);
+            const uint32_t sl = qs[e];
+            const float light = light_raymarched<PRECISE, false>(rc, ex, ey, ez, eh, ed, sx, sy, sz, nullptr);
             slot[sl] = light * slot[sl];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         RMQ_STAT_B_END();
     };
 
-    constexpr int RMQ_CHUNK = rmq_chunk(LOD);
     for (int c0 = 0; c0 < steps; c0 += RMQ_CHUNK) {
         const int cn = steps - c0 < RMQ_CHUNK ? steps - c0 : RMQ_CHUNK;
         uint32_t lit_bits = 0;
@@ -1879,7 +1845,7 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
             const float r2 = px * px + py * py + pz * pz;
             if (wave_may_be_in_layer(rc, r2)) {
                 cloud_height_r2(rc, r2, r, hr);
-                density = cloud_density<true, PRECISE, LOD, LOD>(rc, px, py, pz, hr, LOD ? &nb : nullptr);
+                density = cloud_density<true, PRECISE>(rc, px, py, pz, hr);
             }
             const bool lit = density > 0.0f;
             float w = 0.0f;
@@ -1889,16 +1855,7 @@ __device__ __forceinline__ float2 march_clouds_rm_queue(const RenderConsts &rc, 
                 const int e = (qcount + rank_in(lm)) & (RMQ_CAP - 1);
                 const uint32_t sl = (uint32_t)(k * 64 + lane);
                 qx[e] = px; qy[e] = py; qz[e] = pz; qh[e] = hr; qd[e] = density;
-                if (LOD) {
-                    // the light taps of this sample difference the partners' tap positions: their sample positions, read from the partner lanes
-                    // (which march in lock-step but may be unlit, i.e. disabled here: whole-quad mode again)
-                    quad_exchange_positions(px, py, pz, *qregs);
-                    qn[e] = qregs->fidx; qn[RMQ_CAP + e] = qregs->scx; qn[2 * RMQ_CAP + e] = qregs->tcx;
-                    qn[3 * RMQ_CAP + e] = qregs->fidy; qn[4 * RMQ_CAP + e] = qregs->scy; qn[5 * RMQ_CAP + e] = qregs->tcy;
-                    qs[e] = sl | (nb.vx ? 1024u : 0u) | (nb.vy ? 2048u : 0u);
-                } else {
-                    qs[e] = sl;
-                }
+                qs[e] = sl;
                 slot[sl] = w;
                 lit_bits |= 1u << k;
             }
@@ -2081,9 +2038,9 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
                 dir_m.y = M[1] * dir.x + M[5] * dir.y + M[9] * dir.z;
                 dir_m.z = M[2] * dir.x + M[6] * dir.y + M[10] * dir.z;
                 float2 rr;
-                if constexpr (RM && SPLIT == 1 && !(LOD && ATMO_RM_INPLACE)) {
-                    __shared__ float rmq[(TILE_W * TILE_H / 64) * rmq_words_per_wave(LOD)];
-                    rr = march_clouds_rm_queue<PRECISE, LOD>(rc, dir_m, c0, c1, jitter, rmq + wave * rmq_words_per_wave(LOD), &qregs, lvl_table);
+                if constexpr (RM && SPLIT == 1 && !LOD) {
+                    __shared__ float rmq[(TILE_W * TILE_H / 64) * RMQ_WORDS_PER_WAVE];
+                    rr = march_clouds_rm_queue<PRECISE>(rc, dir_m, c0, c1, jitter, rmq + wave * RMQ_WORDS_PER_WAVE);
                 } else {
                     rr = march_clouds<RM, PRECISE, SPLIT, LOD>(rc, dir_m, c0, c1, jitter, half, &qregs, lvl_table);
                 }
@@ -2153,9 +2110,9 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
 #ifndef ATMO_MIN_WAVES  // __launch_bounds__ second argument: minimum waves per SIMD the register allocation must allow (0 = none).
 #define ATMO_MIN_WAVES 6  // 6: only atmo_render_kernel<19 / 23, ..> change (84 -> 80 VGPRs); see ATMO_RMQ_CHUNK
 #endif
-#ifndef ATMO_MIN_WAVES_LOD_RM  // the declared-sampler form of that kernel: bound 4 = no constraint in practice.  Round 3: natural 111 VGPRs = 4 waves, and
-#define ATMO_MIN_WAVES_LOD_RM 4  // bound 5 (96 VGPRs, 13 spilled dwords) measured +3 % (profiles/round3/ab_occupancy.txt).  Since round 4 (whole-quad exchange,
-#endif                           // level-0 certificate) it needs 88 VGPRs = 5 waves by itself, and its LDS (ATMO_RMQ_CHUNK_LOD) allows exactly those 5.
+#ifndef ATMO_MIN_WAVES_LOD_RM  // the declared-sampler raymarched-light kernels: bound 4 = no constraint in practice.  The in-place form (rounds 5-6) needs 74-75
+#define ATMO_MIN_WAVES_LOD_RM 4  // VGPRs by itself = six waves; the queue form it replaced needed 111 (round 3) / 88 (round 4) and a bound of 5 cost it +3 %
+#endif                           // (profiles/round3/ab_occupancy.txt).
 #ifndef ATMO_MIN_WAVES_LOD
 #define ATMO_MIN_WAVES_LOD ATMO_MIN_WAVES
 #endif

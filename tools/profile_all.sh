@@ -13,6 +13,9 @@ for spec in "direct32x8 1920 1080" "direct32x8 3840 2160" "lut32 1920 1080" "shi
   python3 tools/summarize_pmc.py gpurun_out/prof_$1_$2x$3 $DST/pmc_$1_$2x$3.json > /dev/null
   cp gpurun_out/prof_$1_$2x$3/stats/s_kernel_stats.csv $DST/kernel_stats_$1_$2x$3.csv 2>/dev/null
 done
+# the counters just collected are the ones the bench lines below (and every later bench.py of this tree) read: profiles/<round>/pmc_*.json, stamped with this
+# build's id -- put them in place BEFORE the default command runs, or its line would say traffic_stale against the previous build's files
+mkdir -p $R/profiles/$ROUND && cp $DST/pmc_*.json $DST/kernel_stats_*.csv $R/profiles/$ROUND/ 2>/dev/null
 PY=$(python3 -c 'import sys,os;print(os.path.realpath(sys.executable))')
 export TMPDIR=/tmp
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $DST/default_cmd -o s -- $PY $R/bench.py --also "" > $DST/bench_default_under_rocprof.json 2> $DST/bench_default_under_rocprof.err)
