@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """the 12 MINIFIED frames of profiles/round5/mesa_pin.txt section 5 (48 x 27, the demo scene, the sampler the reference declares)
-executed by Mesa / llvmpipe HERE, against the CPU oracle under its three treatments of a quad partner that does not reach the fetch:
-  cube_lod = 1   the stated convention (Vulkan's text: no derivative from such a partner)
-  cube_lod = 2   lock-step quads: the partner contributes the coordinate its lane would hold (round 6; what mesa_pin 11e isolated)
-  ... + lod_log2_fast   lambda's log2 piecewise linear, as llvmpipe's level-of-detail unit takes it (a CHECKER option)
+executed by Mesa / llvmpipe HERE, against the CPU oracle under
+  cube_lod = 1   the stated convention (no derivative from a quad partner that does not reach the fetch)
+  cube_lod = 2   lock-step quads: the partner contributes the coordinate its lane would hold (what mesa_pin 11e isolated); 3: only helper pixels below the viewport
+and the CHECKER options of OracleConfig.lod_log2_fast: bit 0 = lambda's log2 piecewise linear (llvmpipe's level-of-detail unit), bit 1 = rho as a 3-D distance on
+the cube, bit 2 = the quotient RULE d(s / ma) = (ds ma - s dma) / ma^2 with the lane's own ma instead of the exact difference of the two projections.
+--save writes Mesa's 12 frames (tests/golden/reference_exec_mesa_lod.npz: the fixture of tests/test_reference_mesa.py::test_minified_frames_...).
 Build container only (needs /root/reference and the image's Mesa).  python tests/checks/mesa_lod_rule.py [--save tests/golden/reference_exec_mesa_lod.npz]"""
 import os
 import sys
@@ -55,11 +57,18 @@ def main():
             rgba, disc, _ = M.run_frame(shader, None, params, w2m, model, cam, depth, tex, cube_chain=chain)
             save[f"mesa_lod_rgba_{pose}_{shader}"] = rgba
             row = f"   {pose:8s} {shader.replace('planet_atmosphere_', ''):16s}"
-            for name, cfg in (("stated (1)", dict(cube_lod=1)), ("lock-step (2)", dict(cube_lod=2)), ("lock-step + fast log2", dict(cube_lod=2, lod_log2_fast=1)),
-                              ("lock-step + 3-D rho", dict(cube_lod=2, lod_log2_fast=2)), ("lock-step + 3-D rho + fast log2", dict(cube_lod=2, lod_log2_fast=3)),
-                              ("stated + 3-D rho + fast log2", dict(cube_lod=1, lod_log2_fast=3))):
+            for name, cfg in (("stated (1)", dict(cube_lod=1)), ("+ quotient rule", dict(cube_lod=1, lod_log2_fast=4)), ("+ fast log2", dict(cube_lod=1, lod_log2_fast=1)),
+                              ("+ BOTH", dict(cube_lod=1, lod_log2_fast=5)), ("lock-step (2) + both", dict(cube_lod=2, lod_log2_fast=5)),
+                              ("helpers below the viewport lock-step (3) + both", dict(cube_lod=3, lod_log2_fast=5)), ("stated + 3-D rho + fast log2", dict(cube_lod=1, lod_log2_fast=3))):
                 orc, _ = oracle.render(oparams, otex, dict(RS.VARIANTS[shader], **cfg), frame, depth, nthreads=8)
-                row += f" | {name}: {stats(rgba, orc)}"
+                row += f"\n        {name:48s} {stats(rgba, orc)}"
+                if name == "+ BOTH":
+                    e = relerr(rgba, orc)
+                    pix = e.max(axis=-1)
+                    bad = np.argwhere(pix[:H - 1] > 1e-4)
+                    row += (f"\n        {'   of which rows 0..%d' % (H - 2):48s} max {e[:H - 1].max():.2e} beyond 1e-4 {100.0 * np.mean(e[:H - 1] > 1e-4):6.3f} %  pixels "
+                            f"{[(int(y), int(x)) for y, x in bad]};  last row (its vertical partners are helper pixels BELOW the viewport): max {e[H - 1].max():.2e}, "
+                            f"{int((pix[H - 1] > 1e-4).sum())} pixels beyond 1e-4")
             print(row, flush=True)
     if "--save" in sys.argv:
         path = sys.argv[sys.argv.index("--save") + 1]

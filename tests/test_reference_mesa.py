@@ -332,6 +332,48 @@ def test_oracle_whole_frame_blocks_against_mesa(oracle32, vm, mesa, case):
     assert err <= bar
 
 
+@pytest.fixture(scope="module")
+def mesa_lod(mesa):
+    z = np.load(os.path.join(GOLDEN, "reference_exec_mesa_lod.npz"))
+    assert str(z["mesa_info"]) == str(mesa["mesa_info"]) and str(z["gallivm_perf"]) == str(mesa["gallivm_perf"])
+    return z
+
+
+@pytest.mark.parametrize("pose", RS.LOD_POSES)
+@pytest.mark.parametrize("shader", RS.LOD_VARIANTS)
+def test_minified_frames_differ_from_mesa_by_two_named_choices(oracle32, vm, mesa_lod, textures, pose, shader):
+    """Round 6: the 12 frames of mesa_pin.txt section 5 -- 48 x 27, the demo scene, the sampler the reference DECLARES, the 64^2 cubemap
+    MINIFIED 4-8x so that lambda > 0 matters -- were "recorded, not a test": llvmpipe and the stated convention differed on 9-15 % of the values by up to 0.33.
+    What separates them is now named and tested: (i) llvmpipe takes the cube-map derivative by the quotient RULE, d(s / ma) = (ds ma - s dma) / ma^2 with the
+    lane's own ma, where the stated convention takes the exact difference of the two projections, (ds ma - s dma) / (ma ma'); (ii) its level-of-detail unit takes
+    log2 piecewise linear (exponent + mantissa - 1).  Both are legal (GLSL / Vulkan leave the derivative's precision and log2's to the implementation).  With the
+    two substituted IN THE CHECKER (OracleConfig.lod_log2_fast = 4 | 1) the oracle reproduces llvmpipe's frames: max 1.6e-5 over every pixel from inside the layer
+    and from the limb, and at pose P_space everything but (a) the LAST ROW of the odd-height frame, whose vertical quad partners are the rasteriser's helper pixels
+    below the viewport (the stated convention gives them no derivative; llvmpipe shades them), and (b) one or two hypersensitive pixels per frame.
+    The chain: HIP == stated convention on these very frames (test_reference_exec.py, the `lod_rgba_*` vectors, <= 1e-4; test below), stated convention + (i) +
+    (ii) == llvmpipe: the HIP path's distance from a third-party executor on minified frames is attributed to two named implementation choices, each measured
+    (profiles/round6/mesa_lod_rule.txt: either one alone does not close it)."""
+    params, model = _scene("demo")
+    cam = RS.camera_from_fixture(vm, RS.W, RS.H, pose)
+    frame = make_frame(cam, model, S.DEMO_SUN_POSITION, 0.0)
+    depth = vm[f"depth_demo_{pose}"]
+    tex = dict(textures, optical_depth=vm["lut_demo"], cubemap=oracle32.cubemap_mip_chain(textures["cubemap"]))
+    want = mesa_lod[f"mesa_lod_rgba_{pose}_{shader}"]
+    stated, _ = oracle32.render(params, tex, dict(RS.VARIANTS[shader], cube_lod=1), frame, depth, nthreads=4)
+    both, _ = oracle32.render(params, tex, dict(RS.VARIANTS[shader], cube_lod=1, lod_log2_fast=5), frame, depth, nthreads=4)
+    e_stated, e = _rel(stated, want), _rel(both, want)
+    body, last = e[:RS.H - 1], e[RS.H - 1]
+    print(f"\n{pose} {shader}: stated convention vs Mesa max {e_stated.max():.2e} ({100 * np.mean(e_stated > 1e-4):.2f} % beyond 1e-4); with llvmpipe's derivative form and "
+          f"log2: rows 0..{RS.H - 2} max {body.max():.2e} ({100 * np.mean(body > 1e-4):.3f} %), last row max {last.max():.2e}")
+    if pose == "P_space":
+        assert np.mean(e_stated > 1e-4) > 0.05                         # the frames on which the conventions DO differ
+        assert np.mean(body > 1e-4) <= 0.002 and body.max() <= 2e-3      # <= 2 pixels of 1 248, the worst 1.1e-3 (hypersensitive: |o32 - o64| there is larger)
+        assert last.max() <= 0.1                                        # the helper row: recorded, not matched (see the docstring)
+    else:
+        assert e.max() <= 5e-5                                          # every pixel, the last row included: 1.6e-5 measured
+        assert e_stated.max() > 10 * e.max()
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/addons/zylann.atmosphere/shaders"), reason="needs the reference tree (the build container)")
 def test_what_mesa_compiles_is_the_references_text():
     """mesa_exec.translate: between the prelude it puts in front (the #version line, the engine built-ins) and the main() it appends, the source handed to
@@ -419,6 +461,26 @@ def test_hip_against_mesa_fragments(vm, mesa, textures, sname, shader):
         worst = max(worst, _check(got, mesa[f"rgba_{sname}_{pose}_{shader}"], shader, f"HIP vs Mesa {sname}/{pose}/{shader}"))
     node.close()
     print(f"\n{sname} {shader}: max |HIP - Mesa| over 5 poses = {worst:.3e}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pose", RS.LOD_POSES)
+def test_hip_is_the_stated_convention_on_the_minified_frames(oracle32, vm, textures, pose):
+    """The other half of the chain of test_minified_frames_differ_from_mesa_by_two_named_choices: on the 12 minified frames the HIP kernels ARE the stated
+    convention (oracle, cube_lod = 1) to 1e-4 -- so what separates them from llvmpipe there is what separates the stated convention from it."""
+    params, model = _scene("demo")
+    cam = RS.camera_from_fixture(vm, RS.W, RS.H, pose)
+    depth = vm[f"depth_demo_{pose}"]
+    otex = dict(textures, optical_depth=vm["lut_demo"], cubemap=oracle32.cubemap_mip_chain(textures["cubemap"]))
+    for shader in RS.LOD_VARIANTS:
+        node = make_node(NODE_CONFIG[shader], textures, params)
+        got = _gpu_render(node, cam, depth)
+        assert int(node.kernel_name.split("<")[1].split(",")[0]) & 32, node.kernel_name
+        node.close()
+        want, _ = oracle32.render(params, otex, dict(RS.VARIANTS[shader], cube_lod=1), make_frame(cam, model, S.DEMO_SUN_POSITION, 0.0), depth, nthreads=8)
+        err = float(_rel(got, want).max())
+        print(f"\n{pose} {shader}: |HIP - stated convention| = {err:.3e}")
+        assert err <= 1e-4, (pose, shader, err)
 
 
 @pytest.mark.gpu
