@@ -858,6 +858,13 @@ def self_launch(args):
     import socket
     import subprocess
 
+    if not args.stub_renderer:
+        # fail before N interpreters are started (counting devices does not initialise the GPU on this image; is_available / any HIP call would)
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py needs an MI355X per rank: --gpus {args.gpus}, but this node shows {have} GPU(s) (there is no CPU fallback)")
+
     port = os.environ.get("MASTER_PORT")
     if not port:
         with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:

@@ -515,7 +515,7 @@ def test_bench_launch_errors_are_loud(tmp_path):
     if not _has_gpu():
         # the real N > 1 command on a host without GPUs: every rank fails loudly, the launcher's code comes back, no JSON line
         p, rec = _run_bench_as_typed(tmp_path, "--gpus", "2", "--steps", "1", "--warmup", "0")
-        assert p.returncode != 0 and rec is None and "needs an MI355X" in p.stderr
+        assert p.returncode != 0 and rec is None and "needs an MI355X" in p.stderr and "torch.distributed.run" not in p.stderr   # refused before anything is launched
     # under a launcher (WORLD_SIZE set) nothing is launched again
     os.environ["WORLD_SIZE"] = "2"
     try:
