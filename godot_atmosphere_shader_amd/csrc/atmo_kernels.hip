@@ -611,7 +611,7 @@ __device__ __forceinline__ float cube_level_sample(const RenderConsts &rc, int f
 // Domain: finite normal x > 0 (callers pass rho^2 > 1).
 /* generated by tools/make_log2_table.py -- do not edit by hand */
 #define LOG2CR_OFF 0x3f320000u
-__device__ const double LOG2CR_TAB[32][2] = {  /* {invc, logc = -log2(invc)} */
+__device__ alignas(16) const double LOG2CR_TAB[32][2] = {  /* {invc, logc = -log2(invc)} */
     {0x1.6c16c20000000p+0, -0x1.042bd5e5bc697p-1},
     {0x1.642c860000000p+0, -0x1.e7df61b2e23edp-2},
     {0x1.5c98820000000p+0, -0x1.c819d91c72820p-2},
@@ -683,14 +683,20 @@ __device__ __forceinline__ float log2_cr(float x, const f32x4 *tab) {
                   __builtin_bit_cast(uint64_t, LOG2CR_C[3]) == 0xbfd71547652b82feull && __builtin_bit_cast(uint64_t, LOG2CR_C[2]) == 0x3fdec709dc3a03fdull &&
                   __builtin_bit_cast(uint64_t, LOG2CR_C[1]) == 0xbfe71547652b82feull && __builtin_bit_cast(uint64_t, LOG2CR_C[0]) == 0x3ff71547652b82feull,
                   "log2_cr: the immediates below are LOG2CR_C");
-    double p = log2_cr_const<0xbfc71547652b82feull>();
-    p = __builtin_fma(p, r, log2_cr_const<0x3fca61762a7aded9ull>());
-    p = __builtin_fma(p, r, log2_cr_const<0xbfcec709dc3a03fdull>());
-    p = __builtin_fma(p, r, log2_cr_const<0x3fd2776c50ef9bfeull>());
-    p = __builtin_fma(p, r, log2_cr_const<0xbfd71547652b82feull>());
-    p = __builtin_fma(p, r, log2_cr_const<0x3fdec709dc3a03fdull>());
-    p = __builtin_fma(p, r, log2_cr_const<0xbfe71547652b82feull>());
-    p = __builtin_fma(p, r, log2_cr_const<0x3ff71547652b82feull>());
+    // (each Horner step as ONE v_fma_f64 with the coefficient read straight from its SGPR pair: left to the compiler, p * r + c became v_fmac_f64 -- whose
+    //  addend must sit in the destination VGPRs -- behind two v_mov_b32 per step, 14 VALU instructions of the block's 38)
+    auto step = [&](double acc, double c) {
+        double o;
+        asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(acc), "v"(r), "s"(c));
+        return o;
+    };
+    double p = step(log2_cr_const<0xbfc71547652b82feull>(), log2_cr_const<0x3fca61762a7aded9ull>());
+    p = step(p, log2_cr_const<0xbfcec709dc3a03fdull>());
+    p = step(p, log2_cr_const<0x3fd2776c50ef9bfeull>());
+    p = step(p, log2_cr_const<0xbfd71547652b82feull>());
+    p = step(p, log2_cr_const<0x3fdec709dc3a03fdull>());
+    p = step(p, log2_cr_const<0xbfe71547652b82feull>());
+    p = step(p, log2_cr_const<0x3ff71547652b82feull>());
     const double y0 = logc + (double)k;
     return (float)__builtin_fma(p, r, y0);
 }
