@@ -611,7 +611,7 @@ __device__ __forceinline__ float cube_level_sample(const RenderConsts &rc, int f
 // Domain: finite normal x > 0 (callers pass rho^2 > 1).
 /* generated by tools/make_log2_table.py -- do not edit by hand */
 #define LOG2CR_OFF 0x3f320000u
-__device__ alignas(16) const double LOG2CR_TAB[32][2] = {  /* {invc, logc = -log2(invc)} */
+__device__ const double LOG2CR_TAB[32][2] = {  /* {invc, logc = -log2(invc)} */
     {0x1.6c16c20000000p+0, -0x1.042bd5e5bc697p-1},
     {0x1.642c860000000p+0, -0x1.e7df61b2e23edp-2},
     {0x1.5c98820000000p+0, -0x1.c819d91c72820p-2},
