@@ -404,9 +404,10 @@ def _random_scene(rng, k):
 # Seeds 0-11, then (round 6) the four scenes of the 1 212-scene soak that exceeded 1e-4 in rounds 3-5 -- 442 / 658 / 890 carried a 24^3 shape volume whose
 # filter coordinates the kernels had fused (fma(p, n, -0.5): the same bits as the reference's rounded product only for power-of-two n), 1040 one ulp of
 # the declared sampler's lambda; profiles/round6/fuzz_four.txt -- and 20 more drawn from the 1 212 (np.random.default_rng(6).choice(arange(12, 1212), 20)).
-# ATMO_FUZZ_EXTRA=n: seeds 12 .. 12 + n - 1 as well, on demand (the soak: n = 1200).
+# ATMO_FUZZ_EXTRA=n: seeds 12 .. 12 + n - 1 as well, on demand (the soak: n = 1200); ATMO_FUZZ_FIRST=k: k .. k + n - 1 instead (fresh scenes).
 FUZZ_SEEDS = list(range(12)) + [442, 658, 890, 1040] + [159, 234, 406, 418, 449, 456, 521, 537, 546, 553, 624, 648, 766, 792, 816, 817, 826, 915, 1133, 1187]
-FUZZ_SEEDS += [k for k in range(12, 12 + int(__import__("os").environ.get("ATMO_FUZZ_EXTRA", "0"))) if k not in FUZZ_SEEDS]
+_FUZZ_FIRST = int(__import__("os").environ.get("ATMO_FUZZ_FIRST", "12"))
+FUZZ_SEEDS += [k for k in range(_FUZZ_FIRST, _FUZZ_FIRST + int(__import__("os").environ.get("ATMO_FUZZ_EXTRA", "0"))) if k not in FUZZ_SEEDS]
 
 
 @pytest.mark.parametrize("seed", FUZZ_SEEDS)
