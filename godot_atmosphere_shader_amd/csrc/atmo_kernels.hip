@@ -1167,6 +1167,21 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
     const float dstep = dens2 * step_len;
     float lr = 0.0f, lg = 0.0f, lb = 0.0f, view_od = 0.0f;
 
+    // WHERE THIS LOOP SITS IN THE INSTRUCTION STREAM IS PART OF THE HEADLINE KERNEL'S SPEED (round 6, profiles/round6/ab_loop_phase.txt).  In <4, 8, 1> the loop
+    // is 436 bytes, and the draw takes 0.0865 ms when its first instruction -- the target of the backward branch -- lies 12 bytes into a 32-byte block, 0.094-0.096 ms
+    // (+8.5 ... +11 %) at each of the other seven 4-byte positions; shifted by 32 bytes it is fast again.  Instructions inserted INSIDE the loop behind its first one
+    // cost their issue slot and nothing else, a 2 x unrolled body has no fast position at all, the LUT kernels' and the cloud kernels' loops do not care.  It is what
+    // made rounds 2-5's "any scalar instruction in the preamble costs 8-10 %" and "an 80-SGPR cap (8 waves per SIMD) loses 8 %" -- both moved this loop by 4 bytes
+    // (at the right position the capped build is exactly as fast as this one: the eighth wave buys nothing).  tests/test_host_logic.py holds the position
+    // (tools/loop_phase.py reads it from the built library); if a change to the code in front of the loop moves it, ATMO_LOOP_PAD = the number of s_nop that puts it back.
+#ifndef ATMO_LOOP_PAD
+#define ATMO_LOOP_PAD 0
+#endif
+#if ATMO_LOOP_PAD > 0
+#define ATMO_STR2(x) #x
+#define ATMO_STR(x) ATMO_STR2(x)
+    if (DIRECT && LSTEPS == 8 && SPLIT == 1 && !VIEWPOS) asm volatile(".rept " ATMO_STR(ATMO_LOOP_PAD) "\n\ts_nop 0\n\t.endr");
+#endif
     for (int i = 0; i < steps; ++i) {
         if (VIEWPOS) {
             ox = pvx - rc.center[0]; oy = pvy - rc.center[1]; oz = pvz - rc.center[2];
@@ -2109,9 +2124,11 @@ __device__ __forceinline__ void shade_pixel(const RenderConsts &rc, const int ti
 // floor(800 / (ceil(.sgpr_count / 16) * 16 + 16)): .sgpr_count <= 80 => 8, 81-96 => 7, 97-112 => 6, although the occupancy API
 // and the compiler's "Occupancy" line still say 8 (MI355X_MICROARCH.md "Residency").  What the build does: NOTHING -- no kernel is
 // compiled under an SGPR cap.  The direct-light no-cloud kernels sit at .sgpr_count 82 (7 waves per SIMD; their 40 VGPRs would allow
-// 8); the twin kernel atmo_render_kernel_s80 below compiles them to 78 with the same loop ISA, and that build is 8 % SLOWER at
-// 1920x1080 and 4 % at 3840x2160 (profiles/round4/ab_sgpr_cap.txt, interleaved A/B against the uncapped build and round 3's library;
-// round 2 had measured -3 % on a differently shaped kernel).  The cloud kernels (86-106 SGPRs, 53-89 VGPRs: 5-7 waves either way) lost
+// 8); the twin kernel atmo_render_kernel_s80 below compiles them to 78 with the same loop ISA.  Round 4 measured that build 8 % SLOWER at
+// 1920x1080 and 4 % at 3840x2160 (profiles/round4/ab_sgpr_cap.txt) and blamed the cap; round 6 found the cause -- the capped build moves the
+// view loop by four bytes, off its fast position (march_atmosphere, profiles/round6/ab_loop_phase.txt 3) -- and that at the right position
+// 8 waves per SIMD are exactly as fast as 7 (0.0867 against 0.0865 ms): the kernel is bound by VALU issue, residency buys nothing.
+// The cloud kernels (86-106 SGPRs, 53-89 VGPRs: 5-7 waves either way) lost
 // 5-7 % under a cap in round 2.  The mask below selects families for the next A/B (amdgpu_num_sgpr takes a literal, hence the twin).
 #ifndef ATMO_MIN_WAVES  // __launch_bounds__ second argument: minimum waves per SIMD the register allocation must allow (0 = none).
 #define ATMO_MIN_WAVES 6  // 6: only atmo_render_kernel<19 / 23, ..> change (84 -> 80 VGPRs); see ATMO_RMQ_CHUNK
@@ -2162,9 +2179,10 @@ constexpr bool render_sgpr_cap80(int flags) {
 #endif
 // Keep this preamble exactly as it is for every variant.  Measured on the direct-light kernel (same loop ISA in all
 // three builds, profiles/round2/ab_direct_kernel.txt): this form 0.108-0.109 ms; a branch on tile_order in front of
-// the division (which serialises the prologue's scalar loads behind an early s_waitcnt) 0.115 ms; NO preamble at all
-// (blockIdx used directly) 0.115 ms as well -- the few hundred cycles of scalar work in front of the depth load
-// help (an explicit s_sleep stagger by blockIdx does not: +4..6 %).
+// the division 0.115 ms; NO preamble at all (blockIdx used directly) 0.115 ms as well.  Round 2 read that as "the scalar work in
+// front of the depth load helps"; round 6 found what it was: every one of those edits moved the direct-light kernel's view loop by a few bytes, and
+// that loop is 8.5-11 % slower at seven of its eight possible 4-byte positions (march_atmosphere; profiles/round6/ab_loop_phase.txt).  The preamble
+// itself is neutral; the POSITION is what must be kept (tests/test_host_logic.py::test_headline_view_loop_sits_at_its_fast_position).
 #define ATMO_RENDER_KERNEL_BODY                                                                                  \
     ATMO_TRACE_ENTRY                                                                                             \
     uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;                                                         \

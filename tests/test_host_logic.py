@@ -544,6 +544,29 @@ def test_whole_quad_exchange_registers_are_private():
     assert any("0 with a stack frame, 0 scratch instructions" in ln for ln in p.stdout.splitlines()), p.stdout   # and no kernel spills
 
 
+def test_headline_view_loop_sits_at_its_fast_position():
+    """Round 6 (profiles/round6/ab_loop_phase.txt): the 32 x 8 direct-light kernel <4, 8, 1> -- the BASELINE configs[1] headline -- draws in 0.0865 ms when
+    the first instruction of its 436-byte view loop lies 12 bytes into a 32-byte block of the instruction stream and in 0.094-0.096 ms at each of the other seven
+    positions.  A change anywhere in front of that loop can move it by four bytes (that is what made earlier rounds' preamble and SGPR-cap experiments lose 8-10 %):
+    this test reads the position from the library as built (tools/loop_phase.py) and fails until ATMO_LOOP_PAD (atmo_kernels.hip, march_atmosphere) puts it back."""
+    import sys as _sys
+
+    from godot_atmosphere_shader_amd.build import build_native
+
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("llvm-objdump of the ROCm toolchain not found")
+    _sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import loop_phase
+    finally:
+        _sys.path.pop(0)
+    rows = loop_phase.view_loops(build_native())
+    assert len(rows) == 1, rows                      # one kernel matches, with one loop holding the seven-root cluster of the light march
+    name, offset, phase, size = rows[0]
+    assert phase == loop_phase.FAST_PHASE, (f"{name}: the view loop starts {phase} bytes into its 32-byte block (at +0x{offset:x}, {size} bytes); the measured-fast "
+                                            f"position is {loop_phase.FAST_PHASE}: set ATMO_LOOP_PAD to {((loop_phase.FAST_PHASE - phase) % 32) // 4}")
+
+
 # ---- round 5: the host side of the C ABI without a device (atmo_debug_create_host_only; also what `make sanitize-host` runs) ---------------
 def _host_ctx(variant, view_steps=0, cloud_steps=0, light_mode=0, light_steps=0):
     from godot_atmosphere_shader_amd import _native as N
