@@ -41,3 +41,55 @@ for r in rows:
     k = f"{r[3]:.4f}" if isinstance(r[3], float) and r[3] else ""
     print(f"| {r[0]} | {a} | {b} | {k} | {r[4]} | {r[5]} |")
 print("roofline", {k: full["roofline"].get(k) for k in ("frac", "traffic", "traffic_stale", "build_id", "algorithmic_bytes_per_launch")}, "noise_cubemap", ex["noise_cubemap"]["Mtexels/s"])
+
+
+# ---- --apply: rewrite the numeric cells of README.md's results table (rows recognised by their first cell; the prose of the notes is kept in the templates below) ----
+def ms(name, digits=3):
+    v = ex[name].get("kernel_avg_ms") or 0.0
+    return f"{v:.{digits}f}"
+
+
+def pct(a, b):
+    return f"{(a / b - 1.0) * 100:+.0f} %"
+
+
+def readme_rows():
+    mv, cm = ex["direct32x8@moving"], ex["clouds_high_rm@moving"]
+    cpu = f"| CPU baseline (the oracle on the GPU box's 16 usable host cores, same frame) | {k20['cpu_baseline']['value']:.1f} | {full['cpu_baseline']['value']:.1f} | — | — | `kind: \"port\"` |"
+    r = full["roofline"]
+    pair = lambda n: f"{g(ek[n][0])} | {g(ex[n]['Mrays/s'])}"
+    bold_pair = lambda n: f"**{g(ek[n][0])}** | {g(ex[n]['Mrays/s'])}"
+    return {
+        "| **`no_clouds`, 32 view x 8 light steps, 1920x1080": f"| **`no_clouds`, 32 view x 8 light steps, 1920x1080 (BASELINE configs[1], headline)** | **{g(k20['value'])}** | {g(full['value'])} | {r['kernel_avg_ms']:.4f} | {vr(full)} | {r['frac'] * 100:.1f} % of the 20 B/ray HBM roofline, fabric traffic {r['traffic'] / r['algorithmic_bytes_per_launch']:.3f}x the algorithmic bytes ({r['traffic'] / 1e6:.1f} against {r['algorithmic_bytes_per_launch'] / 1e6:.1f} MB; the path is VALU-bound); row-major tile order (`mrays_per_s_feedback_off`): {g(full['config']['mrays_per_s_feedback_off'])} |",
+        "| same, camera orbiting": "| same, camera orbiting 0.1 / 1 / 5 degrees per frame; panning 1 degree per frame | " + " / ".join(g(ek[f"direct32x8@moving/{k}"][0]) for k in ("orbit:0.1", "orbit:1", "orbit:5")) + "; " + g(ek["direct32x8@moving/pan:1"][0]) + " | " + " / ".join(g(mot(mv, k)) for k in ("orbit:0.1", "orbit:1", "orbit:5")) + "; " + g(mot(mv, "pan:1")) + " | | | a new pose every step |",
+        "| same, 3840x2160": f"| same, 3840x2160 | {pair('direct32x8@3840x2160')} | {ms('direct32x8@3840x2160')} | {vr(ex['direct32x8@3840x2160'])} | at the modelled issue floor |",
+        "| `no_clouds`, 32 view steps, baked-LUT light": f"| `no_clouds`, 32 view steps, baked-LUT light (the reference's algorithm) | {pair('lut32')} | {ms('lut32', 4)} | {vr(ex['lut32'])} | |",
+        "| `no_clouds` as shipped": f"| `no_clouds` as shipped (8 view steps, LUT) | {pair('shipped8')} | {ms('shipped8', 4)} | {vr(ex['shipped8'])} | a 20 us draw; `atmo_set_target_cleared`: {g(ek['shipped8@cleared'][0])} / {g(ex['shipped8@cleared']['Mrays/s'])} |",
+        "| **`clouds_high` 1920x1080 (configs[2])": f"| **`clouds_high` 1920x1080 (configs[2]), declared sampler (default)** | {bold_pair('clouds_high')} | {ms('clouds_high')} | {vr(ex['clouds_high'])} | round 5: 11 900 (0.174 ms): the march's lambda in the oracle's operations +3.8 %, the shape volume's float copy -3.6 % (both interleaved A/B) |",
+        "| `clouds_high@lod0` |": f"| `clouds_high@lod0` | {pair('clouds_high@lod0')} | {ms('clouds_high@lod0')} | {vr(ex['clouds_high@lod0'])} | |",
+        "| `clouds_high_rm` 1920x1080 (raymarched cloud light)": f"| `clouds_high_rm` 1920x1080 (raymarched cloud light), declared sampler | {pair('clouds_high_rm')} | {ms('clouds_high_rm')} | {vr(ex['clouds_high_rm'])} | bound by its tail; under a moving camera see below |",
+        "| `clouds_high_rm@lod0` 1920x1080": f"| `clouds_high_rm@lod0` 1920x1080 | {pair('clouds_high_rm@lod0')} | {ms('clouds_high_rm@lod0')} | {vr(ex['clouds_high_rm@lod0'])} | |",
+        "| **`clouds_high_rm` 3840x2160 (configs[3])": f"| **`clouds_high_rm` 3840x2160 (configs[3]), declared sampler (default)** | **{g(ek['clouds_high_rm@3840x2160'][0])}** | **{g(ex['clouds_high_rm@3840x2160']['Mrays/s'])}** | **{ms('clouds_high_rm@3840x2160')}** | {vr(ex['clouds_high_rm@3840x2160'])} | round 5: 6 914 (1.199 ms) |",
+        "| `clouds_high_rm@lod0` 3840x2160": f"| `clouds_high_rm@lod0` 3840x2160 | {pair('clouds_high_rm@lod0@3840x2160')} | {ms('clouds_high_rm@lod0@3840x2160')} | {vr(ex['clouds_high_rm@lod0@3840x2160'])} | |",
+        "| `clouds_high_rm` 1280x720": f"| `clouds_high_rm` 1280x720 | {pair('clouds_high_rm@1280x720')} | {ms('clouds_high_rm@1280x720')} | | heavy tiles on two lanes per ray; without (`@nosplit`): {g(ek['clouds_high_rm@1280x720@nosplit'][0])} / {g(ex['clouds_high_rm@1280x720@nosplit']['Mrays/s'])} ({ms('clouds_high_rm@1280x720@nosplit')} ms) -- **{pct(ex['clouds_high_rm@1280x720']['Mrays/s'], ex['clouds_high_rm@1280x720@nosplit']['Mrays/s'])}** |",
+        "| `clouds_high_rm` 1920x1080 from the limb": f"| `clouds_high_rm` 1920x1080 from the limb (pose P_limb) | {pair('clouds_high_rm@P_limb')} | {ms('clouds_high_rm@P_limb')} | | the same; without: {g(ek['clouds_high_rm@P_limb@nosplit'][0])} / {g(ex['clouds_high_rm@P_limb@nosplit']['Mrays/s'])} ({ms('clouds_high_rm@P_limb@nosplit')} ms) -- **{pct(ex['clouds_high_rm@P_limb']['Mrays/s'], ex['clouds_high_rm@P_limb@nosplit']['Mrays/s'])}** |",
+        "| `clouds_high_rm` 1920x1080, camera orbiting": "| `clouds_high_rm` 1920x1080, camera orbiting 1 / 5 degrees per frame; panning 1 degree per frame | " + " / ".join(g(ek[f"clouds_high_rm@moving/{k}"][0]) for k in ("orbit:1", "orbit:5")) + "; " + g(ek["clouds_high_rm@moving/pan:1"][0]) + " | " + " / ".join(g(mot(cm, k)) for k in ("orbit:1", "orbit:5")) + "; " + g(mot(cm, "pan:1")) + f" | | | against the STATIC pose {g(mot(cm, 'static'))} -- but an orbit's frames are other, heavier pictures: each frame against its own perfect tile order the library is at 0.95 / 0.80 / 0.91 (`profiles/round6/motion_order.txt`) |",
+        "| CPU baseline (the oracle": cpu,
+    }
+
+
+if "--apply" in sys.argv:
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "README.md")
+    lines = open(path).read().split("\n")
+    new = readme_rows()
+    done = set()
+    for i, ln in enumerate(lines):
+        for key, row in new.items():
+            if ln.startswith(key):
+                assert key not in done, key
+                lines[i] = row
+                done.add(key)
+    assert done == set(new), sorted(set(new) - done)
+    open(path, "w").write("\n".join(lines))
+    print(f"README.md: {len(done)} table rows rewritten from {d}")
