@@ -14,7 +14,7 @@ tex, params = demo_textures(), demo_params()
 SIZES = [(int(sys.argv[1]), int(sys.argv[2]))] if len(sys.argv) > 2 else [(1280, 720), (1920, 1080), (3840, 2160)]
 MODES = os.environ.get("PROBE_MODES", "off,all,t1.3:0.25,t1.3:0.4,t2:0.25,off").split(",")
 for wl, (w, h) in [(a, b) for a in os.environ.get("PROBE_WORKLOADS", "clouds_high_rm").split(",") for b in SIZES]:
-    for pose in ("P_space", "P_limb", "P_ground", "P_clouds", "P_night"):
+    for pose in os.environ.get("PROBE_POSES", "P_space,P_limb,P_ground,P_clouds,P_night").split(","):
         cam = S.Camera.from_pose(w, h, pose)
         depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
         out = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
