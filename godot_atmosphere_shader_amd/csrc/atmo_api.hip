@@ -464,8 +464,10 @@ int heavy_tile_count(const uint32_t *totals, int n_tiles, float ratio, float tri
     double life[atmo::TILE_ORDER_CLASSES], sum = 0.0;
     long long counted = 0;
     for (int k = 0; k < atmo::TILE_ORDER_CLASSES; ++k) {
-        const int q = atmo::TILE_ORDER_CLASSES - 1 - k + 16;                  // the class holds durations from 2^(q/2) up to the next half octave
-        life[k] = std::ldexp(1.0, q >> 1) * ((q & 1) ? 1.5 : 1.0) * 1.2;      // ... its middle
+        constexpr int P = atmo::TILE_ORDER_PER_OCTAVE;
+        const int q = atmo::TILE_ORDER_CLASSES - 1 - k + 8 * P;               // the class holds durations from 2^(q div P) (1 + (q mod P) / P) up to the next 1 / P of the octave
+        life[k] = P == 2 ? std::ldexp(1.0, q >> 1) * ((q & 1) ? 1.5 : 1.0) * 1.2      // ... its middle (half octaves: the constants the split's trigger was tuned with)
+                         : std::ldexp(1.0, q / P) * (1.0 + ((q % P) + 0.5) / P);
         if (k == atmo::TILE_ORDER_CLASSES - 1) life[k] = 0.0;                 // the last class also holds the tiles without a measurement
         sum += life[k] * (double)totals[k];
         counted += totals[k];

@@ -115,7 +115,12 @@ hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream
 hipError_t launch_bake(const BakeConsts &bc, hipStream_t stream);
 hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, int tiles_x, int tiles_y, int rx, int ry, uint32_t *tmp1, uint32_t *tmp2,
                              uint32_t *scratch, hipStream_t stream, uint32_t *order2 = nullptr, uint32_t *class_totals = nullptr);
-constexpr int TILE_ORDER_CLASSES = 32;   // cost classes of the sort: half octaves of the wave duration, class 0 the heaviest (tile_cost_class)
+#ifndef ATMO_ORDER_CLASSES   // 64 since round 6 (was 32, half octaves): clouds_high 1920x1080 -3.7 %, its level-0 form -5.1 %, nothing else beyond +-1 % (profiles/round6/ab_order_classes.txt)
+#define ATMO_ORDER_CLASSES 64
+#endif
+constexpr int TILE_ORDER_CLASSES = ATMO_ORDER_CLASSES;   // cost classes of the sort: 16 octaves of the wave duration (2^8 .. 2^24 cycles) in TILE_ORDER_PER_OCTAVE equal
+constexpr int TILE_ORDER_PER_OCTAVE = TILE_ORDER_CLASSES / 16;   // parts each (by the duration's leading mantissa bits), class 0 the heaviest (tile_cost_class)
+static_assert(TILE_ORDER_CLASSES == 32 || TILE_ORDER_CLASSES == 64, "32 (half octaves) or 64 (quarter octaves): the sort's per-class state is one lane of a wave");
 size_t tile_order_scratch_bytes();
 hipError_t launch_tile_list_bound(const uint32_t *in, uint32_t *out, int n, uint32_t tiles_n, uint32_t sentinel, hipStream_t stream,
                                   uint32_t *out2 = nullptr, int n_heavy = 0, int tiles_x = 1, uint32_t sentinel2 = 0);  // atmo_render_tiles[_split]

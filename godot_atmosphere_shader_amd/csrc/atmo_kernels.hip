@@ -2216,26 +2216,30 @@ __global__ __launch_bounds__(TILE_W *TILE_H ATMO_MIN_WAVES_ARG) __attribute__((a
 }
 
 // Stable counting sort of the tiles by the cost a recording draw measured, heaviest class first; clears the costs for
-// the next recording.  32 classes = half octaves of the wave duration (2^8 .. 2^24 cycles); tiles of one class keep their
-// row-major order, so neighbouring tiles -- which share texture footprints in L1/L2 -- still run together.
+// the next recording.  64 classes = quarter octaves of the wave duration (2^8 .. 2^24 cycles; 32 half octaves until round 6); tiles of one class keep their
+// row-major order, so neighbouring tiles -- which share texture footprints in L1/L2 -- still run together.  How fine: measured with tile-list draws in the
+// library's class order at 32 / 64 / 128 classes and in exact cost order (profiles/round6/ab_order_classes.txt) -- clouds_high at 1920x1080 gains 2.2 / 3.0 / 3.0 %
+// over 32, the headline kernel loses 0.6 / 0.7 / 2.7 % (an exact sort leaves no row-major runs), the rest is within +-0.5 %: 64, which also still fits the sort's
+// one-lane-per-class state.
 // Three small kernels on the context's high-priority side stream (round 3; the round-2 form was ONE 512-thread workgroup
 // with 64 KB of LDS that had to find a free CU beside the draw it runs next to: 33 us at best, 52-713 us on average --
 // that latency is feedback lag when the camera moves):
-//   histogram  256 single-wave workgroups, each owns a contiguous chunk of tiles and counts its 32 classes (wave ballots);
-//   scan       one workgroup turns the 256 x 32 counts into the first output index of every (chunk, class);
+//   histogram  256 single-wave workgroups, each owns a contiguous chunk of tiles and counts its classes (wave ballots);
+//   scan       one workgroup turns the 256 x ORDER_CLASSES counts into the first output index of every (chunk, class);
 //   scatter    the 256 waves write their tiles, in order, behind those indices and clear the costs.
 constexpr int ORDER_BLOCKS = 256, ORDER_CLASSES = TILE_ORDER_CLASSES;
+constexpr int ORDER_SUB_BITS = TILE_ORDER_PER_OCTAVE == 4 ? 2 : 1, ORDER_KEY_BITS = 4 + ORDER_SUB_BITS;   // mantissa bits that split an octave; bits of a class index
 __device__ __forceinline__ uint32_t tile_cost_class(uint32_t c) {
     if (c == 0) return ORDER_CLASSES - 1;
     const int msb = 31 - __builtin_clz(c);
-    const int q = msb * 2 + (msb > 0 ? (int)((c >> (msb - 1)) & 1u) : 0) - 16;
+    const int q = msb * TILE_ORDER_PER_OCTAVE + (msb >= ORDER_SUB_BITS ? (int)((c >> (msb - ORDER_SUB_BITS)) & (uint32_t)(TILE_ORDER_PER_OCTAVE - 1)) : 0) - 8 * TILE_ORDER_PER_OCTAVE;
     return (uint32_t)(ORDER_CLASSES - 1 - (q < 0 ? 0 : (q > ORDER_CLASSES - 1 ? ORDER_CLASSES - 1 : q)));
 }
-// lanes of this wave whose 5-bit key equals mine (inactive lanes excluded by `valid`)
+// lanes of this wave whose class index equals mine (inactive lanes excluded by `valid`)
 __device__ __forceinline__ unsigned long long match_class(uint32_t key, bool valid) {
     unsigned long long m = __builtin_amdgcn_ballot_w64(valid);
 #pragma unroll
-    for (int bit = 0; bit < 5; ++bit) {
+    for (int bit = 0; bit < ORDER_KEY_BITS; ++bit) {
         const bool one = (key >> bit) & 1u;
         const unsigned long long b = __builtin_amdgcn_ballot_w64(one);
         m &= one ? b : ~b;
@@ -2262,7 +2266,7 @@ __global__ __launch_bounds__(64) void atmo_tile_hist_kernel(const uint32_t *__re
     if (lane < ORDER_CLASSES) hist[lane * ORDER_BLOCKS + blockIdx.x] = cnt[lane];   // [class][block]: the scan reads a class's row contiguously
 }
 
-// hist[class][block] -> first output index of (block, class): classes in order 0 (heaviest) .. 31, blocks in order inside a class
+// hist[class][block] -> first output index of (block, class): classes in order 0 (heaviest) .. ORDER_CLASSES - 1, blocks in order inside a class
 // class_totals (may be null): the number of tiles in every cost class, for the host (pinned memory: it picks the frame's heavy tiles from them)
 __global__ __launch_bounds__(256) void atmo_tile_scan_kernel(uint32_t *__restrict__ hist, uint32_t *__restrict__ class_totals) {
     __shared__ uint32_t total[ORDER_CLASSES];
@@ -2289,7 +2293,7 @@ __global__ __launch_bounds__(256) void atmo_tile_scan_kernel(uint32_t *__restric
         if (lane == 63) total[c] = incl;
     }
     __syncthreads();
-    if (threadIdx.x < 64) {  // exclusive scan of the 32 class totals
+    if (threadIdx.x < 64) {  // exclusive scan of the class totals
         const uint32_t c = lane < ORDER_CLASSES ? total[lane] : 0u;
         if (class_totals != nullptr && lane < ORDER_CLASSES) class_totals[lane] = c;
         uint32_t incl = c;
