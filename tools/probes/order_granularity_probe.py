@@ -54,6 +54,20 @@ def main():
             n = 200 if "cloud" not in cfg.replace("no_clouds", "") else 50
             lists = {"32 classes": np.argsort(classes(flat, 2), kind="stable"), "64": np.argsort(classes(flat, 4), kind="stable"), "128": np.argsort(classes(flat, 8), kind="stable"),
                      "exact": np.argsort(-flat, kind="stable")}
+            if os.environ.get("PROBE_WITHIN_CLASS"):   # second question: the order INSIDE a class (the library: row-major) -- Morton order, and 2-tile-high row pairs
+                ty, tx = cost.shape
+                yy, xx = np.divmod(np.arange(flat.size), tx)
+                def part1by1(v):
+                    v = v.astype(np.int64) & 0xFFFF
+                    v = (v | (v << 8)) & 0x00FF00FF
+                    v = (v | (v << 4)) & 0x0F0F0F0F
+                    v = (v | (v << 2)) & 0x33333333
+                    return (v | (v << 1)) & 0x55555555
+                morton = part1by1(xx) | (part1by1(yy) << 1)
+                pairs = (yy // 2) * (2 * tx) + xx * 2 + (yy & 1)          # two tile rows at a time, column by column
+                cls = classes(flat, 4)
+                lists = {"32 classes": lists["32 classes"], "64": lists["64"], "64, Morton inside": np.lexsort((morton, cls)), "64, row pairs inside": np.lexsort((pairs, cls)),
+                         "64, columns inside": np.lexsort((xx * ty + yy, cls))}
             res = {}
             for rnd in range(2):   # two interleaved passes
                 for name, lst in lists.items():

@@ -1,14 +1,13 @@
 #!/bin/bash
-# round 6: the heavy-tile split's behaviour with the shipped 64 cost classes against 32 ('oc32'): its trigger reads the class histogram
+# round 6: 64 cost classes (shipped, 'base') against 32 ('oc32') under a moving camera: bench.py --motion, 128 poses, three interleaved runs each
 cd /root/repo
-export ROUNDS=3 STEPS=100
-for wl in "clouds_high_rm P_space 1280 720" "clouds_high_rm P_limb" "clouds_high_rm P_night" "clouds_high_rm P_limb 1280 720" "clouds_high_rm P_clouds"; do
-  tools/ab_bench.sh "$wl" base oc32
-done
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-# one wave per workgroup (16 x 4 pixel tiles: the order's granularity is one wavefront) on the cloud kernels
-python tests/checks/render_set.py /tmp/base.npz > /dev/null 2>&1; ATMO_HIP_LIB=$PWD/godot_atmosphere_shader_amd/libatmo_hip_th4.so python tests/checks/render_set.py /tmp/th4.npz > /dev/null 2>&1; python tests/checks/render_set.py --compare /tmp/base.npz /tmp/th4.npz | tail -2
-export ROUNDS=3 STEPS=100
-for wl in "clouds_high" "clouds_high_rm" "clouds_high_rm P_space 3840 2160" "clouds_high P_ground" "clouds_high_rm P_ground" "clouds_high@lod0" "clouds_high_rm@lod0" "clouds_high_rm P_space 1280 720" "direct32x8"; do
-  tools/ab_bench.sh "$wl" base th4
-done
+for wl in clouds_high clouds_high_rm direct32x8; do for m in orbit:1 orbit:5 pan:1; do
+  A=""; B=""
+  for r in 1 2 3; do for v in base oc32; do
+    if [ $v = base ]; then unset ATMO_HIP_LIB; else export ATMO_HIP_LIB=$PWD/godot_atmosphere_shader_amd/libatmo_hip_$v.so; fi
+    ms=$(ATMO_BENCH_DETAIL= python bench.py --workload $wl --motion $m --steps 128 --warmup 16 --no-cpu-baseline --also "" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('%.4f' % d['ms_per_step'])")
+    if [ $v = base ]; then A="$A $ms"; else B="$B $ms"; fi
+  done; done
+  unset ATMO_HIP_LIB
+  echo "$wl --motion $m   64 classes:$A   32 classes:$B"
+done; done
