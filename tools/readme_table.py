@@ -65,7 +65,7 @@ def readme_rows():
         "| same, 3840x2160": f"| same, 3840x2160 | {pair('direct32x8@3840x2160')} | {ms('direct32x8@3840x2160')} | {vr(ex['direct32x8@3840x2160'])} | at the modelled issue floor |",
         "| `no_clouds`, 32 view steps, baked-LUT light": f"| `no_clouds`, 32 view steps, baked-LUT light (the reference's algorithm) | {pair('lut32')} | {ms('lut32', 4)} | {vr(ex['lut32'])} | |",
         "| `no_clouds` as shipped": f"| `no_clouds` as shipped (8 view steps, LUT) | {pair('shipped8')} | {ms('shipped8', 4)} | {vr(ex['shipped8'])} | a 20 us draw; `atmo_set_target_cleared`: {g(ek['shipped8@cleared'][0])} / {g(ex['shipped8@cleared']['Mrays/s'])} |",
-        "| **`clouds_high` 1920x1080 (configs[2])": f"| **`clouds_high` 1920x1080 (configs[2]), declared sampler (default)** | {bold_pair('clouds_high')} | {ms('clouds_high')} | {vr(ex['clouds_high'])} | round 5: 11 900 (0.174 ms): the march's lambda in the oracle's operations +3.8 %, the shape volume's float copy -3.6 % (both interleaved A/B) |",
+        "| **`clouds_high` 1920x1080 (configs[2])": f"| **`clouds_high` 1920x1080 (configs[2]), declared sampler (default)** | {bold_pair('clouds_high')} | {ms('clouds_high')} | {vr(ex['clouds_high'])} | round 5: 11 900 (0.174 ms): the march's lambda in the oracle's operations +3.8 %, the shape volume's float copy -3.6 %, the tile order's 64 cost classes -3.7 % (each an interleaved A/B) |",
         "| `clouds_high@lod0` |": f"| `clouds_high@lod0` | {pair('clouds_high@lod0')} | {ms('clouds_high@lod0')} | {vr(ex['clouds_high@lod0'])} | |",
         "| `clouds_high_rm` 1920x1080 (raymarched cloud light)": f"| `clouds_high_rm` 1920x1080 (raymarched cloud light), declared sampler | {pair('clouds_high_rm')} | {ms('clouds_high_rm')} | {vr(ex['clouds_high_rm'])} | bound by its tail; under a moving camera see below |",
         "| `clouds_high_rm@lod0` 1920x1080": f"| `clouds_high_rm@lod0` 1920x1080 | {pair('clouds_high_rm@lod0')} | {ms('clouds_high_rm@lod0')} | {vr(ex['clouds_high_rm@lod0'])} | |",
