@@ -43,6 +43,9 @@ def dilate(cost):
     return out
 
 
+SHIFT_ARMS = bool(os.environ.get("PROBE_SHIFT_ARMS"))
+
+
 def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "clouds_high_rm"
     deg = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
@@ -65,7 +68,7 @@ def main():
         costs.append(cost.astype(np.int64))
     for _ in range(30):   # clocks
         node.render_prepared(frames[0], depths[0].data_ptr(), out.data_ptr(), stream)
-    rows = []
+    rows, shift_rows = [], []
     for k in range(1, n):
         def order_of(c):
             flat = c.reshape(-1)
@@ -73,7 +76,32 @@ def main():
         o_perf, o_lag, o_lagd = order_of(costs[k]), order_of(costs[k - 1]), order_of(dilate(costs[k - 1]))
         t_none = timed(lambda: node.render_prepared(frames[k], depths[k].data_ptr(), out.data_ptr(), stream))
         t = {}
-        for name, o in (("perfect", o_perf), ("lag1", o_lag), ("lag1+d", o_lagd)):
+        arms = [("perfect", o_perf), ("lag1", o_lag), ("lag1+d", o_lagd)]
+        if SHIFT_ARMS and k >= 3:
+            # round 6 (later): a THREE-frame-old cost map (the side-stream sort's real lag), as it is, under a window as wide as the planet centre's motion
+            # over those frames, and TRANSLATED by that motion (the centre projected through both cameras; whole tiles) with and without a one-tile window
+            def centre_px(cam):
+                v = cam.projection @ (cam.view @ np.array([0.0, 0.0, 0.0, 1.0]))
+                return np.array([(v[0] / v[3] * 0.5 + 0.5) * w, (1.0 - (v[1] / v[3] * 0.5 + 0.5)) * h])
+            d = centre_px(cams[k]) - centre_px(cams[k - 3])
+            tx_, ty_ = int(round(d[0] / tw)), int(round(d[1] / th))
+            old = costs[k - 3]
+            def window(c, rx, ry):
+                pd = np.pad(c, ((ry, ry), (rx, rx)), mode="edge")
+                o = c.copy()
+                for dy in range(2 * ry + 1):
+                    for dx in range(2 * rx + 1):
+                        o = np.maximum(o, pd[dy:dy + c.shape[0], dx:dx + c.shape[1]])
+                return o
+            shifted = np.zeros_like(old)
+            H_, W_ = old.shape
+            ys, xs = np.mgrid[0:H_, 0:W_]
+            sy, sx = ys - ty_, xs - tx_
+            ok = (sy >= 0) & (sy < H_) & (sx >= 0) & (sx < W_)
+            shifted[ok] = old[sy[ok], sx[ok]]
+            arms += [("lag3", order_of(old)), ("lag3+w", order_of(window(old, abs(tx_) + 1, abs(ty_) + 1))), ("lag3 shifted", order_of(shifted)),
+                     ("lag3 shifted+d", order_of(dilate(shifted)))]
+        for name, o in arms:
             t[name] = timed(lambda: node.render_tiles_prepared(frames[k], depths[k].data_ptr(), out.data_ptr(), o.data_ptr(), o.numel(), stream))
         # mis-ranking: rank (in the previous frame's order) of this frame's heaviest 5 %
         flat_k, flat_p = costs[k].reshape(-1), costs[k - 1].reshape(-1)
@@ -83,6 +111,8 @@ def main():
         late = rank_prev[top] / flat_p.size
         rows.append((t_none, t["perfect"], t["lag1"], t["lag1+d"], float(np.median(late)), float(np.percentile(late, 95)), float(late.max()),
                      float(np.corrcoef(flat_k, flat_p)[0, 1])))
+        if SHIFT_ARMS and k >= 3:
+            shift_rows.append((t["lag3"], t["lag3+w"], t["lag3 shifted"], t["lag3 shifted+d"]))
     r = np.array(rows)
     node.close()
     # the library's own path on the SAME frames: a context with the tile-order feedback on, the sequence drawn frame by frame (forwards, then again: the
@@ -103,6 +133,9 @@ def main():
     lib = float(np.median(lib_ms[1:]))
     print(f"{wl} {w}x{h} {kind} {deg:g} deg/frame, {n - 1} frames, kernel ms per frame (median over the frames; each frame best of 3), heavy-tile split off:")
     print(f"   row-major {np.median(r[:, 0]):.4f}   perfect order {np.median(r[:, 1]):.4f}   previous frame's order {np.median(r[:, 2]):.4f}   ... with a one-tile window {np.median(r[:, 3]):.4f}")
+    if shift_rows:
+        q = np.median(np.array(shift_rows), axis=0)
+        print(f"   a 3-frame-old cost map: as it is {q[0]:.4f}   under a window as wide as the planet centre's motion {q[1]:.4f}   TRANSLATED by that motion {q[2]:.4f}   ... and a one-tile window {q[3]:.4f}")
     print(f"   the library's own path (feedback on, frame by frame, incl. its in-stream sort kernels) {lib:.4f}   {stats}")
     print(f"   this frame's heaviest 5 % of the tiles in the previous frame's order: median position {np.median(r[:, 4]) * 100:.1f} % of the list, 95th percentile {np.median(r[:, 5]) * 100:.1f} %, "
           f"last one {np.median(r[:, 6]) * 100:.1f} %; correlation of consecutive cost maps {np.median(r[:, 7]):.3f}")
