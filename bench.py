@@ -588,6 +588,12 @@ def time_workload(torch, node, cam, depth, steps, warmup, out=None, sequence=Non
 
     def timed(n):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if os.environ.get("ATMO_BENCH_LAZY_EVENTS") != "1":
+            # torch creates the hipEvent behind an Event at its first record(): inside the region that is host time in front of the first launch with the GPU
+            # idle (round 6: the K = 20 region carried ~40 us beyond its kernels).  Record both once, outside, so the region's own records reuse them.
+            e0.record()
+            e1.record()
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         e0.record()  # on torch's current stream = the stream the kernels are launched on
         draw(n)
