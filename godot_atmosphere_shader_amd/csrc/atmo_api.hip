@@ -160,6 +160,16 @@ struct AtmoContext {
         unsigned long long last_use = 0;
         bool dirty = false;            // released by atmo_set_tile_feedback with work possibly in flight: quiesced when the slot is taken again
     };
+    // the geometric tile order of the cloudless variants (RenderConsts::geo_rows; geo_order_fill): the last frame's table, reused while the camera stands still
+    struct GeoCache {
+        float key[26] = {0};
+        int rows = -1;                      // -1: nothing cached; 0: this camera has no usable table
+        uint16_t prefix[atmo::GEO_MAX_ROWS + 1];
+        uint8_t first[atmo::GEO_MAX_ROWS];
+        uint16_t hint[2][atmo::GEO_MAX_HINTS + 2];
+    } geo;
+    int geo_order = 1;                                 // ATMO_GEO_ORDER=0 (A/B): the learnt order for these variants, as in rounds 2-5
+    unsigned geo_draws = 0;
     static constexpr int FB_SLOTS = 4;
     FeedbackState fb[FB_SLOTS];
     unsigned long long fb_clock = 0;
@@ -830,6 +840,7 @@ int atmo_create(int device, int variant, int view_steps, int cloud_steps, int li
     if (const char *ev = std::getenv("ATMO_HEAVY_SPLIT_TRIGGER_MOVING")) ctx->heavy_split_trigger_moving = (float)std::atof(ev);
     if (const char *ev = std::getenv("ATMO_DRAW_EVENTS")) ctx->draw_events = ev[0] == '0' ? 0 : (ev[0] == '2' ? 2 : 1);
     if (const char *ev = std::getenv("ATMO_TARGET_CLEARED")) ctx->target_cleared = ev[0] == '1' ? 1 : 0;  // tools/ab_env.sh: atmo_set_target_cleared
+    if (const char *ev = std::getenv("ATMO_GEO_ORDER")) ctx->geo_order = ev[0] == '0' ? 0 : 1;
     if (const char *ev = std::getenv("ATMO_FB_INSTREAM")) ctx->instream = ev[0] >= '1' && ev[0] <= '2' ? ev[0] - '0' : 0;  // 2 (A/B): every cloud and direct-light kernel
     if (const char *ev = std::getenv("ATMO_FB_AXIS_WINDOWS")) ctx->fb_axis_windows = ev[0] == '1' ? 1 : 0;
     if (const char *ev = std::getenv("ATMO_FB_REACH_SCALE")) ctx->env_reach_scale = (float)std::atof(ev);
@@ -1288,6 +1299,81 @@ int atmo_render_composite(AtmoContext *ctx, const AtmoFrame *frame, const float 
     return render_impl(ctx, frame, depth_dev, scene_rgba_dev, stream, true);
 }
 
+// The geometric tile order of a cloudless frame seen from outside the atmosphere shell (rc.miss_k > 0: the projection's ray directions do not depend on depth and
+// the camera is well outside): fills rc.geo_rows / geo_prefix / geo_first, or leaves geo_rows = 0 (taller or wider grids than the table holds, a silhouette that is
+// not one run of columns per row, nothing or everything hit).  The view ray through pixel (x, y) is a(x) = A x + B(y), affine; shade_pixel's sure-miss test
+// (c.a)^2 < k |a|^2 is a quadratic in x on every pixel row: the rays that can hit lie between its roots.  A tile row takes the union over its first, middle and
+// last pixel row.  The ORDER depends on this arithmetic, the picture does not.
+static void geo_order_fill(AtmoContext *ctx, atmo::RenderConsts &rc, int gx, int gy, int tile_h) {
+    if (gy > atmo::GEO_MAX_ROWS || gx > 255 || (long long)gx * gy > 65535) return;
+    AtmoContext::GeoCache &g = ctx->geo;
+    float key[26];
+    for (int i = 0; i < 16; ++i) key[i] = rc.inv_p[i];
+    key[16] = rc.center[0]; key[17] = rc.center[1]; key[18] = rc.center[2]; key[19] = rc.miss_k;
+    key[20] = (float)rc.x0; key[21] = (float)rc.y0; key[22] = (float)rc.x1; key[23] = (float)rc.y1; key[24] = (float)(gx * 1024 + tile_h); key[25] = rc.rcp_vw + 3.0f * rc.rcp_vh;
+    if (g.rows < 0 || std::memcmp(key, g.key, sizeof key) != 0) {
+        std::memcpy(g.key, key, sizeof key);
+        g.rows = 0;
+        const double *nul = nullptr; (void)nul;
+        const float *Q = rc.inv_p;
+        const double sx = 2.0 * rc.rcp_vw, ox = 0.5 * sx - 1.0, sy = 2.0 * rc.rcp_vh, oy = 0.5 * sy - 1.0, k = rc.miss_k;
+        const double c[3] = {rc.center[0], rc.center[1], rc.center[2]};
+        const double A[3] = {Q[0] * sx, Q[1] * sx, Q[2] * sx};
+        const double cA = c[0] * A[0] + c[1] * A[1] + c[2] * A[2], AA = A[0] * A[0] + A[1] * A[1] + A[2] * A[2];
+        const double alpha = cA * cA - k * AA;
+        bool ok = alpha < 0.0;   // an ellipse-like silhouette along the rows; anything else: no table
+        unsigned total = 0;
+        for (int r = 0; ok && r < gy; ++r) {
+            const int py0 = rc.y0 + r * tile_h, py1 = std::min(py0 + tile_h, (int)rc.y1) - 1;
+            const int ys[3] = {py0, (py0 + py1) >> 1, py1};
+            double lo = 1e30, hi = -1e30;
+            for (int q = 0; q < 3; ++q) {
+                const double fny = ys[q] * sy + oy;
+                const double B[3] = {Q[0] * ox + Q[4] * fny + Q[12], Q[1] * ox + Q[5] * fny + Q[13], Q[2] * ox + Q[6] * fny + Q[14]};
+                const double cB = c[0] * B[0] + c[1] * B[1] + c[2] * B[2];
+                const double AB = A[0] * B[0] + A[1] * B[1] + A[2] * B[2], BB = B[0] * B[0] + B[1] * B[1] + B[2] * B[2];
+                const double beta = 2.0 * (cA * cB - k * AB), gamma = cB * cB - k * BB;
+                const double disc = beta * beta - 4.0 * alpha * gamma;
+                if (!(disc >= 0.0)) continue;                       // this pixel row misses everywhere
+                const double sq = std::sqrt(disc), x1 = (-beta + sq) / (2.0 * alpha), x2 = (-beta - sq) / (2.0 * alpha);   // alpha < 0: x1 <= x2
+                if (!(cA * 0.5 * (x1 + x2) + cB > 0.0)) continue;   // the cone BEHIND the camera
+                lo = std::min(lo, x1);
+                hi = std::max(hi, x2);
+            }
+            int first = 0, len = 0;
+            if (lo <= hi && hi >= (double)rc.x0 && lo <= (double)(rc.x1 - 1)) {
+                const int c0 = (int)std::floor((std::max(lo, (double)rc.x0) - rc.x0) / 16.0), c1 = (int)std::floor((std::min(hi, (double)(rc.x1 - 1)) - rc.x0) / 16.0);
+                first = std::min(std::max(c0, 0), gx - 1);
+                len = std::min(std::max(c1, first), gx - 1) - first + 1;
+            }
+            g.prefix[r] = (uint16_t)total;
+            g.first[r] = (uint8_t)first;
+            total += (unsigned)len;
+        }
+        if (ok && total > 0 && total < (unsigned)(gx * gy)) {
+            g.prefix[gy] = (uint16_t)total;
+            g.rows = gy;
+            // hint[0][v]: the last row whose prefix is <= 256 v; hint[1][v]: the last row with r gx - prefix[r] (all-miss tiles above it) <= 256 v.  Both sequences
+            // are non-decreasing in r: one merge pass each.  Entries beyond the last block repeat the last row.
+            for (int part = 0; part < 2; ++part) {
+                int r = 0;
+                for (int v = 0; v < atmo::GEO_MAX_HINTS + 2; ++v) {
+                    const unsigned lim = 256u * (unsigned)v;
+                    while (r + 1 <= gy && (part == 0 ? (unsigned)g.prefix[r + 1] : (unsigned)((r + 1) * gx) - g.prefix[r + 1]) <= lim) ++r;
+                    g.hint[part][v] = (uint16_t)r;
+                }
+            }
+        }
+    }
+    if (g.rows > 0) {
+        rc.geo_rows = g.rows;
+        std::memcpy(rc.geo_prefix, g.prefix, (size_t)(g.rows + 1) * sizeof(uint16_t));
+        std::memcpy(rc.geo_first, g.first, (size_t)g.rows * sizeof(uint8_t));
+        std::memcpy(rc.geo_hint, g.hint, sizeof g.hint);
+    }
+}
+
+
 int atmo_render_tiles(AtmoContext *ctx, const AtmoFrame *frame, const float *depth_dev, float *rgba_dev, const uint32_t *tiles_dev, int n_tiles,
                       void *stream) {
     if (!ctx) return ATMO_E_ARG;
@@ -1414,6 +1500,7 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     if (ctx->measure_cost) feedback = false;  // a measuring draw: plain row-major launch that records into the caller's buffer
     if (tiles_dev) feedback = false;          // a tile-list draw: the caller's order
     if (feedback && (long long)gx * gy < 512) feedback = false;  // tiny launches: nothing to schedule
+    const bool geo_policy = feedback;   // (also inside a graph capture: the geometric order enqueues nothing of its own)
     if (feedback) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) feedback = false;  // no side-stream work inside a graph
@@ -1529,6 +1616,19 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         }
     }
     if (ctx->measure_cost) rc.tile_cost = ctx->measure_cost;
+    // The direct-light cloudless kernels seen from outside the shell, when the learnt order has nothing for this draw -- a camera that moves too fast for it (a pan:
+    // the silhouette slides a tile per frame), the first draws of a key, a draw inside a graph capture: the order is a closed form of the camera
+    // (RenderConsts::geo_rows), looked up by the kernel's preamble.  That lookup costs every wave ~9 dependent scalar loads (+5 us on a 1920x1080 draw), which the
+    // learnt order does not: so only where there is no learnt order (profiles/round6/geo_order.txt: under a pan 0.1046 -> 0.0979 ms; with it always on a still
+    // camera loses 6 %, and the 20-50 us LUT kernels lose under every motion).
+    if (geo_policy && ctx->geo_order && rc.tile_order == nullptr && (flags & (atmo::KF_CLOUDS | atmo::KF_LIGHT_DIRECT)) == atmo::KF_LIGHT_DIRECT &&
+        rc.miss_k > 0.0f && split == 1) {
+        geo_order_fill(ctx, rc, gx, gy, (rc.y1 - rc.y0 + gy - 1) / gy);
+        if (rc.geo_rows > 0) {
+            ctx->geo_draws += 1;
+            ctx->fb_ordered_draws += 1;
+        }
+    }
     // kernel timing brackets the draw kernel alone (the tile-order kernel runs beside the previous draw).  The event pair
     // is owned by a guard until it is handed to ctx->pending, so no error path leaks it.
     struct EventPair {

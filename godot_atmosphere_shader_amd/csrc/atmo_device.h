@@ -11,6 +11,8 @@ namespace atmo {
 // argument, so every field lands in SGPRs through scalar loads of the kernarg segment.
 // Values marked [host] are per-frame expressions of the reference shader that do not depend on the
 // pixel; the API evaluates them once in fp32, in the reference's operation order.
+constexpr int GEO_MAX_ROWS = 272;   // tile rows the geometric order covers: 3840 x 2160 in 8-pixel rows (taller grids: the learnt order)
+constexpr int GEO_MAX_HINTS = 256;  // ... and 65 536 tiles, one hint per 256 blocks
 struct RenderConsts {
     // --- atmosphere_fragment prologue (shaders/include/planet_atmosphere_main.gdshaderinc:128-169)
     float inv_p[16];
@@ -89,6 +91,17 @@ struct RenderConsts {
     int32_t gx0, gy0;               // [host] viewport pixel of the launch grid's first tile: (x0, y0), rounded down to even for the declared-sampler kernels
     int32_t store_discards;         // 1: a discarded fragment stores (0,0,0,0); 0: it stores nothing (composite, or atmo_set_target_cleared)
     int32_t cost_rows_halved;       // 1: this launch draws HEAVY tiles of a one-lane grid as pairs of half-height tiles (render_impl's split path): tile_cost is indexed by the one-lane tile
+    // --- the GEOMETRIC tile order of the cloudless variants (round 6; geo_tile in atmo_kernels.hip, geo_order_fill in atmo_api.hip).  Seen from outside the
+    // atmosphere shell the tiles whose rays can hit it form ONE run of columns per tile row -- the shell's silhouette is a conic --, so "the tiles that shade
+    // first, row-major, the all-miss tiles behind them" is a closed-form map from the block index to the tile: no order buffer, no recording draw, no sort,
+    // nothing learnt from earlier frames and therefore nothing that lags behind a moving camera.  geo_rows = 0: off (tile = block index, or tile_order).
+    int32_t geo_rows;                           // [host] tile rows of the launch grid, or 0
+    uint16_t geo_prefix[GEO_MAX_ROWS + 1];      // [host] geo_prefix[r] = tiles that can shade in the rows above r; [geo_rows] = all of them
+    uint8_t geo_first[GEO_MAX_ROWS];            // [host] first column of row r's run (its length: geo_prefix[r + 1] - geo_prefix[r])
+    // where to start looking: geo_hint[0][v] = the last row r with geo_prefix[r] <= 256 v (blocks of the first part), geo_hint[1][v] = the last row r with
+    // r tiles_x - geo_prefix[r] <= 256 v (blocks of the second part) -- the row of block b then lies in [hint[b >> 8], hint[(b >> 8) + 1]]: one or two steps of a
+    // binary search instead of nine (every step is a dependent scalar load in every wave's preamble)
+    uint16_t geo_hint[2][GEO_MAX_HINTS + 2];
 };
 
 struct BakeConsts {

@@ -1175,7 +1175,7 @@ __device__ __forceinline__ float4 march_atmosphere(const RenderConsts &rc, V3 di
     // (at the right position the capped build is exactly as fast as this one: the eighth wave buys nothing).  tests/test_host_logic.py holds the position
     // (tools/loop_phase.py reads it from the built library); if a change to the code in front of the loop moves it, ATMO_LOOP_PAD = the number of s_nop that puts it back.
 #ifndef ATMO_LOOP_PAD
-#define ATMO_LOOP_PAD 0
+#define ATMO_LOOP_PAD 0   // (the geometric tile order's first form in the preamble needed 1; with its hint tables the loop is back on 12 mod 32 by itself)
 #endif
 #if ATMO_LOOP_PAD > 0
 #define ATMO_STR2(x) #x
@@ -2177,6 +2177,27 @@ constexpr bool render_sgpr_cap80(int flags) {
 #define ATMO_TRACE_ENTRY
 #define ATMO_SHADE_TRACED shade_pixel<FLAGS, LSTEPS, SPLIT>(rc, (int)tile_x, (int)tile_y);
 #endif
+// The geometric tile order (RenderConsts::geo_rows; cloudless kernels): block b shades the b-th tile of "the tiles that can shade, row-major, then the others,
+// row-major".  Uniform: scalar ALU and scalar loads from the kernel-argument segment only (a hint per 256 blocks, then one or two steps of a binary search).
+__device__ __forceinline__ uint32_t geo_tile(const RenderConsts &rc, uint32_t b) {
+    const uint32_t rows = (uint32_t)rc.geo_rows, tx = (uint32_t)rc.tiles_x, total = rc.geo_prefix[rows];
+    if (b < total) {                       // largest row r with geo_prefix[r] <= b, between the two hints around b
+        uint32_t lo = rc.geo_hint[0][b >> 8], hi = min((uint32_t)rc.geo_hint[0][(b >> 8) + 1] + 1u, rows);
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (rc.geo_prefix[mid] <= b) lo = mid; else hi = mid;
+        }
+        return lo * tx + rc.geo_first[lo] + (b - rc.geo_prefix[lo]);
+    }
+    const uint32_t m = b - total;           // index among the tiles that cannot shade: row r holds r tx - geo_prefix[r] of them above it
+    uint32_t lo = rc.geo_hint[1][m >> 8], hi = min((uint32_t)rc.geo_hint[1][(m >> 8) + 1] + 1u, rows);
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (mid * tx - rc.geo_prefix[mid] <= m) lo = mid; else hi = mid;
+    }
+    const uint32_t o = m - (lo * tx - rc.geo_prefix[lo]), first = rc.geo_first[lo], len = rc.geo_prefix[lo + 1] - rc.geo_prefix[lo];
+    return lo * tx + (o < first ? o : o + len);
+}
 // Keep this preamble exactly as it is for every variant.  Measured on the direct-light kernel (same loop ISA in all
 // three builds, profiles/round2/ab_direct_kernel.txt): this form 0.108-0.109 ms; a branch on tile_order in front of
 // the division 0.115 ms; NO preamble at all (blockIdx used directly) 0.115 ms as well.  Round 2 read that as "the scalar work in
@@ -2186,6 +2207,9 @@ constexpr bool render_sgpr_cap80(int flags) {
 #define ATMO_RENDER_KERNEL_BODY                                                                                  \
     ATMO_TRACE_ENTRY                                                                                             \
     uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;                                                         \
+    if constexpr ((FLAGS & KF_CLOUDS) == 0) {                                                                    \
+        if (rc.geo_rows > 0) tile = geo_tile(rc, tile);                                                          \
+    }                                                                                                            \
     if (rc.tile_order != nullptr) tile = rc.tile_order[tile];                                                    \
     const uint32_t tile_y = tile / (uint32_t)rc.tiles_x, tile_x = tile - tile_y * (uint32_t)rc.tiles_x;          \
     uint64_t t0 = 0;                                                                                             \

@@ -1565,6 +1565,48 @@ def test_moving_camera_sequence_is_identical_with_feedback_on_and_off():
         off.close()
 
 
+def test_geometric_tile_order_draws_every_tile_exactly_once():
+    """Round 6: the direct-light cloudless kernels, seen from outside the atmosphere shell, take their tile order from the camera in closed form where the learnt
+    order has nothing for a draw (RenderConsts::geo_rows: the tiles that can shade first, the others behind them) -- a map from the block index to the tile that must
+    be a PERMUTATION of the launch grid whatever the silhouette does.  Drawn into a buffer full of NaN and compared with the row-major draw: sizes up to the table's limit, odd sizes, rects, the planet sliding
+    off the screen under a pan, the limb, and poses where the table must NOT engage (inside the shell).  The order is engaged where it can be."""
+    import bench
+
+    tex, params = demo_textures(), demo_params()
+    D = "no_clouds_32x8_direct"
+    cases = [(D, 1920, 1080, "P_space", None), ("no_clouds_8", 1920, 1080, "P_space", None), (D, 1280, 720, "P_limb", None),
+             (D, 3840, 2160, "P_space", None), (D, 1001, 701, "P_space", None), (D, 1920, 1080, "P_space", (333, 77, 1801, 1003)),
+             (D, 1920, 1080, "P_night", None), (D, 1920, 1080, "P_ground", None), (D, 1920, 1080, "P_clouds", None), (D, 640, 360, "P_space", None)]
+    for config_name, w, h, pose, rect in cases:
+        cam = S.Camera.from_pose(w, h, pose)
+        depth = torch.from_numpy(S.depth_ground_sphere(cam)).cuda()
+        on, off = make_node(config_name, tex, params), make_node(config_name, tex, params, tile_feedback=0)
+        want = off.render(cam, depth, rect=rect).clone()
+        frame = on.prepare_frame(cam, rect=rect)
+        out = torch.full_like(want, float("nan"))
+        on.render_prepared(frame, depth.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), (config_name, w, h, pose, rect, int(torch.isnan(out).sum()))
+        # the first draw of a context has no learnt order yet: the direct-light kernel takes the geometric one where the camera is outside the shell
+        assert (on.feedback_stats()["ordered_draws"] == 1) == (config_name == "no_clouds_32x8_direct" and pose not in ("P_ground", "P_clouds")), (config_name, pose, on.feedback_stats())
+        on.close()
+        off.close()
+    # the disc slides across and partly off the screen
+    w, h = 1920, 1080
+    cams = bench.motion_cameras(S, w, h, ("pan", 3.0), 20)
+    on, off = make_node("no_clouds_32x8_direct", tex, params), make_node("no_clouds_32x8_direct", tex, params, tile_feedback=0)
+    for k, cam in enumerate(cams):
+        depth = bench.depth_ground_sphere_torch(torch, S, cam, torch.device("cuda"))
+        want = off.render(cam, depth).clone()
+        out = torch.full_like(want, float("nan"))
+        on.render_prepared(on.prepare_frame(cam), depth.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), k
+    assert on.feedback_stats()["ordered_draws"] == 20, on.feedback_stats()   # every frame of the pan ordered (the learnt order has nothing for any of them)
+    on.close()
+    off.close()
+
+
 def test_bench_depth_on_the_device_matches_the_host_depth():
     """bench.depth_ground_sphere_torch (the --motion loops) states scene.depth_ground_sphere on the GPU."""
     import bench
