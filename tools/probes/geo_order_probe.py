@@ -22,8 +22,9 @@ def main():
     w, h = 1920, 1080
     device = torch.device("cuda", 0)
     n = 64
-    for wl in ("direct32x8", "lut32", "shipped8"):
+    for wl in (os.environ.get("PROBE_WORKLOADS", "direct32x8,lut32,shipped8").split(",")):
         config_name = bench.WORKLOADS[wl][0]
+        n = 64 if "cloud" not in wl else 32
         for motion in (("orbit", 0.0), ("orbit", 1.0), ("pan", 1.0), ("pan", 3.0)):
             cams = bench.motion_cameras(S, w, h, motion, n)
             depths = [bench.depth_ground_sphere_torch(torch, S, c, device) for c in cams]
