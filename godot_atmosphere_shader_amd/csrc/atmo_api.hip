@@ -1314,7 +1314,6 @@ static void geo_order_fill(AtmoContext *ctx, atmo::RenderConsts &rc, int gx, int
     if (g.rows < 0 || std::memcmp(key, g.key, sizeof key) != 0) {
         std::memcpy(g.key, key, sizeof key);
         g.rows = 0;
-        const double *nul = nullptr; (void)nul;
         const float *Q = rc.inv_p;
         const double sx = 2.0 * rc.rcp_vw, ox = 0.5 * sx - 1.0, sy = 2.0 * rc.rcp_vh, oy = 0.5 * sy - 1.0, k = rc.miss_k;
         const double c[3] = {rc.center[0], rc.center[1], rc.center[2]};

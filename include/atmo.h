@@ -285,7 +285,7 @@ int atmo_set_target_cleared(AtmoContext *ctx, int cleared);
  * miss the planet, clear sky) into that drain: direct light 32x8 +9.7 %, clouds_high +5 %, clouds_high_rm +49 %
  * (its heaviest tiles are ~10x the mean), baked-LUT atmosphere +4..5 %; within +-1.5 % on frames whose tiles all weigh
  * the same (profiles/round2/ab_tile_feedback.txt).  The picture does not depend on the order.
- * -1 (default) = on; 0 = off; 1 = on.  Launches inside a HIP graph capture never use it.
+ * -1 (default) = on; 0 = off; 1 = on.  Launches inside a HIP graph capture never use the LEARNT order (see the last paragraph).
  * Host-side waits: none since round 5 in a host whose draws and texture updates use different streams or the null stream.  Changing the
  * mode never waits (a state with work in flight is handed to its next owner behind that work, on the device); a FIFTH distinct (rect
  * grid, stream) pair while four are cached recycles the least recently used state (at most 8 times in a row, then such draws simply run
@@ -301,6 +301,10 @@ int atmo_set_target_cleared(AtmoContext *ctx, int cleared);
  * draw stream itself, one frame of lag), and falls back to the row-major launch when the picture moves faster than a cost
  * map stays meaningful -- so two different views alternating on ONE (grid, stream) key (stereo eyes) look like a fast camera
  * and get no reordering: give each eye its own stream or context.
+ * Round 6: a draw of the direct-light cloudless kernels that has no learnt order (such a fast camera, the first draws of a key, a draw inside a
+ * graph capture) is ordered anyway while the camera is outside the atmosphere shell -- from the camera alone: the tiles whose rays can hit the
+ * shell form one run of columns per tile row, passed by value with the kernel arguments (no buffer, no extra launch, nothing to wait for; a
+ * captured draw replays with the table it was captured with).  Mode 0 turns that off as well.
  */
 int atmo_set_tile_feedback(AtmoContext *ctx, int mode);
 
