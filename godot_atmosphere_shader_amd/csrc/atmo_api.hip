@@ -1620,10 +1620,11 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
     // (RenderConsts::geo_rows), looked up by the kernel's preamble.  That lookup costs every wave ~9 dependent scalar loads (+5 us on a 1920x1080 draw), which the
     // learnt order does not: so only where there is no learnt order (profiles/round6/geo_order.txt: under a pan 0.1046 -> 0.0979 ms; with it always on a still
     // camera loses 6 %, and the 20-50 us LUT kernels lose under every motion).
-    if (geo_policy && ctx->geo_order && rc.tile_order == nullptr && (flags & (atmo::KF_CLOUDS | atmo::KF_LIGHT_DIRECT)) == atmo::KF_LIGHT_DIRECT &&
-        rc.miss_k > 0.0f && split == 1) {
+    int launch_flags = flags;
+    if (geo_policy && ctx->geo_order && rc.tile_order == nullptr && flags == atmo::KF_LIGHT_DIRECT && rc.miss_k > 0.0f && split == 1) {
         geo_order_fill(ctx, rc, gx, gy, (rc.y1 - rc.y0 + gy - 1) / gy);
         if (rc.geo_rows > 0) {
+            launch_flags |= atmo::KF_GEO;   // the twin kernel whose preamble looks the tile up (the plain kernel's preamble stays what it was)
             ctx->geo_draws += 1;
             ctx->fb_ordered_draws += 1;
         }
@@ -1731,7 +1732,7 @@ static int render_impl(AtmoContext *ctx, const AtmoFrame *frame, const float *de
         ctx->split_draws += 1;
         ctx->split_tiles_last = (unsigned)heavy;
     } else {
-        HIP_TRY(ctx, atmo::launch_render(flags, split, rc, s, tiles_dev ? n_tiles : 0));
+        HIP_TRY(ctx, atmo::launch_render(launch_flags, split, rc, s, tiles_dev ? n_tiles : 0));
     }
     ctx->last_flags = flags;
     if (fb_record) {

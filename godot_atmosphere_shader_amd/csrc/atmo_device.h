@@ -122,7 +122,9 @@ struct NoiseCubemapConsts {
 // kernel launchers (atmo_kernels.hip)
 enum KernelFlags : int { KF_CLOUDS = 1, KF_CLOUD_LIGHT_RM = 2, KF_LIGHT_DIRECT = 4, KF_LITE = 8, KF_PRECISE = 16, KF_CUBE_LOD = 32,
                           KF_ATMO_REF = 64 /* the v2 atmosphere march in the reference's operation order (atmo_set_precision 2) */,
-                          KF_VIEW_POS = 128 /* view_steps > 32: the fast v2 march accumulates the view-space position like the reference (march_atmosphere<VIEWPOS>) */ };
+                          KF_VIEW_POS = 128 /* view_steps > 32: the fast v2 march accumulates the view-space position like the reference (march_atmosphere<VIEWPOS>) */,
+                          KF_GEO = 256 /* the block -> tile map is the geometric order's closed form (RenderConsts::geo_rows): a twin of the plain direct-light kernel, so that
+                                          the draws that do not use it keep their preamble to the byte (the lookup compiled in cost a still camera 0.6 %) */ };
 
 hipError_t launch_render(int flags, int split, const RenderConsts &rc, hipStream_t stream, int tile_list_blocks = 0);  // > 0: rc.tile_order lists that many tiles of the rect's grid
 hipError_t launch_bake(const BakeConsts &bc, hipStream_t stream);

@@ -2198,6 +2198,12 @@ __device__ __forceinline__ uint32_t geo_tile(const RenderConsts &rc, uint32_t b)
     const uint32_t o = m - (lo * tx - rc.geo_prefix[lo]), first = rc.geo_first[lo], len = rc.geo_prefix[lo + 1] - rc.geo_prefix[lo];
     return lo * tx + (o < first ? o : o + len);
 }
+#ifndef ATMO_LOOP_PAD_GEO   // s_nop in front of shade_pixel in the twin kernels <4 | KF_GEO, 8, 1>: puts their view loop 12 bytes into a 32-byte block
+#define ATMO_LOOP_PAD_GEO 6
+#endif
+#define ATMO_GEO_STR2(x) #x
+#define ATMO_GEO_STR(x) ATMO_GEO_STR2(x)
+#define ATMO_GEO_PAD_STR ATMO_GEO_STR(ATMO_LOOP_PAD_GEO)
 // Keep this preamble exactly as it is for every variant.  Measured on the direct-light kernel (same loop ISA in all
 // three builds, profiles/round2/ab_direct_kernel.txt): this form 0.108-0.109 ms; a branch on tile_order in front of
 // the division 0.115 ms; NO preamble at all (blockIdx used directly) 0.115 ms as well.  Round 2 read that as "the scalar work in
@@ -2207,8 +2213,10 @@ __device__ __forceinline__ uint32_t geo_tile(const RenderConsts &rc, uint32_t b)
 #define ATMO_RENDER_KERNEL_BODY                                                                                  \
     ATMO_TRACE_ENTRY                                                                                             \
     uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;                                                         \
-    if constexpr ((FLAGS & KF_CLOUDS) == 0) {                                                                    \
-        if (rc.geo_rows > 0) tile = geo_tile(rc, tile);                                                          \
+    if constexpr ((FLAGS & KF_GEO) != 0) {   /* the twin kernels of the geometric order only: render_impl launches them with a table */ \
+        tile = geo_tile(rc, tile);                                                                               \
+        /* ... and their view loop on ITS fast position (march_atmosphere; tools/loop_phase.py reads both kernels) */ \
+        asm volatile(".rept " ATMO_GEO_PAD_STR "\n\ts_nop 0\n\t.endr");                                          \
     }                                                                                                            \
     if (rc.tile_order != nullptr) tile = rc.tile_order[tile];                                                    \
     const uint32_t tile_y = tile / (uint32_t)rc.tiles_x, tile_x = tile - tile_y * (uint32_t)rc.tiles_x;          \
@@ -2776,6 +2784,8 @@ static hipError_t launch_render_grid(int flags, int split, const RenderConsts &r
     switch (flags) {
     case 0: return launch_t<0, 0>(rc, split, stream);
     case KF_LIGHT_DIRECT: return launch_direct<KF_LIGHT_DIRECT>(rc, split, stream);
+    case KF_LIGHT_DIRECT | KF_GEO:   // (one lane per ray; render_impl has filled rc.geo_rows)
+        return rc.light_steps == 8 ? launch_s<KF_LIGHT_DIRECT | KF_GEO, 8, 1>(rc, stream) : launch_s<KF_LIGHT_DIRECT | KF_GEO, 0, 1>(rc, stream);
     case KF_CLOUDS: return launch_t<KF_CLOUDS, 0>(rc, split, stream);
     case KF_CLOUDS | KF_LIGHT_DIRECT: return launch_direct<KF_CLOUDS | KF_LIGHT_DIRECT>(rc, split, stream);
     case KF_CLOUDS | KF_CLOUD_LIGHT_RM: return launch_t<KF_CLOUDS | KF_CLOUD_LIGHT_RM, 0>(rc, split, stream);

@@ -560,11 +560,13 @@ def test_headline_view_loop_sits_at_its_fast_position():
         import loop_phase
     finally:
         _sys.path.pop(0)
-    rows = loop_phase.view_loops(build_native())
-    assert len(rows) == 1, rows                      # one kernel matches, with one loop holding the seven-root cluster of the light march
-    name, offset, phase, size = rows[0]
-    assert phase == loop_phase.FAST_PHASE, (f"{name}: the view loop starts {phase} bytes into its 32-byte block (at +0x{offset:x}, {size} bytes); the measured-fast "
-                                            f"position is {loop_phase.FAST_PHASE}: set ATMO_LOOP_PAD to {((loop_phase.FAST_PHASE - phase) % 32) // 4}")
+    lib = build_native()
+    for pattern, knob in (("atmo_render_kernelILi4ELi8ELi1E", "ATMO_LOOP_PAD"), (loop_phase.GEO_TWIN, "ATMO_LOOP_PAD_GEO")):   # ... and its twin behind the geometric order's lookup
+        rows = loop_phase.view_loops(lib, pattern)
+        assert len(rows) == 1, rows                      # one kernel matches, with one loop holding the seven-root cluster of the light march
+        name, offset, phase, size = rows[0]
+        assert phase == loop_phase.FAST_PHASE, (f"{name}: the view loop starts {phase} bytes into its 32-byte block (at +0x{offset:x}, {size} bytes); the measured-fast "
+                                                f"position is {loop_phase.FAST_PHASE}: move {knob} by {((loop_phase.FAST_PHASE - phase) % 32) // 4}")
 
 
 # ---- round 5: the host side of the C ABI without a device (atmo_debug_create_host_only; also what `make sanitize-host` runs) ---------------

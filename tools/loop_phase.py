@@ -50,7 +50,10 @@ def view_loops(lib, pattern="atmo_render_kernelILi4ELi8ELi1E"):
         return rows
 
 
+GEO_TWIN = "atmo_render_kernelILi260ELi8ELi1E"   # <KF_LIGHT_DIRECT | KF_GEO, 8, 1>: the same loop behind the geometric order's lookup (ATMO_LOOP_PAD_GEO)
+
+
 if __name__ == "__main__":
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "godot_atmosphere_shader_amd", "libatmo_hip.so")
-    for name, off, phase, size in view_loops(lib, *(sys.argv[2:3])):
+    for name, off, phase, size in (view_loops(lib, sys.argv[2]) if len(sys.argv) > 2 else view_loops(lib) + view_loops(lib, GEO_TWIN)):
         print(f"{name}: view loop at +0x{off:x}, {size} bytes, header {phase} bytes into its 32-byte block ({'the fast position' if phase == FAST_PHASE else 'a SLOW position'})")
